@@ -1,0 +1,976 @@
+/*
+ * ble_oracle.c -- CPU restatement (plain C, fp64) of the Balloon Learning Environment
+ * simulator transition.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP path in
+ * balloon_learning_environment_amd/csrc/.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it, and only as the checker / the timed CPU
+ * baseline.  The product package never imports, links or falls back to it.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py)
+ * against golden vectors produced by importing the reference's own Python from
+ * /root/reference under container-type shims (oracle/ref_shims.py,
+ * tests/golden/make_golden.py) and against the known answers inlined in the
+ * reference's unit tests (tests/golden/reference_known_answers.json).
+ * NOT pinned (dependency absent): OpenSimplex wind noise
+ * (opensimplex==0.3) -- modelled as an additive (u,v) input that defaults to 0.
+ *
+ * Every function cites the reference file:line it follows; paths are relative to
+ * /root/reference/balloon_learning_environment/.  Arithmetic follows the reference
+ * operation by operation (same association order) so that agreement is ~1e-13.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---- utils/constants.py:23-30 ---- */
+static const double GRAVITY = 9.80665;
+static const double UNIVERSAL_GAS_CONSTANT = 8.3144621;
+static const double DRY_AIR_MOLAR_MASS = 0.028964922481160;
+static const double HE_MOLAR_MASS = 0.004002602;
+#define DRY_AIR_SPECIFIC_GAS_CONSTANT (UNIVERSAL_GAS_CONSTANT / DRY_AIR_MOLAR_MASS)
+
+/* CPython math.radians / math.degrees: x * (pi/180), x * (180/pi). */
+static const double PI = 3.14159265358979323846;
+static inline double radians(double x) { return x * (PI / 180.0); }
+static inline double degrees(double x) { return x * (180.0 / PI); }
+
+/* control.py:21-25 */
+enum { DOWN = 0, STAY = 1, UP = 2 };
+/* balloon.py:66-70 */
+enum { ST_OK = 0, ST_OUT_OF_POWER = 1, ST_BURST = 2, ST_ZEROPRESSURE = 3 };
+
+/* error bits reported by the oracle where the reference raises */
+enum {
+  ORC_ERR_PRESSURE_RANGE = 1,   /* standard_atmosphere.py:126-127 asserts */
+  ORC_ERR_ABSORPTIVITY = 2,     /* thermal.py:142-145 ValueError */
+  ORC_ERR_SOLAR_RANGE = 4,      /* solar.py:60-63,190-197 ValueError */
+  ORC_ERR_TERMINAL_STEP = 8,    /* balloon.py:288-290 AssertionError */
+  ORC_ERR_POWER_TABLE = 16,     /* power_table.py:24 assert */
+};
+
+/* ------------------------------------------------------------------------- */
+/* Atmosphere: env/balloon/standard_atmosphere.py                             */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  double lapse[7];
+  double temp[8];
+  double pres[8];
+} orc_atm;
+
+static const double HEIGHT_TRANSITIONS[8] = {-610.0, 17000.0, 21000.0, 32000.0,
+                                             47000.0, 51000.0, 71000.0, 85000.0};
+static const double LAPSE_LOW[7] = {-0.007, 0.006, 0.001, 0.0028, 0.0, -0.0028, -0.002};
+static const double LAPSE_HIGH[7] = {-0.0058, 0.005, 0.001, 0.0028, 0.0, -0.0028, -0.002};
+
+/* standard_atmosphere.py:185-202 */
+static double pressure_for_constant_temperature(double dh, double t, double p_init) {
+  return p_init * exp(-(GRAVITY * dh) / (DRY_AIR_SPECIFIC_GAS_CONSTANT * t));
+}
+static double pressure_for_linear_temperature(double t_ratio, double lapse, double p_init) {
+  return p_init * pow(t_ratio, -GRAVITY / (DRY_AIR_SPECIFIC_GAS_CONSTANT * lapse));
+}
+
+/* standard_atmosphere.py:76-87 (alpha given instead of drawn), :156-183 */
+ORC_API void orc_atm_init(double alpha, orc_atm* a) {
+  for (int i = 0; i < 7; ++i) a->lapse[i] = (1 - alpha) * LAPSE_LOW[i] + alpha * LAPSE_HIGH[i];
+  a->temp[0] = 300.0;
+  for (int i = 0; i < 7; ++i)
+    a->temp[i + 1] = a->temp[i] + a->lapse[i] * (HEIGHT_TRANSITIONS[i + 1] - HEIGHT_TRANSITIONS[i]);
+  a->pres[0] = 108870.8213;
+  for (int i = 0; i < 7; ++i) {
+    if (a->lapse[i] == 0.0)
+      a->pres[i + 1] = pressure_for_constant_temperature(
+          HEIGHT_TRANSITIONS[i + 1] - HEIGHT_TRANSITIONS[i], a->temp[i + 1], a->pres[i]);
+    else
+      a->pres[i + 1] = pressure_for_linear_temperature(a->temp[i + 1] / a->temp[i], a->lapse[i],
+                                                       a->pres[i]);
+  }
+}
+
+/* standard_atmosphere.py:122-154.  Returns error bits. */
+static int atm_at_pressure(const orc_atm* a, double pressure, double* height, double* temperature) {
+  int err = 0;
+  if (!(pressure > a->pres[7]) || !(pressure <= a->pres[0])) err = ORC_ERR_PRESSURE_RANGE;
+  double t = 0.0, h = 0.0;
+  for (int i = 0; i < 7; ++i) {
+    if (pressure > a->pres[i + 1]) {
+      if (a->lapse[i] == 0.0) {
+        h = ((-DRY_AIR_SPECIFIC_GAS_CONSTANT * a->temp[i] / GRAVITY) * log(pressure / a->pres[i]) +
+             HEIGHT_TRANSITIONS[i]);
+      } else {
+        h = ((pow(pressure / a->pres[i], -DRY_AIR_SPECIFIC_GAS_CONSTANT * a->lapse[i] / GRAVITY) - 1) *
+                 a->temp[i] / a->lapse[i] +
+             HEIGHT_TRANSITIONS[i]);
+      }
+      t = a->temp[i] + a->lapse[i] * (h - HEIGHT_TRANSITIONS[i]);
+      break;
+    }
+  }
+  *height = h;
+  *temperature = t;
+  return err;
+}
+
+/* standard_atmosphere.py:89-120 */
+static int atm_at_height(const orc_atm* a, double height, double* pressure, double* temperature) {
+  int err = 0;
+  if (!(height >= HEIGHT_TRANSITIONS[0]) || !(height < HEIGHT_TRANSITIONS[7])) err = ORC_ERR_PRESSURE_RANGE;
+  double t = 0.0, p = 0.0;
+  for (int i = 0; i < 7; ++i) {
+    if (height < HEIGHT_TRANSITIONS[i + 1]) {
+      t = a->temp[i] + a->lapse[i] * (height - HEIGHT_TRANSITIONS[i]);
+      if (a->lapse[i] == 0.0)
+        p = pressure_for_constant_temperature(height - HEIGHT_TRANSITIONS[i], t, a->pres[i]);
+      else
+        p = pressure_for_linear_temperature(t / a->temp[i], a->lapse[i], a->pres[i]);
+      break;
+    }
+  }
+  *pressure = p;
+  *temperature = t;
+  return err;
+}
+
+ORC_API int orc_at_pressure(double alpha, int64_t n, const double* p, double* h, double* t,
+                            double* rho) {
+  orc_atm a;
+  orc_atm_init(alpha, &a);
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    err |= atm_at_pressure(&a, p[i], &h[i], &t[i]);
+    rho[i] = p[i] / (DRY_AIR_SPECIFIC_GAS_CONSTANT * t[i]);
+  }
+  return err;
+}
+
+ORC_API int orc_at_height(double alpha, int64_t n, const double* h, double* p, double* t,
+                          double* rho) {
+  orc_atm a;
+  orc_atm_init(alpha, &a);
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    err |= atm_at_height(&a, h[i], &p[i], &t[i]);
+    rho[i] = p[i] / (DRY_AIR_SPECIFIC_GAS_CONSTANT * t[i]);
+  }
+  return err;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Calendar helper (what datetime.year/.month/.day give for a UTC timestamp)  */
+/* ------------------------------------------------------------------------- */
+static void civil_from_unix(int64_t unix_s, int* year, int* month, int* day) {
+  int64_t z = unix_s / 86400;
+  if (unix_s % 86400 < 0) z -= 1;
+  z += 719468;
+  int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  int64_t doe = z - era * 146097;
+  int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  int64_t y = yoe + era * 400;
+  int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  int64_t mp = (5 * doy + 2) / 153;
+  int64_t d = doy - (153 * mp + 2) / 5 + 1;
+  int64_t m = mp < 10 ? mp + 3 : mp - 9;
+  *year = (int)(y + (m <= 2));
+  *month = (int)m;
+  *day = (int)d;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Solar: env/balloon/solar.py                                                */
+/* ------------------------------------------------------------------------- */
+static const double MIN_SOLAR_EL_DEG = -4.242; /* solar.py:38 */
+
+/* solar.py:43-174.  lat/lng in radians (s2.LatLng), integer unix seconds (UTC). */
+static int solar_calculator(double lat_rad, double lng_rad, int64_t unix_s, double* el_deg_out,
+                            double* az_deg_out, double* flux_out) {
+  int err = 0;
+  if (!(fabs(lat_rad) <= PI / 2 && fabs(lng_rad) <= PI)) err = ORC_ERR_SOLAR_RANGE; /* :60-61 */
+  int64_t sod = unix_s % 86400;
+  if (sod < 0) sod += 86400;
+  double fraction_of_day = (double)sod / 86400.0; /* :66-68 */
+  int year, month, day;
+  civil_from_unix(unix_s, &year, &month, &day);
+  /* :71-75 */
+  double julian_day_number =
+      (367.0 * year - floor(7.0 * (year + floor((month + 9.0) / 12.0)) / 4.0) -
+       floor(3.0 * (floor((year + (month - 9.0) / 7.0) / 100.0) + 1.0) / 4.0) +
+       floor(275.0 * month / 9.0) + day + 1721028.5);
+  double julian_time = julian_day_number + fraction_of_day;
+  double jc = (julian_time - 2451545.0) / 36525.0;
+
+  double l0 = radians(280.46646 + jc * (36000.76983 + jc * 0.0003032)); /* :82-83 */
+  double sin2l0 = sin(2.0 * l0);
+  double cos2l0 = cos(2.0 * l0);
+  double sin4l0 = sin(4.0 * l0);
+  double m0 = radians(357.52911 + jc * (35999.05029 - 0.0001537 * jc)); /* :88-89 */
+  double sinm0 = sin(m0);
+  double sin2m0 = sin(2.0 * m0);
+  double sin3m0 = sin(3.0 * m0);
+  double mean_obliquity = radians(
+      23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
+  double obliquity_correction =
+      mean_obliquity + radians(0.00256 * cos(radians(125.04 - 1934.136 * jc)));
+  double tan_half = tan(obliquity_correction / 2.0);
+  double var_y = tan_half * tan_half;
+  double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
+  double equation_of_time =
+      (4.0 * (var_y * sin2l0 - 2.0 * ecc * sinm0 + 4.0 * ecc * var_y * sinm0 * cos2l0 -
+              0.5 * var_y * var_y * sin4l0 - 1.25 * ecc * ecc * sin2m0));
+  double hour_angle =
+      radians(fmod(1440.0 * fraction_of_day + degrees(equation_of_time) + 4.0 * degrees(lng_rad),
+                   1440.0)) /
+      4.0; /* :113-116 */
+  if (hour_angle < 0)
+    hour_angle += PI;
+  else
+    hour_angle -= PI;
+  double eq_of_center = radians(sinm0 * (1.914602 - jc * (0.004817 + 0.000014 * jc)) +
+                                sin2m0 * (0.019993 - 0.000101 * jc) + sin3m0 * 0.000289);
+  double true_long = l0 + eq_of_center;
+  double apparent_long =
+      true_long - radians(0.00569 - 0.00478 * sin(radians(125.04 - 1934.136 * jc)));
+  double declination = asin(sin(obliquity_correction) * sin(apparent_long));
+  double zenith = acos(sin(lat_rad) * sin(declination) +
+                       cos(lat_rad) * cos(declination) * cos(hour_angle)); /* :136-139 */
+  double el_unc = 90.0 - degrees(zenith);
+  double refraction;
+  if (el_unc > 85.0) {
+    refraction = 0;
+  } else if (el_unc > 5.0) {
+    double tan_seu = tan(radians(el_unc));
+    refraction = (58.1 / tan_seu - 0.07 / pow(tan_seu, 3) + 0.000086 / pow(tan_seu, 5));
+  } else if (el_unc > -0.575) {
+    refraction = (1735.0 + el_unc * (-518.2 + el_unc * (103.4 + el_unc * (-12.79 + el_unc * 0.711))));
+  } else {
+    refraction = -20.772 / tan(radians(el_unc));
+  }
+  double el_deg = el_unc + refraction / 3600.0; /* :157 */
+  /* azimuth :160-168 (not on the transition path; kept for the known-answer tests) */
+  double cos_az = ((sin(lat_rad) * cos(zenith) - sin(declination)) / (cos(lat_rad) * sin(zenith)));
+  if (cos_az < -1.0) cos_az = -1.0;
+  if (cos_az > 1.0) cos_az = 1.0;
+  double az_unwrapped = acos(cos_az);
+  double az_deg = hour_angle > 0 ? degrees(az_unwrapped) + 180.0 : 180.0 - degrees(az_unwrapped);
+  double r = (1 + ecc) / (1 - ecc);
+  double flux = 1366.0 * (1 + 0.5 * (r * r - 1) * cos(m0)); /* :170-172 */
+  *el_deg_out = el_deg;
+  if (az_deg_out) *az_deg_out = az_deg;
+  *flux_out = flux;
+  return err;
+}
+
+ORC_API int orc_solar_calculator(int64_t n, const double* lat_rad, const double* lng_rad,
+                                 const int64_t* unix_s, double* el, double* az, double* flux) {
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i)
+    err |= solar_calculator(lat_rad[i], lng_rad[i], unix_s[i], &el[i], &az[i], &flux[i]);
+  return err;
+}
+
+/* solar.py:177-209 */
+static int solar_atmospheric_attenuation(double el_deg, double p, double* out) {
+  int err = 0;
+  if (el_deg > 90.0 || el_deg < -90.0) err |= ORC_ERR_SOLAR_RANGE;
+  if (p > 101325.0 || p < 0.0) err |= ORC_ERR_SOLAR_RANGE;
+  if (el_deg < MIN_SOLAR_EL_DEG) {
+    *out = 0.0;
+    return err;
+  }
+  double tmp_sin_elev = 614.0 * sin(radians(el_deg));
+  double airmass =
+      (0.34764 * (p / 101325.0) * (sqrt(1229.0 + tmp_sin_elev * tmp_sin_elev) - tmp_sin_elev));
+  *out = 0.5 * (exp(-0.65 * airmass) + exp(-0.95 * airmass));
+  return err;
+}
+
+/* solar.py:212-236 */
+static double balloon_shadow(double el_deg, double panel_height_below_balloon_m) {
+  const double balloon_radius = 8.69275;
+  const double balloon_height = 10.41603;
+  double shadow_el_deg = degrees(atan2(
+      sqrt(panel_height_below_balloon_m * (balloon_height + panel_height_below_balloon_m)),
+      balloon_radius));
+  return el_deg >= shadow_el_deg ? 0.4392 : 1.0;
+}
+
+/* solar.py:515-536 */
+static int solar_power(double el_deg, double p, double* watts) {
+  double att;
+  int err = solar_atmospheric_attenuation(el_deg, p, &att);
+  *watts = 210.0 * att *
+           (4 * cos(radians(el_deg - 35)) * balloon_shadow(el_deg, 3.3) +
+            2 * cos(radians(el_deg - 65)) * balloon_shadow(el_deg, 2.7));
+  return err;
+}
+
+ORC_API int orc_solar_attenuation(int64_t n, const double* el, const double* p, double* out) {
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) err |= solar_atmospheric_attenuation(el[i], p[i], &out[i]);
+  return err;
+}
+ORC_API void orc_balloon_shadow(int64_t n, const double* el, const double* h, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = balloon_shadow(el[i], h[i]);
+}
+ORC_API int orc_solar_power(int64_t n, const double* el, const double* p, double* out) {
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) err |= solar_power(el[i], p[i], &out[i]);
+  return err;
+}
+
+/* utils/spherical_geometry.py:44-76 + s2sphere LatLng.normalized() */
+static void latlng_from_offset(double lat0, double lng0, double x_m, double y_m, double* lat,
+                               double* lng) {
+  double heading = atan2(x_m / 1000.0, y_m / 1000.0);
+  double angle = sqrt(x_m * x_m + y_m * y_m) / 6371000.0; /* units.relative_distance / R */
+  double cos_angle = cos(angle), sin_angle = sin(angle);
+  double sin_from_lat = sin(lat0), cos_from_lat = cos(lat0);
+  double sin_lat = (cos_angle * sin_from_lat + sin_angle * cos_from_lat * cos(heading));
+  double d_lng = atan2(sin_angle * cos_from_lat * sin(heading), cos_angle - sin_from_lat * sin_lat);
+  double new_lat = asin(sin_lat);
+  new_lat = fmin(fmax(new_lat, -PI / 2.0), PI / 2.0);
+  double new_lng = lng0 + d_lng;
+  *lat = fmax(-PI / 2, fmin(PI / 2, new_lat));
+  *lng = remainder(new_lng, 2 * PI);
+}
+
+ORC_API void orc_latlng_from_offset(int64_t n, const double* lat0, const double* lng0,
+                                    const double* x, const double* y, double* lat, double* lng) {
+  for (int64_t i = 0; i < n; ++i) latlng_from_offset(lat0[i], lng0[i], x[i], y[i], &lat[i], &lng[i]);
+}
+
+/* ---- sunrise / sunset search: solar.py:239-483 (reset path + PowerSafetyLayer.__init__) ---- */
+static double el_at(double lat, double lng, int64_t t) {
+  double el, fl;
+  solar_calculator(lat, lng, t, &el, NULL, &fl);
+  return el;
+}
+static int is_solar_afternoon(double lat, double lng, int64_t t) { /* :239-256 */
+  return el_at(lat, lng, t + 1) < el_at(lat, lng, t);
+}
+/* mode 0: minimum (operator.pos), 1: maximum (operator.neg), 2: |x-target|  (:263-292) */
+static double xfer(int mode, double target, double el) {
+  if (mode == 0) return el;
+  if (mode == 1) return -el;
+  return fabs(el - target);
+}
+/* :295-372 */
+static int64_t find_solar_elevation(double lat, double lng, int64_t min_t, int64_t max_t, int mode,
+                                    double target, int64_t dt) {
+  int64_t max_steps = (max_t - min_t) / dt;
+  int64_t low = 0, high = max_steps;
+  while (high > low + 1) {
+    double midpoint = low + (high - low) / 2.0;
+    double ol = xfer(mode, target, el_at(lat, lng, min_t + dt * low));
+    double oh = xfer(mode, target, el_at(lat, lng, min_t + dt * high));
+    if (ol < oh)
+      high = (int64_t)ceil(midpoint);
+    else
+      low = (int64_t)floor(midpoint);
+  }
+  double ol = xfer(mode, target, el_at(lat, lng, min_t + dt * low));
+  double oh = xfer(mode, target, el_at(lat, lng, min_t + dt * high));
+  int64_t idx = (ol < oh) ? low : high;
+  return min_t + dt * idx;
+}
+/* :432-483 */
+static void next_sunrise_sunset(double lat, double lng, int64_t t, int64_t* sunrise,
+                                int64_t* sunset) {
+  const int64_t dt = 180, H12 = 12 * 3600, H24 = 24 * 3600;
+  int afternoon = is_solar_afternoon(lat, lng, t);
+  int64_t next_noon, next_midnight;
+  if (afternoon) { /* :399-429 */
+    next_noon = find_solar_elevation(lat, lng, t + H12, t + H24, 1, 0, dt);
+    next_midnight = find_solar_elevation(lat, lng, t, t + H12, 0, 0, dt);
+  } else {
+    next_noon = find_solar_elevation(lat, lng, t, t + H12, 1, 0, dt);
+    next_midnight = find_solar_elevation(lat, lng, t + H12, t + H24, 0, 0, dt);
+  }
+  int64_t sr, ss;
+  if (afternoon) {
+    sr = find_solar_elevation(lat, lng, next_midnight, next_noon, 2, MIN_SOLAR_EL_DEG, dt);
+    ss = find_solar_elevation(lat, lng, next_noon - H24, next_midnight, 2, MIN_SOLAR_EL_DEG, dt);
+  } else {
+    sr = find_solar_elevation(lat, lng, next_midnight - H24, next_noon, 2, MIN_SOLAR_EL_DEG, dt);
+    ss = find_solar_elevation(lat, lng, next_noon, next_midnight, 2, MIN_SOLAR_EL_DEG, dt);
+  }
+  if (sr < t) sr += H24;
+  if (ss < t) ss += H24;
+  *sunrise = sr;
+  *sunset = ss;
+}
+ORC_API void orc_next_sunrise_sunset(int64_t n, const double* lat, const double* lng,
+                                     const int64_t* t, int64_t* sunrise, int64_t* sunset) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) next_sunrise_sunset(lat[i], lng[i], t[i], &sunrise[i], &sunset[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Thermal: env/balloon/thermal.py                                            */
+/* ------------------------------------------------------------------------- */
+static const double STEFAN_BOLTZMAN = 0.000000056704;
+
+static double absorptivity_ir(double t) { return (0.04587 + 0.000232 * (t - 210)); } /* :74-87 */
+static double total_absorptivity(double a, double r, int* err) { /* :92-147 */
+  double transmisivity = 1.0 - a - r;
+  double f = a * (1.0 + transmisivity / (1.0 - r));
+  if (f < 0.0 || f > 1.0) *err |= ORC_ERR_ABSORPTIVITY;
+  return f;
+}
+/* :150-172 */
+static double convective_heat_air_factor(double radius, double t_balloon, double t_amb, double p) {
+  double viscosity = 1.458e-6 * pow(t_amb, 1.5) / (t_amb + 110.4);
+  double conductivity = 0.0241 * pow(t_amb / 273.15, 0.9);
+  double prandtl = 0.804 - 3.25e-4 * t_amb;
+  double air_density = (p * DRY_AIR_MOLAR_MASS / (UNIVERSAL_GAS_CONSTANT * t_amb));
+  double grashof = (9.80665 * pow(air_density, 2) * pow(2 * radius, 3) /
+                    (t_amb * pow(viscosity, 2))) *
+                   fabs(t_amb - t_balloon);
+  double rayleigh = prandtl * grashof;
+  double nusselt = (2 + 0.457 * pow(rayleigh, 0.25) + pow(1 + 2.69e-8 * rayleigh, 1.0 / 12.0));
+  double k = nusselt * conductivity / (2 * radius);
+  return k * (t_amb - t_balloon);
+}
+/* :175-230 */
+static double d_balloon_temperature_dt(double volume, double mass, double t_balloon, double t_amb,
+                                       double p, double el_deg, double solar_flux,
+                                       double earth_flux, int* err) {
+  double radius = pow(3 * volume / (4 * PI), 1.0 / 3);
+  double area = 4 * PI * radius * radius;
+  double att;
+  *err |= solar_atmospheric_attenuation(el_deg, p, &att);
+  double q_solar = (solar_flux * att * 0.25 * area * total_absorptivity(0.01435, 0.0291, err));
+  double q_earth = (earth_flux * 0.4605 * area *
+                    total_absorptivity(absorptivity_ir(pow(earth_flux / STEFAN_BOLTZMAN, 0.25)),
+                                       0.0291, err));
+  double q_emitted = (STEFAN_BOLTZMAN * pow(t_balloon, 4) * area *
+                      total_absorptivity(absorptivity_ir(t_balloon), 0.0291, err));
+  double q_conv = area * convective_heat_air_factor(radius, t_balloon, t_amb, p);
+  return (q_solar + q_earth + q_conv - q_emitted) / (1500 * mass);
+}
+ORC_API int orc_thermal_dtdt(int64_t n, const double* v, const double* t_int, const double* t_amb,
+                             const double* p, const double* el, const double* flux,
+                             const double* ir, double* out) {
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i)
+    out[i] = d_balloon_temperature_dt(v[i], 68.5, t_int[i], t_amb[i], p[i], el[i], flux[i], ir[i], &err);
+  return err;
+}
+
+/* ------------------------------------------------------------------------- */
+/* balloon.py:552-609                                                         */
+/* ------------------------------------------------------------------------- */
+static void superpressure_and_volume(double mols_lift_gas, double mols_air, double t_int, double p,
+                                     double v_base, double dv_dp, double* volume, double* sp) {
+  double vu = ((mols_lift_gas + mols_air) * UNIVERSAL_GAS_CONSTANT * t_int / p);
+  if (vu <= v_base) {
+    *volume = vu;
+    *sp = 0.0;
+  } else {
+    double b = -(v_base - dv_dp * p);
+    double c = -(dv_dp * vu * p);
+    *volume = 0.5 * (-b + sqrt(b * b - 4 * c));
+    *sp = (p * vu / *volume - p);
+  }
+}
+ORC_API void orc_sp_volume(int64_t n, const double* mols_air, const double* t_int, const double* p,
+                           double* volume, double* sp) {
+  for (int64_t i = 0; i < n; ++i)
+    superpressure_and_volume(6830.0, mols_air[i], t_int[i], p[i], 1804, 0.0199, &volume[i], &sp[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* ACS tables: env/balloon/acs.py                                             */
+/* ------------------------------------------------------------------------- */
+/* acs.py:24-28: scipy interp1d(kind='linear', fill_value='extrapolate') */
+static double acs_most_efficient_power(double pr) {
+  static const double X[5] = {1.0, 1.05, 1.2, 1.25, 1.35};
+  static const double Y[5] = {100.0, 100.0, 300.0, 400.0, 400.0};
+  int idx = 0; /* searchsorted side='left' */
+  while (idx < 5 && X[idx] < pr) ++idx;
+  if (idx < 1) idx = 1;
+  if (idx > 4) idx = 4;
+  int lo = idx - 1, hi = idx;
+  double slope = (Y[hi] - Y[lo]) / (X[hi] - X[lo]);
+  return slope * (pr - X[lo]) + Y[lo];
+}
+/* acs.py:31-41: interp2d(linear) on a regular 13x4 grid; fill_value=None -> nearest
+ * outside.  Restated as the degree-1 tensor B-spline FITPACK evaluates (fpbisp/fpbspl).
+ * Between nodes this is an ASSUMPTION about scipy==1.7.1's interp2d (removed in
+ * SciPy>=1.14; the reference's acs_test.py:46-64 pins table nodes only). */
+static const double ACS_EFF[4][13] = {
+    {0.4, 0.4, 0.3, 0.2, 0.2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {0.4, 0.3, 0.3, 0.30, 0.25, 0.23, 0.20, 0.15, 0.12, 0.10, 0.0, 0.0, 0.0},
+    {0.0, 0.3, 0.25, 0.25, 0.25, 0.20, 0.20, 0.20, 0.2, 0.15, 0.13, 0.12, 0.11},
+    {0.0, 0.23, 0.23, 0.23, 0.23, 0.23, 0.20, 0.20, 0.20, 0.18, 0.16, 0.15, 0.13}};
+static double acs_fan_efficiency(double pr, double power) {
+  double xs[13], ys[4];
+  for (int i = 0; i < 13; ++i) xs[i] = 1.05 + (1.35 - 1.05) / 12 * i; /* np.linspace */
+  xs[12] = 1.35;
+  for (int j = 0; j < 4; ++j) ys[j] = 100.0 + (400.0 - 100.0) / 3 * j;
+  ys[3] = 400.0;
+  double x = fmin(fmax(pr, xs[0]), xs[12]);
+  double y = fmin(fmax(power, ys[0]), ys[3]);
+  int ix = 0;
+  while (ix < 11 && x >= xs[ix + 1]) ++ix;
+  int iy = 0;
+  while (iy < 2 && y >= ys[iy + 1]) ++iy;
+  double fx = 1.0 / (xs[ix + 1] - xs[ix]);
+  double hx0 = fx * (xs[ix + 1] - x), hx1 = fx * (x - xs[ix]);
+  double fy = 1.0 / (ys[iy + 1] - ys[iy]);
+  double hy0 = fy * (ys[iy + 1] - y), hy1 = fy * (y - ys[iy]);
+  double sp = 0.0;
+  sp += ACS_EFF[iy][ix] * hx0 * hy0;
+  sp += ACS_EFF[iy + 1][ix] * hx0 * hy1;
+  sp += ACS_EFF[iy][ix + 1] * hx1 * hy0;
+  sp += ACS_EFF[iy + 1][ix + 1] * hx1 * hy1;
+  return sp;
+}
+ORC_API void orc_acs(int64_t n, const double* pr, double* power, double* eff, double* mass_flow) {
+  for (int64_t i = 0; i < n; ++i) {
+    power[i] = acs_most_efficient_power(pr[i]);
+    eff[i] = acs_fan_efficiency(pr[i], power[i]);
+    mass_flow[i] = eff[i] * power[i] / 3600; /* acs.py:67-68 */
+  }
+}
+ORC_API void orc_acs_efficiency(int64_t n, const double* pr, const double* power, double* eff) {
+  for (int64_t i = 0; i < n; ++i) eff[i] = acs_fan_efficiency(pr[i], power[i]);
+}
+
+/* env/balloon/power_table.py:21-38 (bisect.bisect == bisect_right) */
+static int power_table_lookup(double pr, double soc, double* watts) {
+  static const double PR_EDGES[7] = {1.08, 1.11, 1.14, 1.17, 1.2, 1.23, 1.26};
+  static const double SOC_EDGES[8][3] = {{0.3, 0.4, 0.5}, {0.3, 0.4, 0.7}, {0.3, 0.4, 0.6},
+                                         {0.3, 0.4, 0.5}, {0.3, 0.4, 0.5}, {0.4, 0.5, 0},
+                                         {0.5, 0.6, 0},   {0.5, 0.6, 0}};
+  static const int SOC_N[8] = {3, 3, 3, 3, 3, 2, 2, 2};
+  static const double WATTS[8][4] = {{0, 150, 175, 200}, {0, 200, 200, 225}, {0, 225, 225, 250},
+                                     {0, 200, 225, 250}, {0, 225, 250, 275}, {0, 275, 300, 0},
+                                     {0, 300, 325, 0},   {0, 325, 350, 0}};
+  int err = (pr >= 0.99 && pr <= 5) ? 0 : ORC_ERR_POWER_TABLE;
+  int i = 0;
+  while (i < 7 && !(pr < PR_EDGES[i])) ++i;
+  int j = 0;
+  while (j < SOC_N[i] && !(soc < SOC_EDGES[i][j])) ++j;
+  *watts = WATTS[i][j];
+  return err;
+}
+ORC_API int orc_power_table(int64_t n, const double* pr, const double* soc, double* watts) {
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) err |= power_table_lookup(pr[i], soc[i], &watts[i]);
+  return err;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Safety layers                                                              */
+/* ------------------------------------------------------------------------- */
+/* altitude_safety.py:33-111.  FSM: 0 NOMINAL, 1 LOW, 2 VERY_LOW */
+static int altitude_safety(int action, const orc_atm* atm, double pressure, uint8_t* fsm, int* err) {
+  const double min_alt = 50000.0 * 0.3048, buffer = 500.0 * 0.3048, hyst = 500.0 * 0.3048;
+  double h, t;
+  *err |= atm_at_pressure(atm, pressure, &h, &t);
+  if (h < min_alt)
+    *fsm = 2;
+  else if (h < min_alt + buffer)
+    *fsm = 1;
+  else if (h < min_alt + buffer + hyst)
+    *fsm = (*fsm == 2 || *fsm == 1) ? 1 : 0;
+  else
+    *fsm = 0;
+  if (*fsm == 2) return UP;
+  if (*fsm == 1 && action == DOWN) return STAY;
+  return action;
+}
+/* envelope_safety.py:40-157. FSM: 0 NOMINAL 1 LOW_CRITICAL 2 LOW 3 HIGH 4 HIGH_CRITICAL */
+static int envelope_safety(int action, double sp, double max_sp, uint8_t* fsm) {
+  const double CRIT = 150, BUF = 250, HYST = 50;
+  if (sp < CRIT)
+    *fsm = 1;
+  else if (sp < BUF)
+    *fsm = 2;
+  else if (sp < BUF + HYST)
+    *fsm = (*fsm == 1 || *fsm == 2) ? 2 : 0;
+  else if (sp < max_sp - BUF - HYST)
+    *fsm = 0;
+  else if (sp < max_sp - BUF)
+    *fsm = (*fsm == 3 || *fsm == 4) ? 3 : 0;
+  else if (sp < max_sp - CRIT)
+    *fsm = 3;
+  else
+    *fsm = 4;
+  if (*fsm == 1 || *fsm == 4) return UP;
+  if ((*fsm == 2 || *fsm == 3) && action == DOWN) return STAY;
+  return action;
+}
+/* power_safety.py:52-126.  Times are integer unix seconds. */
+static int power_safety(int action, int64_t now, double night_load_w, double batt_wh, double cap_wh,
+                        int64_t* sunrise_h, int64_t* sunset, uint8_t* paused) {
+  while (now > *sunrise_h) *sunrise_h += 86400;
+  while (now > *sunset) *sunset += 86400;
+  int paused_action = (action == DOWN) ? STAY : action;
+  if (*sunset < *sunrise_h) {
+    double soc = batt_wh / cap_wh;
+    if (*paused && soc < 0.05) return paused_action;
+    *paused = 0;
+    return action;
+  }
+  if (*paused) return paused_action;
+  double hours = (double)(*sunrise_h - now) / 3600.0; /* units.timedelta_to_hours */
+  double floating = night_load_w * hours;
+  double expected = (batt_wh - floating) / cap_wh;
+  if (expected < 0.025) {
+    *paused = 1;
+    return paused_action;
+  }
+  return action;
+}
+
+ORC_API int orc_altitude_safety_trace(double alpha, int64_t n, const uint8_t* action,
+                                      const double* pressure, uint8_t fsm0, uint8_t* out_action,
+                                      uint8_t* out_fsm) {
+  orc_atm a;
+  orc_atm_init(alpha, &a);
+  uint8_t fsm = fsm0;
+  int err = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    out_action[i] = (uint8_t)altitude_safety(action[i], &a, pressure[i], &fsm, &err);
+    out_fsm[i] = fsm;
+  }
+  return err;
+}
+ORC_API void orc_envelope_safety_trace(int64_t n, const uint8_t* action, const double* sp,
+                                       uint8_t fsm0, uint8_t* out_action, uint8_t* out_fsm) {
+  uint8_t fsm = fsm0;
+  for (int64_t i = 0; i < n; ++i) {
+    out_action[i] = (uint8_t)envelope_safety(action[i], sp[i], 2380, &fsm);
+    out_fsm[i] = fsm;
+  }
+}
+ORC_API void orc_power_safety_trace(int64_t n, const uint8_t* action, const int64_t* now,
+                                    const double* batt, double night_load_w, double cap_wh,
+                                    int64_t sunrise_h0, int64_t sunset0,
+                                    uint8_t paused0, uint8_t* out_action, int64_t* out_sunrise_h,
+                                    int64_t* out_sunset, uint8_t* out_paused) {
+  int64_t sr = sunrise_h0, ss = sunset0;
+  uint8_t paused = paused0;
+  for (int64_t i = 0; i < n; ++i) {
+    out_action[i] = (uint8_t)power_safety(action[i], now[i], night_load_w, batt[i], cap_wh, &sr, &ss, &paused);
+    out_sunrise_h[i] = sr;
+    out_sunset[i] = ss;
+    out_paused[i] = paused;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Wind field: env/grid_based_wind_field.py                                   */
+/* ------------------------------------------------------------------------- */
+#define NX 21
+#define NY 21
+#define NP 10
+#define NT 9
+/* grid_based_wind_field.py:134-143 */
+static double boomerang(double t, double max_val) {
+  int cycle_direction = ((int64_t)(t / max_val)) % 2;
+  double remainder_ = fmod(t, max_val); /* python % on non-negative operands */
+  return (cycle_direction % 2 == 0) ? remainder_ : max_val - remainder_;
+}
+/* One axis of scipy's RegularGridInterpolator index search (find_indices in
+ * _rgi_cython.pyx, SciPy 1.15.3 here; same result as pinned 1.7.1's searchsorted form
+ * up to which of two equal-valued corners gets weight 1): the interval with
+ * grid[i] <= x < grid[i+1] (last interval closed); norm = (x - grid[i]) / (grid[i+1]-grid[i]) */
+static void axis_index(double x, double g0, double step, int n, int* idx, double* w) {
+  int i = 0;
+  while (i < n - 2 && x >= (g0 + step * (i + 1))) ++i;
+  *idx = i;
+  *w = (x - (g0 + step * i)) / ((g0 + step * (i + 1)) - (g0 + step * i));
+}
+/* grid_based_wind_field.py:70-94,145-187 + scipy.interpolate.interpn(method='linear').
+ * The query point is packed as float32 (:181) and interpolated in fp64. */
+static void wind_forecast(const float* field, double x_m, double y_m, double pressure,
+                          int64_t elapsed_s, double* u, double* v) {
+  double x_km = x_m / 1000.0, y_km = y_m / 1000.0;
+  x_km = fmin(fmax(x_km, -500.0), 500.0);
+  y_km = fmin(fmax(y_km, -500.0), 500.0);
+  double p = fmin(fmax(pressure, 5000.0), 14000.0);
+  double elapsed_hours = (double)elapsed_s / 3600.0;
+  double tpos = elapsed_hours < 48 ? elapsed_hours : boomerang(elapsed_hours, 48);
+  double q[4] = {(double)(float)x_km, (double)(float)y_km, (double)(float)p, (double)(float)tpos};
+  int ix, iy, ip, it;
+  double wx, wy, wp, wt;
+  axis_index(q[0], -500.0, 50.0, NX, &ix, &wx);
+  axis_index(q[1], -500.0, 50.0, NY, &iy, &wy);
+  axis_index(q[2], 5000.0, 1000.0, NP, &ip, &wp);
+  axis_index(q[3], 0.0, 6.0, NT, &it, &wt);
+  double acc[2] = {0.0, 0.0};
+  /* itertools.product over (i, i+1) per axis, weight = prod(where(edge==i, 1-y, y)) */
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c)
+        for (int d = 0; d < 2; ++d) {
+          double w = 1.0;
+          w = w * (a ? wx : 1 - wx);
+          w = w * (b ? wy : 1 - wy);
+          w = w * (c ? wp : 1 - wp);
+          w = w * (d ? wt : 1 - wt);
+          const float* cell =
+              field + ((((int64_t)(ix + a) * NY + (iy + b)) * NP + (ip + c)) * NT + (it + d)) * 2;
+          acc[0] += (double)cell[0] * w;
+          acc[1] += (double)cell[1] * w;
+        }
+  *u = acc[0];
+  *v = acc[1];
+}
+ORC_API void orc_wind_forecast(const float* field, int64_t n, const double* x_m, const double* y_m,
+                               const double* p, const int64_t* elapsed_s, double* u, double* v) {
+  for (int64_t i = 0; i < n; ++i) wind_forecast(field, x_m[i], y_m[i], p[i], elapsed_s[i], &u[i], &v[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Per-env state, SoA of doubles (what tests hand in / read back)             */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  /* mutable floats (balloon.py:175-195) */
+  double *x, *y, *pressure, *ambient_temperature, *internal_temperature, *envelope_volume,
+      *superpressure, *mols_air, *battery_charge;
+  /* derived floats written every substep (balloon.py:189-193) */
+  double *acs_power, *acs_mass_flow, *solar_charging, *power_load;
+  /* per-episode constants */
+  double *center_lat_deg, *center_lng_deg, *upwelling_infrared, *alpha;
+  int64_t* start_unix;       /* date_time at time_elapsed == 0 */
+  int64_t* time_elapsed_s;   /* balloon.py:153 */
+  int64_t *sunrise_h, *sunset; /* PowerSafetyLayer._sunrise_with_hysteresis / _sunset, unix s */
+  uint8_t *status, *last_command, *alt_fsm, *env_fsm, *power_paused;
+} orc_state;
+
+typedef struct {
+  double x, y, p, t_amb, t_int, vol, sp, n_air, batt, acs_power, mdot, charge, load;
+  int64_t t_elapsed;
+  int status;
+} sub_state;
+
+/* balloon.py:356-549: one stride; all right-hand sides read the OLD state `s`. */
+static int simulate_step_internal(sub_state* s, double u, double v, const orc_atm* atm, int action,
+                                  double lat0_rad, double lng0_rad, int64_t start_unix, double ir,
+                                  double stride_s) {
+  int err = 0;
+  sub_state n = *s;
+  n.x = s->x + (u * stride_s); /* :394-395 */
+  n.y = s->y + (v * stride_s);
+
+  double rho_air = (s->p * DRY_AIR_MOLAR_MASS) / (UNIVERSAL_GAS_CONSTANT * s->t_amb); /* :412 */
+  double drag = 0.25 * pow(s->vol, 2.0 / 3.0);                                       /* :415 */
+  double total_mass = (HE_MOLAR_MASS * 6830.0 + DRY_AIR_MOLAR_MASS * s->n_air + 68.5 + 92.5);
+  double direction = (rho_air * s->vol >= total_mass) ? 1.0 : -1.0;
+  double dh_dt =
+      direction * sqrt(fabs(2 * (rho_air * s->vol - total_mass) * GRAVITY / (rho_air * drag)));
+  double dp = 1.0;
+  double h0, h1, tt;
+  err |= atm_at_pressure(atm, s->p, &h0, &tt);
+  err |= atm_at_pressure(atm, s->p + direction * dp, &h1, &tt);
+  double dp_dh = direction * dp / (h1 - h0);
+  double dp_dt = dp_dh * dh_dt;
+  n.p = s->p + dp_dt * stride_s; /* :445 */
+
+  double lat, lng, el, flux;
+  latlng_from_offset(lat0_rad, lng0_rad, s->x, s->y, &lat, &lng); /* state.latlng :452 */
+  err |= solar_calculator(lat, lng, start_unix + s->t_elapsed, &el, NULL, &flux);
+  double h_unused;
+  err |= atm_at_pressure(atm, s->p, &h_unused, &n.t_amb); /* :457 */
+  double d_t = d_balloon_temperature_dt(s->vol, 68.5, s->t_int, s->t_amb, s->p, el, flux, ir, &err);
+  n.t_int = s->t_int + d_t * stride_s; /* :466-467 */
+
+  superpressure_and_volume(6830.0, s->n_air, s->t_int, s->p, 1804, 0.0199, &n.vol, &n.sp);
+  if (n.sp > 2380) n.status = ST_BURST;       /* :479-480 */
+  if (n.sp <= 0.0) n.status = ST_ZEROPRESSURE; /* :481-482 */
+
+  if (action == UP) { /* :487-499 */
+    n.acs_power = 0.0;
+    double valve_area = PI * pow(0.04, 2) / 4.0;
+    double gas_density = (s->sp + s->p) * DRY_AIR_MOLAR_MASS / (UNIVERSAL_GAS_CONSTANT * s->t_int);
+    n.mdot = (-1 * 0.62 * valve_area * sqrt(2.0 * s->sp * gas_density));
+  } else if (action == DOWN) { /* :500-510 */
+    double sp_pos = fmax(s->sp, 0.0);
+    double pr = (s->p + sp_pos) / s->p; /* BalloonState.pressure_ratio :247-250 */
+    n.acs_power = acs_most_efficient_power(pr);
+    double eff = acs_fan_efficiency(pr, n.acs_power);
+    n.mdot = eff * n.acs_power / 3600;
+  } else {
+    n.acs_power = 0.0;
+    n.mdot = 0.0;
+  }
+  n.n_air = s->n_air + (n.mdot / DRY_AIR_MOLAR_MASS) * stride_s; /* :515-517 */
+  n.n_air = fmax(n.n_air, 0.0);
+
+  int is_day = el > MIN_SOLAR_EL_DEG; /* :524 */
+  if (is_day)
+    err |= solar_power(el, s->p, &n.charge);
+  else
+    n.charge = 0.0;
+  n.load = (is_day ? 120.4 : 183.7);
+  n.load += n.acs_power;
+  /* Power * timedelta -> watts * (seconds / 3600.0) watt-hours (units.py:277-281,309-314) */
+  n.batt = s->batt + (n.charge - n.load) * (stride_s / 3600.0);
+  n.batt = fmin(fmax(n.batt, 0.0), 3058.56);
+  if (n.batt <= 0.0) n.status = ST_OUT_OF_POWER; /* :541-542 */
+  n.t_elapsed = s->t_elapsed + (int64_t)stride_s;
+  *s = n;
+  return err;
+}
+
+/* env/balloon_env.py:44-102 + BalloonState.excess_energy balloon.py:231-238 */
+static double perciatelli_reward(const sub_state* s, int last_command, double lat0_rad,
+                                 double lng0_rad, int64_t start_unix, int* err) {
+  double distance = sqrt(s->x * s->x + s->y * s->y);
+  double radius = 50.0 * 1000.0;
+  double reward;
+  if (distance <= radius)
+    reward = 1.0;
+  else
+    reward = 0.4 * exp(-0.69314718056 / 100.0 * ((distance - radius) / 1000.0));
+  if (last_command == DOWN) {
+    double lat, lng, el, flux, sp_w;
+    latlng_from_offset(lat0_rad, lng0_rad, s->x, s->y, &lat, &lng);
+    *err |= solar_calculator(lat, lng, start_unix + s->t_elapsed, &el, NULL, &flux);
+    *err |= solar_power(el, s->p, &sp_w);
+    int excess = (sp_w > 120.4) && (s->batt / 3058.56 > 0.99);
+    if (!excess) {
+      double scale = (s->acs_power - 100.0) / (300.0 - 100.0); /* transforms.py:47-66 */
+      scale = fmin(fmax(scale, 0.0), 1.0);
+      reward *= 0.95 - 0.3 * scale;
+    }
+  }
+  return reward;
+}
+
+/*
+ * One agent step for n envs: BalloonArena.step (balloon_arena.py:184-202) minus the
+ * feature constructor, then BalloonEnv.step's reward/terminal (balloon_env.py:172-186).
+ *   wind = forecast(pre-step x,y,p,time_elapsed) + noise_uv    (wind_field.py:125-145)
+ *   Balloon.simulate_step(wind, atm, action, 180 s, stride 10 s) (balloon.py:263-328)
+ * Envs whose status != OK on entry are skipped (state frozen, reward 0, terminal 1,
+ * ORC_ERR_TERMINAL_STEP reported) where the reference raises AssertionError.
+ * `noise_uv` (n x 2) may be NULL.  `field` may be NULL if `wind_uv` (n x 2) is given
+ * (fixed wind per step, used by trajectory fixtures).  Returns OR of error bits.
+ */
+ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* field,
+                     const double* wind_uv, const double* noise_uv, double* reward,
+                     uint8_t* terminal, uint8_t* effective_action, int64_t n, int substeps,
+                     int n_threads) {
+  int err_all = 0;
+  (void)n_threads;
+#pragma omp parallel for schedule(static) reduction(| : err_all) num_threads(n_threads > 0 ? n_threads : 1)
+  for (int64_t i = 0; i < n; ++i) {
+    int err = 0;
+    if (st->status[i] != ST_OK) {
+      reward[i] = 0.0;
+      terminal[i] = 1;
+      if (effective_action) effective_action[i] = action[i];
+      err_all |= ORC_ERR_TERMINAL_STEP;
+      continue;
+    }
+    orc_atm atm;
+    orc_atm_init(st->alpha[i], &atm);
+    double lat0 = radians(st->center_lat_deg[i]), lng0 = radians(st->center_lng_deg[i]);
+    double u, v;
+    if (wind_uv) {
+      u = wind_uv[2 * i];
+      v = wind_uv[2 * i + 1];
+    } else {
+      wind_forecast(field, st->x[i], st->y[i], st->pressure[i], st->time_elapsed_s[i], &u, &v);
+    }
+    if (noise_uv) {
+      u = u + noise_uv[2 * i];
+      v = v + noise_uv[2 * i + 1];
+    }
+    st->last_command[i] = action[i]; /* balloon.py:286 */
+    int eff = action[i];
+    int64_t now = st->start_unix[i] + st->time_elapsed_s[i];
+    eff = power_safety(eff, now, 183.7, st->battery_charge[i], 3058.56, &st->sunrise_h[i],
+                       &st->sunset[i], &st->power_paused[i]);
+    eff = envelope_safety(eff, st->superpressure[i], 2380, &st->env_fsm[i]);
+    eff = altitude_safety(eff, &atm, st->pressure[i], &st->alt_fsm[i], &err);
+    if (effective_action) effective_action[i] = (uint8_t)eff;
+
+    sub_state s;
+    s.x = st->x[i]; s.y = st->y[i]; s.p = st->pressure[i]; s.t_amb = st->ambient_temperature[i];
+    s.t_int = st->internal_temperature[i]; s.vol = st->envelope_volume[i];
+    s.sp = st->superpressure[i]; s.n_air = st->mols_air[i]; s.batt = st->battery_charge[i];
+    s.acs_power = st->acs_power[i]; s.mdot = st->acs_mass_flow[i];
+    s.charge = st->solar_charging[i]; s.load = st->power_load[i];
+    s.t_elapsed = st->time_elapsed_s[i]; s.status = ST_OK;
+    for (int k = 0; k < substeps; ++k) { /* balloon.py:321-328 */
+      err |= simulate_step_internal(&s, u, v, &atm, eff, lat0, lng0, st->start_unix[i],
+                                    st->upwelling_infrared[i], 10.0);
+      if (s.status != ST_OK) break;
+    }
+    st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
+    st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol;
+    st->superpressure[i] = s.sp; st->mols_air[i] = s.n_air; st->battery_charge[i] = s.batt;
+    st->acs_power[i] = s.acs_power; st->acs_mass_flow[i] = s.mdot;
+    st->solar_charging[i] = s.charge; st->power_load[i] = s.load;
+    st->time_elapsed_s[i] = s.t_elapsed; st->status[i] = (uint8_t)s.status;
+    reward[i] = perciatelli_reward(&s, action[i], lat0, lng0, st->start_unix[i], &err);
+    terminal[i] = s.status != ST_OK;
+    err_all |= err;
+  }
+  return err_all;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Reset path: stable_init.py:40-157                                          */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* center_lat_deg,
+                            const double* center_lng_deg, const double* x, const double* y,
+                            const int64_t* unix_s, const double* ir, const double* alpha,
+                            double* t_amb, double* t_int, double* mols_air, double* volume,
+                            double* sp) {
+  int err_all = 0;
+#pragma omp parallel for schedule(static) reduction(| : err_all)
+  for (int64_t i = 0; i < n; ++i) {
+    int err = 0;
+    orc_atm atm;
+    orc_atm_init(alpha[i], &atm);
+    double h, ta;
+    err |= atm_at_pressure(&atm, pressure[i], &h, &ta);
+    double ma = ((pressure[i] * DRY_AIR_MOLAR_MASS * 1804 / (UNIVERSAL_GAS_CONSTANT * ta) - 68.5 -
+                  92.5 - HE_MOLAR_MASS * 6830.0) /
+                 DRY_AIR_MOLAR_MASS);
+    if (ma < 0.0) ma = 0.0;
+    double ti = 206.0;
+    double lat, lng, el, flux;
+    latlng_from_offset(radians(center_lat_deg[i]), radians(center_lng_deg[i]), x[i], y[i], &lat, &lng);
+    err |= solar_calculator(lat, lng, unix_s[i], &el, NULL, &flux);
+    double delta = 0.01;
+    for (int k = 0; k < 10; ++k) {
+      double d1 = d_balloon_temperature_dt(1804, 68.5, ti - delta / 2, ta, pressure[i], el, flux, ir[i], &err);
+      double d2 = d_balloon_temperature_dt(1804, 68.5, ti + delta / 2, ta, pressure[i], el, flux, ir[i], &err);
+      double d2t = (d2 - d1) / delta;
+      double mean = (d1 + d2) / 2.0;
+      if (fabs(d2t) > 0.0) ti -= (mean / d2t);
+      if (fabs(mean) < 1e-5) break;
+    }
+    t_amb[i] = ta;
+    t_int[i] = ti;
+    mols_air[i] = ma;
+    superpressure_and_volume(6830.0, ma, ti, pressure[i], 1804, 0.0199, &volume[i], &sp[i]);
+    err_all |= err;
+  }
+  return err_all;
+}
+
+ORC_API double orc_reward_only(double x, double y, double p, double batt, double acs_power,
+                               int last_command, double lat_deg, double lng_deg,
+                               int64_t start_unix, int64_t elapsed) {
+  sub_state s;
+  memset(&s, 0, sizeof s);
+  s.x = x; s.y = y; s.p = p; s.batt = batt; s.acs_power = acs_power; s.t_elapsed = elapsed;
+  int err = 0;
+  return perciatelli_reward(&s, last_command, radians(lat_deg), radians(lng_deg), start_unix, &err);
+}
+
+ORC_API int orc_abi_version(void) { return 1; }

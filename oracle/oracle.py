@@ -1,0 +1,278 @@
+"""ctypes front-end for the CPU oracle (oracle/ble_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (balloon_learning_environment_amd) never
+imports this module and has no CPU fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libble_oracle.so')
+
+FLOAT_FIELDS = ('x', 'y', 'pressure', 'ambient_temperature', 'internal_temperature',
+                'envelope_volume', 'superpressure', 'mols_air', 'battery_charge',
+                'acs_power', 'acs_mass_flow', 'solar_charging', 'power_load',
+                'center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha')
+I64_FIELDS = ('start_unix', 'time_elapsed_s', 'sunrise_h', 'sunset')
+U8_FIELDS = ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused')
+ALL_FIELDS = FLOAT_FIELDS + I64_FIELDS + U8_FIELDS
+
+ERR_PRESSURE_RANGE, ERR_ABSORPTIVITY, ERR_SOLAR_RANGE, ERR_TERMINAL_STEP, ERR_POWER_TABLE = 1, 2, 4, 8, 16
+
+
+class _State(ctypes.Structure):
+  _fields_ = ([(f, ctypes.POINTER(ctypes.c_double)) for f in FLOAT_FIELDS] +
+              [(f, ctypes.POINTER(ctypes.c_int64)) for f in I64_FIELDS] +
+              [(f, ctypes.POINTER(ctypes.c_uint8)) for f in U8_FIELDS])
+
+
+def build(force: bool = False) -> str:
+  src = os.path.join(_HERE, 'ble_oracle.c')
+  if force or not os.path.exists(_LIB_PATH) or (
+      os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)):
+    subprocess.check_call(['make', '-C', _HERE, '-s', '-B', 'libble_oracle.so'])
+  return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    build()
+    _lib = ctypes.CDLL(_LIB_PATH)
+    _lib.orc_reward_only.restype = ctypes.c_double
+  return _lib
+
+
+def _d(a):
+  return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, ct):
+  return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _pd(a):
+  return _p(a, ctypes.c_double)
+
+
+def at_pressure(alpha, p):
+  p = _d(np.atleast_1d(p)); n = p.size
+  h, t, rho = np.empty(n), np.empty(n), np.empty(n)
+  err = lib().orc_at_pressure(ctypes.c_double(alpha), ctypes.c_int64(n), _pd(p), _pd(h), _pd(t), _pd(rho))
+  return h, t, rho, err
+
+
+def at_height(alpha, h):
+  h = _d(np.atleast_1d(h)); n = h.size
+  p, t, rho = np.empty(n), np.empty(n), np.empty(n)
+  err = lib().orc_at_height(ctypes.c_double(alpha), ctypes.c_int64(n), _pd(h), _pd(p), _pd(t), _pd(rho))
+  return p, t, rho, err
+
+
+def atm_tables(alpha):
+  buf = np.empty(23)
+  lib().orc_atm_init(ctypes.c_double(alpha), _pd(buf))
+  return buf[:7].copy(), buf[7:15].copy(), buf[15:23].copy()
+
+
+def solar_calculator(lat_rad, lng_rad, unix_s):
+  lat, lng = _d(np.atleast_1d(lat_rad)), _d(np.atleast_1d(lng_rad))
+  t = np.ascontiguousarray(np.atleast_1d(unix_s), dtype=np.int64); n = t.size
+  el, az, fl = np.empty(n), np.empty(n), np.empty(n)
+  err = lib().orc_solar_calculator(ctypes.c_int64(n), _pd(lat), _pd(lng), _p(t, ctypes.c_int64),
+                                   _pd(el), _pd(az), _pd(fl))
+  return el, az, fl, err
+
+
+def solar_attenuation(el, p):
+  el, p = _d(np.atleast_1d(el)), _d(np.atleast_1d(p)); out = np.empty(el.size)
+  err = lib().orc_solar_attenuation(ctypes.c_int64(el.size), _pd(el), _pd(p), _pd(out))
+  return out, err
+
+
+def balloon_shadow(el, h):
+  el, h = _d(np.atleast_1d(el)), _d(np.atleast_1d(h)); out = np.empty(el.size)
+  lib().orc_balloon_shadow(ctypes.c_int64(el.size), _pd(el), _pd(h), _pd(out))
+  return out
+
+
+def solar_power(el, p):
+  el, p = _d(np.atleast_1d(el)), _d(np.atleast_1d(p)); out = np.empty(el.size)
+  err = lib().orc_solar_power(ctypes.c_int64(el.size), _pd(el), _pd(p), _pd(out))
+  return out, err
+
+
+def latlng_from_offset(lat0_rad, lng0_rad, x, y):
+  a, b, x, y = (_d(np.atleast_1d(v)) for v in (lat0_rad, lng0_rad, x, y))
+  lat, lng = np.empty(x.size), np.empty(x.size)
+  lib().orc_latlng_from_offset(ctypes.c_int64(x.size), _pd(a), _pd(b), _pd(x), _pd(y), _pd(lat), _pd(lng))
+  return lat, lng
+
+
+def next_sunrise_sunset(lat_rad, lng_rad, unix_s):
+  lat, lng = _d(np.atleast_1d(lat_rad)), _d(np.atleast_1d(lng_rad))
+  t = np.ascontiguousarray(np.atleast_1d(unix_s), dtype=np.int64)
+  sr, ss = np.empty(t.size, np.int64), np.empty(t.size, np.int64)
+  lib().orc_next_sunrise_sunset(ctypes.c_int64(t.size), _pd(lat), _pd(lng), _p(t, ctypes.c_int64),
+                                _p(sr, ctypes.c_int64), _p(ss, ctypes.c_int64))
+  return sr, ss
+
+
+def thermal_dtdt(v, t_int, t_amb, p, el, flux, ir):
+  arrs = [_d(np.atleast_1d(a)) for a in (v, t_int, t_amb, p, el, flux, ir)]
+  out = np.empty(arrs[0].size)
+  err = lib().orc_thermal_dtdt(ctypes.c_int64(out.size), *[_pd(a) for a in arrs], _pd(out))
+  return out, err
+
+
+def sp_volume(mols_air, t_int, p):
+  arrs = [_d(np.atleast_1d(a)) for a in (mols_air, t_int, p)]
+  vol, sp = np.empty(arrs[0].size), np.empty(arrs[0].size)
+  lib().orc_sp_volume(ctypes.c_int64(vol.size), *[_pd(a) for a in arrs], _pd(vol), _pd(sp))
+  return vol, sp
+
+
+def acs(pr):
+  pr = _d(np.atleast_1d(pr)); n = pr.size
+  power, eff, mdot = np.empty(n), np.empty(n), np.empty(n)
+  lib().orc_acs(ctypes.c_int64(n), _pd(pr), _pd(power), _pd(eff), _pd(mdot))
+  return power, eff, mdot
+
+
+def acs_efficiency(pr, power):
+  pr, power = _d(np.atleast_1d(pr)), _d(np.atleast_1d(power)); eff = np.empty(pr.size)
+  lib().orc_acs_efficiency(ctypes.c_int64(pr.size), _pd(pr), _pd(power), _pd(eff))
+  return eff
+
+
+def power_table(pr, soc):
+  pr, soc = _d(np.atleast_1d(pr)), _d(np.atleast_1d(soc)); w = np.empty(pr.size)
+  err = lib().orc_power_table(ctypes.c_int64(pr.size), _pd(pr), _pd(soc), _pd(w))
+  return w, err
+
+
+def altitude_safety_trace(alpha, actions, pressures, fsm0=0):
+  a = np.ascontiguousarray(actions, np.uint8); p = _d(pressures)
+  oa, of = np.empty(a.size, np.uint8), np.empty(a.size, np.uint8)
+  err = lib().orc_altitude_safety_trace(ctypes.c_double(alpha), ctypes.c_int64(a.size),
+                                        _p(a, ctypes.c_uint8), _pd(p), ctypes.c_uint8(fsm0),
+                                        _p(oa, ctypes.c_uint8), _p(of, ctypes.c_uint8))
+  return oa, of, err
+
+
+def envelope_safety_trace(actions, sps, fsm0=0):
+  a = np.ascontiguousarray(actions, np.uint8); s = _d(sps)
+  oa, of = np.empty(a.size, np.uint8), np.empty(a.size, np.uint8)
+  lib().orc_envelope_safety_trace(ctypes.c_int64(a.size), _p(a, ctypes.c_uint8), _pd(s),
+                                  ctypes.c_uint8(fsm0), _p(oa, ctypes.c_uint8), _p(of, ctypes.c_uint8))
+  return oa, of
+
+
+def power_safety_trace(actions, now, batt, sunrise_h0, sunset0, paused0=0, load_w=183.7, cap_wh=3058.56):
+  a = np.ascontiguousarray(actions, np.uint8); t = np.ascontiguousarray(now, np.int64); b = _d(batt)
+  n = a.size
+  oa, op = np.empty(n, np.uint8), np.empty(n, np.uint8)
+  osr, oss = np.empty(n, np.int64), np.empty(n, np.int64)
+  lib().orc_power_safety_trace(ctypes.c_int64(n), _p(a, ctypes.c_uint8), _p(t, ctypes.c_int64), _pd(b),
+                               ctypes.c_double(load_w), ctypes.c_double(cap_wh),
+                               ctypes.c_int64(int(sunrise_h0)), ctypes.c_int64(int(sunset0)),
+                               ctypes.c_uint8(paused0), _p(oa, ctypes.c_uint8),
+                               _p(osr, ctypes.c_int64), _p(oss, ctypes.c_int64), _p(op, ctypes.c_uint8))
+  return oa, osr, oss, op
+
+
+def wind_forecast(field, x_m, y_m, p, elapsed_s):
+  field = np.ascontiguousarray(field, np.float32)
+  assert field.shape == (21, 21, 10, 9, 2)
+  x, y, p = (_d(np.atleast_1d(v)) for v in (x_m, y_m, p))
+  t = np.ascontiguousarray(np.atleast_1d(elapsed_s), np.int64)
+  u, v = np.empty(x.size), np.empty(x.size)
+  lib().orc_wind_forecast(_p(field, ctypes.c_float), ctypes.c_int64(x.size), _pd(x), _pd(y), _pd(p),
+                          _p(t, ctypes.c_int64), _pd(u), _pd(v))
+  return u, v
+
+
+def stable_init(pressure, lat_deg, lng_deg, x, y, unix_s, ir, alpha):
+  arrs = [_d(np.atleast_1d(a)) for a in (pressure, lat_deg, lng_deg, x, y)]
+  t = np.ascontiguousarray(np.atleast_1d(unix_s), np.int64)
+  ir, alpha = _d(np.atleast_1d(ir)), _d(np.atleast_1d(alpha))
+  n = t.size
+  outs = [np.empty(n) for _ in range(5)]
+  err = lib().orc_stable_init(ctypes.c_int64(n), *[_pd(a) for a in arrs], _p(t, ctypes.c_int64),
+                              _pd(ir), _pd(alpha), *[_pd(o) for o in outs])
+  return dict(zip(('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume',
+                   'superpressure'), outs)), err
+
+
+def reward_only(x, y, p, batt, acs_power, last_command, lat_deg, lng_deg, start_unix, elapsed):
+  return lib().orc_reward_only(ctypes.c_double(x), ctypes.c_double(y), ctypes.c_double(p),
+                               ctypes.c_double(batt), ctypes.c_double(acs_power),
+                               ctypes.c_int(last_command), ctypes.c_double(lat_deg),
+                               ctypes.c_double(lng_deg), ctypes.c_int64(start_unix),
+                               ctypes.c_int64(elapsed))
+
+
+def new_state(n):
+  st = {}
+  for f in FLOAT_FIELDS:
+    st[f] = np.zeros(n, np.float64)
+  for f in I64_FIELDS:
+    st[f] = np.zeros(n, np.int64)
+  for f in U8_FIELDS:
+    st[f] = np.zeros(n, np.uint8)
+  return st
+
+
+def coerce_state(state):
+  """Returns a dict of contiguous oracle-typed arrays (copies) from any array-likes."""
+  out = {}
+  for f in FLOAT_FIELDS:
+    out[f] = np.array(state[f], dtype=np.float64, copy=True, order='C')
+  for f in I64_FIELDS:
+    out[f] = np.array(state[f], dtype=np.int64, copy=True, order='C')
+  for f in U8_FIELDS:
+    out[f] = np.array(state[f], dtype=np.uint8, copy=True, order='C')
+  return out
+
+
+def step(state, action, field=None, wind_uv=None, noise_uv=None, substeps=18, threads=1):
+  """In-place agent step on an oracle state dict. Returns (reward, terminal, effective_action, err)."""
+  n = state['x'].size
+  cst = _State()
+  for f in FLOAT_FIELDS:
+    assert state[f].dtype == np.float64 and state[f].flags.c_contiguous, f
+    setattr(cst, f, _pd(state[f]))
+  for f in I64_FIELDS:
+    assert state[f].dtype == np.int64, f
+    setattr(cst, f, _p(state[f], ctypes.c_int64))
+  for f in U8_FIELDS:
+    assert state[f].dtype == np.uint8, f
+    setattr(cst, f, _p(state[f], ctypes.c_uint8))
+  action = np.ascontiguousarray(action, np.uint8)
+  assert action.size == n
+  fptr = None
+  if field is not None:
+    field = np.ascontiguousarray(field, np.float32)
+    assert field.shape == (21, 21, 10, 9, 2)
+    fptr = _p(field, ctypes.c_float)
+  wptr = None
+  if wind_uv is not None:
+    wind_uv = _d(wind_uv); assert wind_uv.shape == (n, 2)
+    wptr = _pd(wind_uv)
+  assert fptr is not None or wptr is not None
+  nptr = None
+  if noise_uv is not None:
+    noise_uv = _d(noise_uv); assert noise_uv.shape == (n, 2)
+    nptr = _pd(noise_uv)
+  reward = np.empty(n); terminal = np.empty(n, np.uint8); eff = np.empty(n, np.uint8)
+  err = lib().orc_step(ctypes.byref(cst), _p(action, ctypes.c_uint8), fptr, wptr, nptr, _pd(reward),
+                       _p(terminal, ctypes.c_uint8), _p(eff, ctypes.c_uint8), ctypes.c_int64(n),
+                       ctypes.c_int(substeps), ctypes.c_int(threads))
+  return reward, terminal, eff, err
