@@ -1,0 +1,40 @@
+"""ctypes mirror of include/ble_abi.h (struct ble_state_f32 and field metadata)."""
+import ctypes
+
+import numpy as np
+
+# (name, numpy dtype, ctypes scalar type, mutable?) in the order of struct ble_state_f32.
+STATE_FIELDS = (
+    ('x', np.float32, ctypes.c_float), ('y', np.float32, ctypes.c_float),
+    ('pressure', np.float32, ctypes.c_float), ('ambient_temperature', np.float32, ctypes.c_float),
+    ('internal_temperature', np.float32, ctypes.c_float), ('envelope_volume', np.float32, ctypes.c_float),
+    ('superpressure', np.float32, ctypes.c_float), ('mols_air', np.float32, ctypes.c_float),
+    ('battery_charge', np.float32, ctypes.c_float),
+    ('acs_power', np.float32, ctypes.c_float), ('acs_mass_flow', np.float32, ctypes.c_float),
+    ('solar_charging', np.float32, ctypes.c_float), ('power_load', np.float32, ctypes.c_float),
+    ('center_lat_deg', np.float32, ctypes.c_float), ('center_lng_deg', np.float32, ctypes.c_float),
+    ('upwelling_infrared', np.float32, ctypes.c_float), ('alpha', np.float32, ctypes.c_float),
+    ('start_unix', np.int64, ctypes.c_int64),
+    ('time_elapsed_s', np.int32, ctypes.c_int32),
+    ('sunrise_h_rel', np.int32, ctypes.c_int32), ('sunset_rel', np.int32, ctypes.c_int32),
+    ('status', np.uint8, ctypes.c_uint8), ('last_command', np.uint8, ctypes.c_uint8),
+    ('alt_fsm', np.uint8, ctypes.c_uint8), ('env_fsm', np.uint8, ctypes.c_uint8),
+    ('power_paused', np.uint8, ctypes.c_uint8),
+)
+FIELD_NAMES = tuple(f[0] for f in STATE_FIELDS)
+FIELD_DTYPES = {f[0]: f[1] for f in STATE_FIELDS}
+MUTABLE_FLOATS = FIELD_NAMES[:9]
+DERIVED_FLOATS = FIELD_NAMES[9:13]
+EPISODE_CONSTS = FIELD_NAMES[13:18]
+
+
+class BleStateF32(ctypes.Structure):
+  _fields_ = [(name, ctypes.POINTER(ct)) for name, _, ct in STATE_FIELDS]
+
+
+def state_struct(pointers):
+  """Builds a BleStateF32 from a {field: integer address} mapping."""
+  st = BleStateF32()
+  for name, _, ct in STATE_FIELDS:
+    setattr(st, name, ctypes.cast(ctypes.c_void_p(int(pointers[name])), ctypes.POINTER(ct)))
+  return st

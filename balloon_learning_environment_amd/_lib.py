@@ -1,0 +1,89 @@
+"""Loader for libble_hip.so (the C ABI in include/ble_abi.h).
+
+The HIP library is the ONLY compute path of this package.  If it is missing or cannot
+be loaded the import of anything that needs it raises -- there is no CPU fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+from balloon_learning_environment_amd import _abi
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'libble_hip.so')
+_SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_step_core.h', 'ble_physics.h')]
+_HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
+
+ABI_VERSION = 1
+BLE_OK = 0
+FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
+
+# every symbol include/ble_abi.h declares
+EXPORTS = ('ble_abi_version', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_forecast_f32',
+           'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32',
+           'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32')
+
+
+class BleLibraryError(RuntimeError):
+  pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+  """Compiles csrc/ble_kernels.hip for gfx950 into libble_hip.so (in-tree)."""
+  deps = _SOURCES + [_HEADER]
+  stale = (not os.path.exists(LIB_PATH) or
+           any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps))
+  if force or stale:
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+      hipcc = 'hipcc'
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH, _SOURCES[0]]
+    if verbose:
+      cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+    subprocess.check_call(cmd)
+  return LIB_PATH
+
+
+_lib = None
+_vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+
+
+def lib():
+  """Returns the loaded library; raises BleLibraryError if it is not there."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise BleLibraryError(
+        f'{LIB_PATH} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        '(hipcc --offload-arch=gfx950). This package has no CPU fallback.')
+  try:
+    l = ctypes.CDLL(LIB_PATH)
+  except OSError as e:  # e.g. libamdhip64 missing
+    raise BleLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+  for name in EXPORTS:
+    if not hasattr(l, name):
+      raise BleLibraryError(f'{LIB_PATH} does not export {name}')
+  if l.ble_abi_version() != ABI_VERSION:
+    raise BleLibraryError('ABI version mismatch between libble_hip.so and the Python mirror')
+  st = ctypes.POINTER(_abi.BleStateF32)
+  l.ble_step_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]
+  l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
+  l.ble_forecast_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_forecast_column_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]
+  l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_atmosphere_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_solar_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_solar_power_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_thermal_f32.argtypes = [_vp] * 9 + [_i64, _vp]
+  l.ble_probe_sp_volume_f32.argtypes = [_vp] * 5 + [_i64, _vp]
+  l.ble_probe_acs_f32.argtypes = [_vp] * 4 + [_i64, _vp]
+  for name in EXPORTS:
+    getattr(l, name).restype = _int
+  _lib = l
+  return l
+
+
+def check(code: int, what: str) -> None:
+  if code != BLE_OK:
+    raise BleLibraryError(f'{what} failed with BLE error {code}')

@@ -1,0 +1,377 @@
+// ble_kernels.hip -- gfx950 (MI355X, CDNA4) kernels and the C ABI of libble_hip.so.
+//
+// Execution model: one wavefront lane per environment, 64-thread workgroups (one wave),
+// so N = 65 536 environments is 1 024 workgroups = one wave on every SIMD of the 256 CUs.
+// The state is struct-of-arrays: every load/store below is a fully coalesced
+// 64-lane x 4 B (or 1 B) transaction.  The 317 KB wind grid is shared by all lanes and is
+// served from the per-XCD L2 after first touch; each lane gathers its 16 corners as
+// 8 x (4 contiguous floats).  Nothing here is a dense contraction: no MFMA.
+// Target: gfx950 only (hipcc --offload-arch=gfx950); no other backend, no shims.
+#include <hip/hip_runtime.h>
+
+#include "../../include/ble_abi.h"
+#include "ble_step_core.h"
+
+using namespace ble;
+
+namespace {
+
+constexpr int kBlock = 64;  // one wavefront per workgroup
+
+__device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags) {
+  // wave-level OR, one atomic per wave at most (normally none)
+  if (err_flags == nullptr) return;
+  if (__any(flags != 0)) {
+    for (int off = 32; off > 0; off >>= 1) flags |= __shfl_xor(flags, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(err_flags, flags);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
+                                                          const float* __restrict__ wind_grid,
+                                                          int64_t grid_env_stride,
+                                                          const float* __restrict__ noise_uv,
+                                                          float* __restrict__ reward,
+                                                          uint8_t* __restrict__ terminal,
+                                                          uint8_t* __restrict__ effective_action,
+                                                          uint32_t* err_flags, unsigned long long* active_count,
+                                                          int64_t n, int substeps) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool in_range = i < n;
+  bool live = false;
+  uint32_t flags = 0;
+  if (in_range) {
+    const uint8_t status = st.status[i];
+    live = status == kOk;
+    if (!live) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
+      reward[i] = 0.0f;
+      terminal[i] = 1;
+      if (effective_action) effective_action[i] = action[i];
+    }
+  }
+  if (active_count) {
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(active_count, (unsigned long long)__popcll(m));
+  }
+  if (live) {
+    EnvRegs s;
+    s.x = st.x[i]; s.y = st.y[i]; s.p = st.pressure[i]; s.t_amb = st.ambient_temperature[i];
+    s.t_int = st.internal_temperature[i]; s.vol = st.envelope_volume[i]; s.sp = st.superpressure[i];
+    s.n_air = st.mols_air[i]; s.batt = st.battery_charge[i];
+    s.acs_power = 0.0f; s.mdot = 0.0f; s.charge = 0.0f; s.load = 0.0f;
+    s.t_elapsed = st.time_elapsed_s[i]; s.sunrise_h = st.sunrise_h_rel[i]; s.sunset = st.sunset_rel[i];
+    s.status = kOk; s.alt_fsm = st.alt_fsm[i]; s.env_fsm = st.env_fsm[i]; s.paused = st.power_paused[i];
+    EnvConst c;
+    c.lat0_deg = st.center_lat_deg[i]; c.lng0_deg = st.center_lng_deg[i];
+    c.ir = st.upwelling_infrared[i]; c.alpha = st.alpha[i]; c.start_unix = st.start_unix[i];
+    const int act = action[i];
+
+    // wind at the PRE-step position/time (balloon_arena.py:194,270-275)
+    float u, v;
+    {
+      const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+      wind_blend(wind_grid + i * grid_env_stride, wq, &u, &v);
+      if (noise_uv) { u += noise_uv[2 * i]; v += noise_uv[2 * i + 1]; }
+    }
+
+    float r;
+    const int eff = agent_step(s, c, act, u, v, substeps, &r, &flags);
+
+    if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
+      flags |= kFlagNonFinite;
+
+    st.x[i] = s.x; st.y[i] = s.y; st.pressure[i] = s.p; st.ambient_temperature[i] = s.t_amb;
+    st.internal_temperature[i] = s.t_int; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp;
+    st.mols_air[i] = s.n_air; st.battery_charge[i] = s.batt;
+    st.acs_power[i] = s.acs_power; st.acs_mass_flow[i] = s.mdot; st.solar_charging[i] = s.charge;
+    st.power_load[i] = s.load;
+    st.time_elapsed_s[i] = s.t_elapsed; st.sunrise_h_rel[i] = s.sunrise_h; st.sunset_rel[i] = s.sunset;
+    st.status[i] = s.status; st.last_command[i] = (uint8_t)act;
+    st.alt_fsm[i] = s.alt_fsm; st.env_fsm[i] = s.env_fsm; st.power_paused[i] = s.paused;
+    reward[i] = r;
+    terminal[i] = s.status != kOk;
+    if (effective_action) effective_action[i] = (uint8_t)eff;
+  }
+  report_flags(flags, err_flags);
+}
+
+__global__ __launch_bounds__(256) void ble_forecast_kernel(const float* __restrict__ wind_grid,
+                                                           int64_t grid_env_stride, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ pressure,
+                                                           const int32_t* __restrict__ elapsed, float* __restrict__ u,
+                                                           float* __restrict__ v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const WindQuery wq = wind_query(x[i], y[i], pressure[i], elapsed[i]);
+  float uu, vv;
+  wind_blend(wind_grid + i * grid_env_stride, wq, &uu, &vv);
+  u[i] = uu; v[i] = vv;
+}
+
+// get_forecast_column (grid_based_wind_field.py:96-132): one wave per column.  The wave
+// first collapses the (x, y, t) axes: lanes 0..19 each own one (pressure node, component)
+// and blend its 8 (x, y, t) corners -- the "local pressure column" -- into LDS; then every
+// lane interpolates its pressure levels from the 10-node column held in LDS.
+__global__ __launch_bounds__(kBlock) void ble_forecast_column_kernel(
+    const float* __restrict__ wind_grid, int64_t grid_env_stride, const float* __restrict__ x,
+    const float* __restrict__ y, const int32_t* __restrict__ elapsed, const float* __restrict__ levels,
+    int n_levels, float* __restrict__ out_uv, int64_t n) {
+  __shared__ float column[BLE_GRID_NP * 2];
+  const int64_t env = blockIdx.x;
+  if (env >= n) return;
+  const int lane = threadIdx.x;
+  const WindQuery wq = wind_query(x[env], y[env], 5000.0f, elapsed[env]);
+  const float* grid = wind_grid + env * grid_env_stride;
+  if (lane < BLE_GRID_NP * 2) {
+    const int ip = lane >> 1, comp = lane & 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
+          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
+        }
+    column[lane] = acc;
+  }
+  __syncthreads();
+  for (int l = lane; l < n_levels; l += kBlock) {
+    const float p = f_clamp(levels[l], 5000.0f, 14000.0f);
+    int ip; float wp;
+    wind_axis(p, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
+    const float u = f_fma(wp, column[(ip + 1) * 2] - column[ip * 2], column[ip * 2]);
+    const float v = f_fma(wp, column[(ip + 1) * 2 + 1] - column[ip * 2 + 1], column[ip * 2 + 1]);
+    out_uv[(env * n_levels + l) * 2] = u;
+    out_uv[(env * n_levels + l) * 2 + 1] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ble_power_table_kernel(const float* __restrict__ pr,
+                                                              const float* __restrict__ soc, float* __restrict__ watts,
+                                                              uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n) watts[i] = power_table_lookup(pr[i], soc[i], &flags);
+  report_flags(flags, err_flags);
+}
+
+// ---- probes: the same lane functions, one element per lane ----
+__global__ __launch_bounds__(256) void probe_atmosphere_kernel(const float* alpha, const float* pressure, float* height,
+                                                               float* temperature, uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n) {
+    const double p = (double)pressure[i];
+    const AtmLayerD l = atm_select_f64((double)alpha[i], p);
+    if (!(p > l.p_top) || !(p <= 108870.8213)) flags |= kFlagPressureRange;
+    double h, t;
+    atm_at_pressure_f64(l, p, &h, &t);
+    height[i] = (float)h; temperature[i] = (float)t;
+  }
+  report_flags(flags, err_flags);
+}
+__global__ __launch_bounds__(256) void probe_solar_kernel(const float* lat0, const float* lng0, const float* x,
+                                                          const float* y, const int64_t* unix_s, float* el_deg,
+                                                          float* flux, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Ephemeris e = ephemeris(unix_s[i]);
+  int64_t sod = unix_s[i] % 86400;
+  if (sod < 0) sod += 86400;
+  const double b = (double)sod * (1.0 / 240.0) + 0.25 * e.eot_min + (double)lng0[i];
+  double sl, cl;
+  sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
+  const double oms = sun_one_minus_sin_f64(sl, cl, (double)x[i], (double)y[i], b, e.sin_decl, e.cos_decl);
+  const SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
+  el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
+  flux[i] = (float)e.flux;
+}
+__global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_deg, const float* pressure, float* att,
+                                                                float* power, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
+  uint32_t flags = 0;
+  const float a = solar_attenuation((float)s, pressure[i], &flags);
+  att[i] = a;
+  power[i] = solar_power((float)s, (float)c, a);
+}
+__global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume, const float* t_int, const float* t_amb,
+                                                            const float* pressure, const float* el_deg,
+                                                            const float* flux, const float* ir, float* dtdt,
+                                                            uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n) {
+    double s, c;
+    sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
+    const float att = solar_attenuation((float)s, pressure[i], &flags);
+    const float rho = pressure[i] * kAirMolarOverR * f_rcp(t_amb[i]);
+    const float v23 = f_exp2((2.0f / 3.0f) * f_log2(volume[i]));
+    dtdt[i] = thermal_dtdt(v23, t_int[i], t_amb[i], rho, flux[i] * att, earth_heat_per_area(ir[i], &flags), &flags);
+  }
+  report_flags(flags, err_flags);
+}
+__global__ __launch_bounds__(256) void probe_sp_volume_kernel(const float* mols_air, const float* t_int,
+                                                              const float* pressure, float* volume, float* sp,
+                                                              int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v, s;
+  superpressure_volume_f64((double)mols_air[i], (double)t_int[i], (double)pressure[i], &v, &s);
+  volume[i] = (float)v; sp[i] = (float)s;
+}
+__global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* power, float* eff, float* mdot,
+                                                        int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float prm1 = pr[i] - 1.0f;
+  const float w = acs_power(prm1);
+  const float e = acs_efficiency(prm1, w);
+  power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? BLE_OK : BLE_E_LAUNCH; }
+inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+inline bool state_ok(const ble_state_f32* st) {
+  if (!st) return false;
+  const void* const* p = reinterpret_cast<const void* const*>(st);
+  for (size_t k = 0; k < sizeof(ble_state_f32) / sizeof(void*); ++k)
+    if (p[k] == nullptr) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ble_abi_version(void) { return BLE_ABI_VERSION; }
+
+int ble_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BLE_E_NO_DEVICE;
+  return n;
+}
+
+int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
+                 const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action,
+                 uint32_t* err_flags, unsigned long long* active_count, int64_t n, int substeps, void* stream) {
+  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 ||
+      grid_env_stride < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+                     wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
+                     active_count, n, substeps);
+  return launch_status();
+}
+
+int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
+                   float* reward, uint8_t* terminal, uint32_t* err_flags, unsigned long long* active_count,
+                   int64_t n, int substeps, int n_steps, void* stream) {
+  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || n_steps < 0 ||
+      grid_env_stride < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  for (int k = 0; k < n_steps; ++k) {
+    hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st,
+                       action + (int64_t)k * n, wind_grid, grid_env_stride, (const float*)nullptr,
+                       reward + (int64_t)k * n, terminal + (int64_t)k * n, (uint8_t*)nullptr, err_flags,
+                       active_count ? active_count + k : nullptr, n, substeps);
+  }
+  return launch_status();
+}
+
+int ble_forecast_f32(const float* wind_grid, int64_t grid_env_stride, const float* x_m, const float* y_m,
+                     const float* pressure, const int32_t* elapsed_s, float* u, float* v, int64_t n, void* stream) {
+  if (!wind_grid || !x_m || !y_m || !pressure || !elapsed_s || !u || !v || n < 0 || grid_env_stride < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(ble_forecast_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, wind_grid,
+                     grid_env_stride, x_m, y_m, pressure, elapsed_s, u, v, n);
+  return launch_status();
+}
+
+int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, const float* x_m, const float* y_m,
+                            const int32_t* elapsed_s, const float* levels_pa, int n_levels, float* out_uv, int64_t n,
+                            void* stream) {
+  if (!wind_grid || !x_m || !y_m || !elapsed_s || !levels_pa || !out_uv || n < 0 || n_levels < 1 ||
+      grid_env_stride < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(ble_forecast_column_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, wind_grid,
+                     grid_env_stride, x_m, y_m, elapsed_s, levels_pa, n_levels, out_uv, n);
+  return launch_status();
+}
+
+int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts, uint32_t* err_flags,
+                        int64_t n, void* stream) {
+  if (!pressure_ratio || !state_of_charge || !watts || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(ble_power_table_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
+                     state_of_charge, watts, err_flags, n);
+  return launch_status();
+}
+
+int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* height, float* temperature,
+                             uint32_t* err_flags, int64_t n, void* stream) {
+  if (!alpha || !pressure || !height || !temperature || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_atmosphere_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, pressure,
+                     height, temperature, err_flags, n);
+  return launch_status();
+}
+
+int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg, const float* x_m, const float* y_m,
+                        const int64_t* unix_s, float* el_deg, float* flux, int64_t n, void* stream) {
+  if (!center_lat_deg || !center_lng_deg || !x_m || !y_m || !unix_s || !el_deg || !flux || n < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_solar_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, center_lat_deg,
+                     center_lng_deg, x_m, y_m, unix_s, el_deg, flux, n);
+  return launch_status();
+}
+
+int ble_probe_solar_power_f32(const float* el_deg, const float* pressure, float* attenuation, float* power_w,
+                              int64_t n, void* stream) {
+  if (!el_deg || !pressure || !attenuation || !power_w || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_solar_power_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, el_deg,
+                     pressure, attenuation, power_w, n);
+  return launch_status();
+}
+
+int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* t_amb, const float* pressure,
+                          const float* el_deg, const float* flux, const float* upwelling_ir, float* dtdt,
+                          uint32_t* err_flags, int64_t n, void* stream) {
+  if (!volume || !t_int || !t_amb || !pressure || !el_deg || !flux || !upwelling_ir || !dtdt || n < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_thermal_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, volume, t_int,
+                     t_amb, pressure, el_deg, flux, upwelling_ir, dtdt, err_flags, n);
+  return launch_status();
+}
+
+int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const float* pressure, float* volume,
+                            float* superpressure, int64_t n, void* stream) {
+  if (!mols_air || !t_int || !pressure || !volume || !superpressure || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
+                     pressure, volume, superpressure, n);
+  return launch_status();
+}
+
+int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency, float* mass_flow, int64_t n,
+                      void* stream) {
+  if (!pressure_ratio || !power_w || !efficiency || !mass_flow || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_acs_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
+                     power_w, efficiency, mass_flow, n);
+  return launch_status();
+}
+
+}  // extern "C"

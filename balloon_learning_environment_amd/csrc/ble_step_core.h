@@ -1,0 +1,180 @@
+// ble_step_core.h -- one agent step of one environment, in registers.
+//
+// Balloon.simulate_step (env/balloon/balloon.py:263-328) with _simulate_step_internal
+// (:356-549) inlined, preceded by the three safety layers (:304-313) and followed by
+// perciatelli_reward_function (env/balloon_env.py:44-102).  Called by the HIP kernel in
+// ble_kernels.hip with one lane per environment; also compiled on the host by tests/emul.
+//
+// Precision map.  The reference's vertical dynamics are an UNSTABLE map near float
+// equilibrium: dh/dt = +-sqrt(|rho V - m| ...) has unbounded gain where rho V - m -> 0 and
+// |gain| ~ 1.5-3 per 10 s substep in the quasi-steady regime, so a 1e-7 relative error in
+// anything that feeds rho V - m (p, T_amb(p), V(n_air, T_int, p)) grows to O(1 Pa) within
+// one agent step.  That chain -- p, T_amb, T_int, n_air, V, superpressure and the
+// difference itself -- is therefore carried in fp64 registers across the 18 substeps
+// (inputs and outputs stay fp32).  Everything that only produces *increments* (thermal
+// model, ACS, solar geometry and power, dH series, drag) is fp32.
+#pragma once
+#include "ble_physics.h"
+
+namespace ble {
+
+struct EnvRegs {
+  float x, y, p, t_amb, t_int, vol, sp, n_air, batt;
+  float acs_power, mdot, charge, load;
+  int32_t t_elapsed, sunrise_h, sunset;
+  uint8_t status, alt_fsm, env_fsm, paused;
+};
+struct EnvConst {
+  float lat0_deg, lng0_deg, ir, alpha;
+  int64_t start_unix;
+};
+
+// Returns the effective action (after the safety layers).  `reward` gets the post-step
+// reward; `s` is advanced in place.  Precondition: s.status == kOk.
+BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float v, int substeps,
+                      float* reward, uint32_t* flags) {
+  // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
+  double p = (double)s.p;
+  AtmLayerD layer_d = atm_select_f64((double)c.alpha, p);
+  if (!(p > layer_d.p_top) || !(p <= 108870.8213)) *flags |= kFlagPressureRange;
+  double altitude, t_at_p;
+  atm_at_pressure_f64(layer_d, p, &altitude, &t_at_p);
+  AtmLayer layer = atm_layer_f32(layer_d, c.alpha);
+
+  // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
+  int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
+  eff = envelope_safety(eff, s.sp, &s.env_fsm);
+  eff = altitude_safety(eff, altitude, &s.alt_fsm);
+
+  // ---- per-step constants
+  const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
+  const Ephemeris e0 = ephemeris(t0);
+  const Ephemeris e1 = ephemeris(t0 + (int64_t)(10 * substeps));
+  const double inv_n = 1.0 / (double)substeps;
+  const float fl0 = (float)e0.flux, dfl = (float)((e1.flux - e0.flux) * inv_n);
+  // Solar geometry: 1 - sin(el_uncorrected) at substep indices 0, n/2, n in fp64, then a
+  // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
+  float oms_c0, oms_c1, oms_c2;
+  {
+    int64_t sod = t0 % 86400;
+    if (sod < 0) sod += 86400;
+    // hour-angle base B = 360 frac_day + eot/4 + lng0  [deg]  (solar.py:113-116)
+    const double b0 = (double)sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)c.lng0_deg;
+    const double b2 = b0 + (double)substeps * (10.0 / 240.0) + 0.25 * (e1.eot_min - e0.eot_min);
+    double sl0, cl0;
+    sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &sl0, &cl0);
+    const double x0 = (double)s.x, y0 = (double)s.y;
+    const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
+    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, b0, e0.sin_decl, e0.cos_decl);
+    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, 0.5 * (b0 + b2),
+                                            0.5 * (e0.sin_decl + e1.sin_decl), 0.5 * (e0.cos_decl + e1.cos_decl));
+    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, b2, e1.sin_decl, e1.cos_decl);
+    const double m = 0.5 * (double)substeps;
+    oms_c0 = (float)f0;
+    oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
+    oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+  }
+  const float q_earth = earth_heat_per_area(c.ir, flags);
+
+  // ---- fp64 carried chain
+  double t_amb = (double)s.t_amb, t_int = (double)s.t_int, n_air = (double)s.n_air, vol = (double)s.vol,
+         sp = (double)s.sp;
+  float x = s.x, y = s.y, batt = s.batt;
+  float acs_w = s.acs_power, mdot = s.mdot, charge = s.charge, load = s.load;
+  int status = kOk;
+
+  int k = 0;
+#pragma unroll 1
+  for (; k < substeps; ++k) {
+    const float pf = (float)p, t_ambf = (float)t_amb, t_intf = (float)t_int, volf = (float)vol, spf = (float)sp;
+    // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
+    const float fk = (float)k;
+    const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
+    const float flux = f_fma(fk, dfl, fl0);
+
+    // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445)
+    const float rho = pf * kAirMolarOverR * f_rcp(t_ambf);
+    const float v23 = f_exp2((2.0f / 3.0f) * f_log2(volf));
+    const float drag = kEnvelopeCod * v23;
+    // rho V - m = (p V M/R - m T) / T : the cancelling numerator in fp64
+    const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
+    const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
+    const float diff = (float)num * f_rcp(t_ambf);
+    const float dir = num >= 0.0 ? 1.0f : -1.0f;
+    const float dh_dt = dir * f_sqrt(fabsf(2.0f * diff * kGravity * f_rcp(rho * drag)));
+    const float dh = atm_delta_height(layer, pf, dir, (float)t_at_p);
+    const double p_new = p + (double)(dir * f_rcp(dh) * dh_dt * kStride);
+
+    // ---- step 3: temperatures (balloon.py:451-467)
+    const float att = solar_attenuation(sun.sin_el, pf, flags);
+    const float dtdt = thermal_dtdt(v23, t_intf, t_ambf, rho, flux * att, q_earth, flags);
+    const double t_int_new = t_int + (double)(dtdt * kStride);
+
+    // ---- step 4: superpressure and volume (balloon.py:470-482)
+    double vol_new, sp_new;
+    superpressure_volume_f64(n_air, t_int, p, &vol_new, &sp_new);
+    if (sp_new > 2380.0) status = kBurst;
+    if (sp_new <= 0.0) status = kZeroPressure;
+
+    // ---- step 5: ACS (balloon.py:487-519)
+    acs_w = 0.0f; mdot = 0.0f;
+    if (eff == kUp) {
+      const float valve_area = (float)(kPiD * 0.04 * 0.04 / 4.0);
+      const float gas_density = (spf + pf) * kAirMolarOverR * f_rcp(t_intf);
+      mdot = -0.62f * valve_area * f_sqrt(2.0f * spf * gas_density);
+    } else if (eff == kDown) {
+      const float prm1 = f_max(spf, 0.0f) * f_rcp(pf);      // pressure_ratio - 1 (balloon.py:247-250)
+      acs_w = acs_power(prm1);
+      mdot = acs_efficiency(prm1, acs_w) * acs_w * (1.0f / 3600.0f);
+    }
+    double n_air_new = n_air + (double)(mdot * (float)(kStride / kAirMolarMassD));
+    n_air_new = n_air_new > 0.0 ? n_air_new : 0.0;
+
+    // ---- step 6: power (balloon.py:524-542)
+    const bool is_day = sun.sin_el > kSinMinSolarEl;
+    charge = is_day ? solar_power(sun.sin_el, sun.cos_el, att) : 0.0f;
+    load = (is_day ? kDayLoad : kNightLoad) + acs_w;
+    batt = f_clamp(f_fma(charge - load, kStride / 3600.0f, batt), 0.0f, kBatteryCapacity);
+    if (batt <= 0.0f) status = kOutOfPower;
+
+    // ---- commit (balloon.py:322-325): every RHS above used the old state
+    x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
+    y = f_fma(v, kStride, y);
+    t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
+    // T(p_new) for the next substep: stay in the layer -> incremental, else re-select
+    if (p_new <= layer_d.p_base && p_new > layer_d.p_top) {
+      t_at_p = atm_temperature_advance(t_at_p, p, p_new, layer_d.lapse);
+    } else {
+      layer_d = atm_select_f64((double)c.alpha, p_new);
+      if (!(p_new > layer_d.p_top) || !(p_new <= 108870.8213)) *flags |= kFlagPressureRange;
+      double h_unused;
+      atm_at_pressure_f64(layer_d, p_new, &h_unused, &t_at_p);
+      layer = atm_layer_f32(layer_d, c.alpha);
+    }
+    p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
+    if (status != kOk) { ++k; break; }     // balloon.py:327-328
+  }
+
+  s.x = x; s.y = y; s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
+  s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;
+  s.acs_power = acs_w; s.mdot = mdot; s.charge = charge; s.load = load;
+  s.t_elapsed += 10 * k;
+  s.status = (uint8_t)status;
+
+  // ---- reward (env/balloon_env.py:44-102), on the post-step state
+  float r = reward_distance(s.x, s.y);
+  if (action == kDown) {   // last_command is the RAW action (balloon.py:286)
+    const float fk = (float)k;
+    const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
+    const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p, flags));
+    const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
+    if (!excess) {
+      const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
+      r *= f_fma(-0.3f, scale, 0.95f);
+    }
+  }
+  *reward = r;
+  return eff;
+}
+
+}  // namespace ble

@@ -1,0 +1,38 @@
+"""Thin torch plumbing: device tensors, current stream, pointers.  torch is used for
+device memory, streams and torch.distributed only -- all arithmetic is in libble_hip.so."""
+import torch
+
+from balloon_learning_environment_amd import _abi
+
+_TORCH_DTYPES = {'float32': torch.float32, 'int64': torch.int64, 'int32': torch.int32, 'uint8': torch.uint8}
+
+
+def torch_dtype(np_dtype):
+  import numpy as np
+  return _TORCH_DTYPES[np.dtype(np_dtype).name]
+
+
+def require_gpu(device) -> torch.device:
+  device = torch.device(device)
+  if device.type != 'cuda' or not torch.cuda.is_available():
+    raise RuntimeError('balloon_learning_environment_amd needs a HIP device (torch device "cuda[:i]"); '
+                       'there is no CPU path')
+  return device
+
+
+def stream_ptr(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+  return 0 if t is None else t.data_ptr()
+
+
+def state_struct(tensors):
+  """BleStateF32 from {field: torch tensor} (contiguous, right dtype, same device)."""
+  ptrs = {}
+  for name in _abi.FIELD_NAMES:
+    t = tensors[name]
+    assert t.is_contiguous() and t.dtype == torch_dtype(_abi.FIELD_DTYPES[name]), name
+    ptrs[name] = t.data_ptr()
+  return _abi.state_struct(ptrs)

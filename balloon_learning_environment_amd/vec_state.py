@@ -1,0 +1,123 @@
+"""Batched simulator state held as device tensors + the stepping call into libble_hip.so.
+
+`VecSimulator` is the device-side counterpart of N reference `Balloon` objects
+(env/balloon/balloon.py:253-328) with their `Atmosphere` alphas and one shared (or
+per-env) wind grid.  It owns tensors only; all arithmetic happens in the HIP library.
+"""
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from balloon_learning_environment_amd import _abi
+from balloon_learning_environment_amd import _lib
+from balloon_learning_environment_amd import device as dev
+
+GRID_SHAPE = (21, 21, 10, 9, 2)  # generative/vae.py:30-38 FieldShape.grid_shape()
+SUBSTEPS = 18                    # constants.AGENT_TIME_STEP (180 s) / 10 s stride
+
+
+class ReferenceError_(Exception):
+  """Base for conditions on which the reference raises inside the transition."""
+
+
+def raise_for_flags(flags: int) -> None:
+  """Turns BLE_FLAG_* bits back into the exceptions the reference raises."""
+  if flags & _lib.FLAG_PRESSURE_RANGE:
+    raise AssertionError('Atmosphere.at_pressure: pressure out of range '
+                         '(standard_atmosphere.py:126-127)')
+  if flags & _lib.FLAG_ABSORPTIVITY:
+    raise ValueError('total_absorptivity: Computed total absorptivity factor out of expected range [0, 1].')
+  if flags & _lib.FLAG_SOLAR_RANGE:
+    raise ValueError('solar_atmospheric_attenuation: Pressure altitude out of expected range [0, 101325] Pa.')
+  if flags & _lib.FLAG_POWER_TABLE:
+    raise AssertionError('power_table.lookup: pressure_ratio out of [0.99, 5]')
+  if flags & _lib.FLAG_NONFINITE:
+    raise FloatingPointError('non-finite balloon state')
+
+
+class VecSimulator:
+  """N balloons on one GPU.  State tensors are exposed as attributes of `.state`."""
+
+  def __init__(self, n: int, device='cuda:0'):
+    self.device = dev.require_gpu(device)
+    self.lib = _lib.lib()
+    self.n = int(n)
+    with torch.cuda.device(self.device):
+      self.state: Dict[str, torch.Tensor] = {
+          name: torch.zeros(self.n, dtype=dev.torch_dtype(_abi.FIELD_DTYPES[name]), device=self.device)
+          for name in _abi.FIELD_NAMES}
+      self.reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+      self.terminal = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+      self.effective_action = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+      self.err_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+      self.active_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+    self.grid: Optional[torch.Tensor] = None
+    self.grid_env_stride = 0
+    self._struct = dev.state_struct(self.state)
+
+  # ------------------------------------------------------------------ data in / out
+  def set_state(self, arrays: Dict[str, np.ndarray]) -> None:
+    """Copies host arrays (any float/int dtype) into the device state."""
+    for name in _abi.FIELD_NAMES:
+      if name in arrays:
+        a = np.ascontiguousarray(np.asarray(arrays[name]).astype(_abi.FIELD_DTYPES[name]))
+        assert a.shape == (self.n,), (name, a.shape)
+        self.state[name].copy_(torch.from_numpy(a))
+
+  def get_state(self) -> Dict[str, np.ndarray]:
+    return {name: t.cpu().numpy() for name, t in self.state.items()}
+
+  def set_grid(self, grid, per_env: bool = False) -> None:
+    """`grid`: (21,21,10,9,2) float32 shared by all envs, or (n,21,21,10,9,2) per env."""
+    g = grid if isinstance(grid, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(grid, np.float32))
+    g = g.to(device=self.device, dtype=torch.float32).contiguous()
+    if per_env:
+      assert tuple(g.shape) == (self.n,) + GRID_SHAPE, g.shape
+      self.grid_env_stride = int(np.prod(GRID_SHAPE))
+    else:
+      assert tuple(g.shape) == GRID_SHAPE, g.shape
+      self.grid_env_stride = 0
+    self.grid = g
+
+  # ------------------------------------------------------------------ stepping
+  def step(self, action: torch.Tensor, noise_uv: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):
+    """One agent step for all envs (asynchronous on the current stream).
+
+    Returns (reward, terminal) device tensors (views of internal buffers).
+    """
+    assert self.grid is not None, 'Must call set_grid (reset) before step.'   # grid_based_wind_field.py:86-87
+    assert action.dtype == torch.uint8 and action.is_contiguous() and action.numel() == self.n
+    assert action.device == self.device
+    if noise_uv is not None:
+      assert noise_uv.dtype == torch.float32 and noise_uv.is_contiguous() and tuple(noise_uv.shape) == (self.n, 2)
+    code = self.lib.ble_step_f32(ctypes.byref(self._struct), action.data_ptr(), self.grid.data_ptr(),
+                                 self.grid_env_stride, dev.ptr(noise_uv), self.reward.data_ptr(),
+                                 self.terminal.data_ptr(), self.effective_action.data_ptr(),
+                                 self.err_flags.data_ptr(), self.active_count.data_ptr(), self.n, substeps,
+                                 dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_step_f32')
+    return self.reward, self.terminal
+
+  def step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
+             active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS) -> None:
+    """`actions` [K, n] uint8 -> K agent steps enqueued by one library call."""
+    k = actions.shape[0]
+    assert actions.dtype == torch.uint8 and actions.is_contiguous() and tuple(actions.shape) == (k, self.n)
+    assert rewards.dtype == torch.float32 and tuple(rewards.shape) == (k, self.n) and rewards.is_contiguous()
+    assert terminals.dtype == torch.uint8 and tuple(terminals.shape) == (k, self.n) and terminals.is_contiguous()
+    if active_counts is not None:
+      assert active_counts.dtype == torch.int64 and active_counts.numel() == k
+    code = self.lib.ble_step_n_f32(ctypes.byref(self._struct), actions.data_ptr(), self.grid.data_ptr(),
+                                   self.grid_env_stride, rewards.data_ptr(), terminals.data_ptr(),
+                                   self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k,
+                                   dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_step_n_f32')
+
+  def check_errors(self) -> None:
+    """Synchronises and raises what the reference would have raised (see raise_for_flags)."""
+    flags = int(self.err_flags.item())
+    if flags:
+      self.err_flags.zero_()
+      raise_for_flags(flags)

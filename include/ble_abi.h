@@ -1,0 +1,199 @@
+/*
+ * ble_abi.h -- C ABI of libble_hip.so, the MI355X (gfx950) vectorised Balloon Learning
+ * Environment transition.
+ *
+ * The reference (google/balloon-learning-environment, pure Python) has no FFI for this
+ * path; the seams it does have are Python classes.  Each entry point below replaces the
+ * arithmetic behind one of those seams, for N environments at once, and is what a
+ * ctypes binding inside the reference would call (INTEGRATION.md shows the stub).
+ * Paths are relative to /root/reference/balloon_learning_environment/.
+ *
+ * Conventions
+ *  - All array pointers are DEVICE pointers (HIP), caller-owned, struct-of-arrays,
+ *    length n unless stated.  No torch types, no C++ types.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream).  The caller keeps the buffers alive until the stream has passed
+ *    the call, and synchronises before reading results on the host.
+ *  - Return value: BLE_OK (0) or a negative BLE_E_* code for host-side argument / launch
+ *    errors.  The library never throws, aborts or asserts on the device.  Conditions on
+ *    which the reference raises *inside* the arithmetic (range checks) are OR-ed into
+ *    the device word `err_flags` (BLE_FLAG_*), which the host mirror turns back into the
+ *    reference's exceptions.
+ *  - Re-entrant: no global mutable state; different streams may run concurrently on
+ *    disjoint buffers.
+ *  - Units and encodings follow the reference: metres, Pa, K, mol, Wh, W, kg/s, seconds;
+ *    actions 0=DOWN 1=STAY 2=UP (env/balloon/control.py:21-25); status 0=OK
+ *    1=OUT_OF_POWER 2=BURST 3=ZEROPRESSURE (env/balloon/balloon.py:66-70).
+ */
+#ifndef BLE_ABI_H_
+#define BLE_ABI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLE_ABI_VERSION 1
+
+/* return codes */
+#define BLE_OK 0
+#define BLE_E_INVALID_ARG (-1) /* NULL required pointer, n < 0, substeps < 1 ... */
+#define BLE_E_LAUNCH (-2)      /* hipLaunchKernel / hipGetLastError failed */
+#define BLE_E_NO_DEVICE (-3)   /* no HIP device visible */
+
+/* bits OR-ed into *err_flags by the kernels (where the reference raises) */
+#define BLE_FLAG_PRESSURE_RANGE 1u /* standard_atmosphere.py:126-127 assert */
+#define BLE_FLAG_ABSORPTIVITY 2u   /* thermal.py:142-145 ValueError */
+#define BLE_FLAG_SOLAR_RANGE 4u    /* solar.py:190-197 ValueError */
+#define BLE_FLAG_POWER_TABLE 16u   /* power_table.py:24 assert */
+#define BLE_FLAG_NONFINITE 32u     /* a state value became NaN/Inf (no reference analogue) */
+
+/* wind grid geometry: generative/vae.py:30-38,77-93 (FieldShape defaults) */
+#define BLE_GRID_NX 21 /* x (lat axis of the grid), -500..500 km step 50 */
+#define BLE_GRID_NY 21 /* y, -500..500 km step 50 */
+#define BLE_GRID_NP 10 /* pressure, 5000..14000 Pa step 1000 */
+#define BLE_GRID_NT 9  /* time, 0..48 h step 6 */
+#define BLE_GRID_FLOATS (BLE_GRID_NX * BLE_GRID_NY * BLE_GRID_NP * BLE_GRID_NT * 2) /* 79380 */
+
+/*
+ * Per-environment simulator state, struct of device arrays.
+ * Replaces: BalloonState (env/balloon/balloon.py:73-250), the three safety-layer
+ * objects it owns (altitude_safety.py:63-111, envelope_safety.py:93-157,
+ * power_safety.py:26-126) and Atmosphere's per-episode alpha
+ * (standard_atmosphere.py:76-87).  Flight-vehicle constants (balloon.py:156-173) are
+ * compile-time constants of the kernel.
+ */
+typedef struct ble_state_f32 {
+  /* mutable, read+written by ble_step_f32 (balloon.py:175-195) */
+  float* x;                    /* [m]  units.Distance x, W->E offset from the station */
+  float* y;                    /* [m] */
+  float* pressure;             /* [Pa] */
+  float* ambient_temperature;  /* [K] */
+  float* internal_temperature; /* [K] */
+  float* envelope_volume;      /* [m^3] */
+  float* superpressure;        /* [Pa] */
+  float* mols_air;             /* [mol] */
+  float* battery_charge;       /* [Wh] */
+  /* derived, written by ble_step_f32 (balloon.py:189-193) */
+  float* acs_power;      /* [W] */
+  float* acs_mass_flow;  /* [kg/s] */
+  float* solar_charging; /* [W] */
+  float* power_load;     /* [W] */
+  /* per-episode constants, read only */
+  const float* center_lat_deg;     /* BalloonState.center_latlng */
+  const float* center_lng_deg;
+  const float* upwelling_infrared; /* [W/m^2] balloon.py:208 */
+  const float* alpha;              /* Atmosphere lapse-rate mix, standard_atmosphere.py:82-84 */
+  const int64_t* start_unix;       /* date_time when time_elapsed == 0, UTC seconds */
+  /* clocks: date_time = start_unix + time_elapsed_s (balloon.py:546-547) */
+  int32_t* time_elapsed_s;
+  /* PowerSafetyLayer._sunrise_with_hysteresis / ._sunset, seconds relative to start_unix */
+  int32_t* sunrise_h_rel;
+  int32_t* sunset_rel;
+  /* discrete state */
+  uint8_t* status;       /* BalloonStatus */
+  uint8_t* last_command; /* raw action of the last step, balloon.py:286 */
+  uint8_t* alt_fsm;      /* 0 NOMINAL 1 LOW 2 VERY_LOW         (altitude_safety.py:40-44) */
+  uint8_t* env_fsm;      /* 0 NOMINAL 1 LOW_CRITICAL 2 LOW 3 HIGH 4 HIGH_CRITICAL (envelope_safety.py:45-50) */
+  uint8_t* power_paused; /* PowerSafetyLayer.navigation_is_paused */
+} ble_state_f32;
+
+int ble_abi_version(void);
+
+/* Number of visible HIP devices (>= 0) or BLE_E_NO_DEVICE. */
+int ble_device_count(void);
+
+/*
+ * One agent step (180 s = `substeps` x 10 s) for n environments.
+ * Replaces BalloonArena.step (env/balloon_arena.py:184-202) up to, not including, the
+ * feature constructor:
+ *     wind = WindField.get_ground_truth(x, y, pressure, time_elapsed)   wind_field.py:125-145
+ *          = GridBasedWindField.get_forecast(...) + noise               grid_based_wind_field.py:70-94
+ *     Balloon.simulate_step(wind, atmosphere, action, 3 min, 10 s)     balloon.py:263-328
+ * and BalloonEnv.step's reward / terminal (env/balloon_env.py:172-186,
+ * perciatelli_reward_function :44-102).
+ *
+ *   st            state, mutated in place
+ *   action        n bytes, 0/1/2
+ *   wind_grid     BLE_GRID_FLOATS floats, row-major (x, y, pressure, time, uv) = the
+ *                 reference's `field` ndarray (21,21,10,9,2)
+ *   grid_env_stride  0: one grid shared by all envs; otherwise env i reads
+ *                 wind_grid + i * grid_env_stride (floats) -- per-env forecasts
+ *   noise_uv      optional n x 2 additive wind noise [m/s] (the SimplexWindNoise term,
+ *                 simplex_wind_noise.py; NULL = 0)
+ *   reward        n floats out;  terminal  n bytes out (status != OK after the step)
+ *   effective_action  optional n bytes out: the action after the three safety layers
+ *   err_flags     optional device uint32, BLE_FLAG_* OR-ed in
+ *   active_count  optional device uint64, incremented by the number of envs that were
+ *                 actually stepped (status == OK on entry)
+ * Envs whose status != OK on entry are skipped: state untouched, reward 0, terminal 1
+ * (the reference raises AssertionError, balloon.py:288-290; the host mirror does too).
+ */
+int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid,
+                 int64_t grid_env_stride, const float* noise_uv, float* reward, uint8_t* terminal,
+                 uint8_t* effective_action, uint32_t* err_flags, unsigned long long* active_count,
+                 int64_t n, int substeps, void* stream);
+
+/*
+ * `n_steps` consecutive agent steps enqueued by one host call (no host round trip
+ * between them).  action / reward / terminal are [n_steps][n] row-major;
+ * active_count, if given, is [n_steps].  Same semantics per step as ble_step_f32.
+ */
+int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid,
+                   int64_t grid_env_stride, float* reward, uint8_t* terminal, uint32_t* err_flags,
+                   unsigned long long* active_count, int64_t n, int substeps, int n_steps,
+                   void* stream);
+
+/*
+ * GridBasedWindField.get_forecast (grid_based_wind_field.py:70-94,145-187) for n query
+ * points: clamp, time boomerang, float32 query packing, 16-corner interpolation.
+ */
+int ble_forecast_f32(const float* wind_grid, int64_t grid_env_stride, const float* x_m,
+                     const float* y_m, const float* pressure, const int32_t* elapsed_s, float* u,
+                     float* v, int64_t n, void* stream);
+
+/*
+ * GridBasedWindField.get_forecast_column (grid_based_wind_field.py:96-132): for each of
+ * n (x, y, elapsed) columns, the forecast at `n_levels` shared pressure levels.
+ * out_uv is [n][n_levels][2].
+ */
+int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, const float* x_m,
+                            const float* y_m, const int32_t* elapsed_s, const float* levels_pa,
+                            int n_levels, float* out_uv, int64_t n, void* stream);
+
+/* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
+int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,
+                        uint32_t* err_flags, int64_t n, void* stream);
+
+/*
+ * Function-level probes: run exactly the device functions ble_step_f32 uses, one lane
+ * per element, so that each reference function can be parity-tested on its own.
+ */
+/* Atmosphere.at_pressure (standard_atmosphere.py:122-154): height [m], temperature [K] */
+int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* height,
+                             float* temperature, uint32_t* err_flags, int64_t n, void* stream);
+/* solar_calculator at BalloonState.latlng (solar.py:43-174, spherical_geometry.py:44-76):
+ * sin/cos of the refraction-corrected elevation, elevation [deg] and flux [W/m^2] */
+int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg, const float* x_m,
+                        const float* y_m, const int64_t* unix_s, float* el_deg, float* flux,
+                        int64_t n, void* stream);
+/* solar_atmospheric_attenuation + solar_power (solar.py:177-209,515-536) from el [deg] */
+int ble_probe_solar_power_f32(const float* el_deg, const float* pressure, float* attenuation,
+                              float* power_w, int64_t n, void* stream);
+/* thermal.d_balloon_temperature_dt (thermal.py:175-230) */
+int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* t_amb,
+                          const float* pressure, const float* el_deg, const float* flux,
+                          const float* upwelling_ir, float* dtdt, uint32_t* err_flags, int64_t n,
+                          void* stream);
+/* calculate_superpressure_and_volume (balloon.py:552-609) */
+int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const float* pressure,
+                            float* volume, float* superpressure, int64_t n, void* stream);
+/* acs.get_most_efficient_power / get_fan_efficiency / get_mass_flow (acs.py:44-68) */
+int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency,
+                      float* mass_flow, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLE_ABI_H_ */

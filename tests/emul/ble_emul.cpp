@@ -1,0 +1,71 @@
+// Host build of the kernel's per-lane functions (ble_physics.h / ble_step_core.h) for
+// numerics triage on machines without a GPU.  TEST TOOLING: never loaded by the package;
+// the product path is the HIP library only.  libm stands in for the v_exp/v_log/v_rcp/
+// v_sqrt hardware approximations, so this shows the algorithmic fp32 error, not the
+// last-ulp behaviour of the device.
+#include "../../balloon_learning_environment_amd/csrc/ble_step_core.h"
+#include "../../include/ble_abi.h"
+
+using namespace ble;
+
+extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid,
+                             const float* wind_uv, float* reward, uint8_t* terminal, uint8_t* effective_action,
+                             uint32_t* err_flags, int64_t n, int substeps) {
+  uint32_t flags_all = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (st->status[i] != kOk) { reward[i] = 0.0f; terminal[i] = 1; if (effective_action) effective_action[i] = action[i]; continue; }
+    EnvRegs s;
+    s.x = st->x[i]; s.y = st->y[i]; s.p = st->pressure[i]; s.t_amb = st->ambient_temperature[i];
+    s.t_int = st->internal_temperature[i]; s.vol = st->envelope_volume[i]; s.sp = st->superpressure[i];
+    s.n_air = st->mols_air[i]; s.batt = st->battery_charge[i]; s.acs_power = st->acs_power[i];
+    s.mdot = st->acs_mass_flow[i]; s.charge = st->solar_charging[i]; s.load = st->power_load[i];
+    s.t_elapsed = st->time_elapsed_s[i]; s.sunrise_h = st->sunrise_h_rel[i]; s.sunset = st->sunset_rel[i];
+    s.status = st->status[i]; s.alt_fsm = st->alt_fsm[i]; s.env_fsm = st->env_fsm[i]; s.paused = st->power_paused[i];
+    EnvConst c{st->center_lat_deg[i], st->center_lng_deg[i], st->upwelling_infrared[i], st->alpha[i], st->start_unix[i]};
+    float u, v;
+    if (wind_uv) { u = wind_uv[2 * i]; v = wind_uv[2 * i + 1]; }
+    else { WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed); wind_blend(wind_grid, wq, &u, &v); }
+    uint32_t flags = 0; float r;
+    int eff = agent_step(s, c, action[i], u, v, substeps, &r, &flags);
+    flags_all |= flags;
+    st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
+    st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;
+    st->mols_air[i] = s.n_air; st->battery_charge[i] = s.batt; st->acs_power[i] = s.acs_power;
+    st->acs_mass_flow[i] = s.mdot; st->solar_charging[i] = s.charge; st->power_load[i] = s.load;
+    st->time_elapsed_s[i] = s.t_elapsed; st->sunrise_h_rel[i] = s.sunrise_h; st->sunset_rel[i] = s.sunset;
+    st->status[i] = s.status; st->alt_fsm[i] = s.alt_fsm; st->env_fsm[i] = s.env_fsm; st->power_paused[i] = s.paused;
+    st->last_command[i] = action[i];
+    reward[i] = r; terminal[i] = s.status != kOk;
+    if (effective_action) effective_action[i] = (uint8_t)eff;
+  }
+  if (err_flags) *err_flags |= flags_all;
+  return 0;
+}
+
+extern "C" void emul_solar(int64_t n, const float* lat0, const float* lng0, const float* x, const float* y,
+                           const int64_t* t, float* el_deg, float* flux) {
+  for (int64_t i = 0; i < n; ++i) {
+    Ephemeris e = ephemeris(t[i]);
+    int64_t sod = t[i] % 86400; if (sod < 0) sod += 86400;
+    double b = (double)sod / 240.0 + 0.25 * e.eot_min + (double)lng0[i];
+    double sl, cl; sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
+    double oms = sun_one_minus_sin_f64(sl, cl, x[i], y[i], b, e.sin_decl, e.cos_decl);
+    SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
+    el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
+    flux[i] = (float)e.flux;
+  }
+}
+
+extern "C" void emul_solar_power(int64_t n, const float* el_deg, const float* p, float* att, float* power) {
+  for (int64_t i = 0; i < n; ++i) {
+    double s, c; sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
+    uint32_t fl = 0;
+    att[i] = solar_attenuation((float)s, p[i], &fl);
+    power[i] = solar_power((float)s, (float)c, att[i]);
+  }
+}
+
+extern "C" void emul_ephemeris(int64_t t, double* out4) {
+  Ephemeris e = ephemeris(t);
+  out4[0] = e.eot_min; out4[1] = e.sin_decl; out4[2] = e.cos_decl; out4[3] = e.flux;
+}
