@@ -8,6 +8,7 @@
 // 8 x (4 contiguous floats).  Nothing here is a dense contraction: no MFMA.
 // Target: gfx950 only (hipcc --offload-arch=gfx950); no other backend, no shims.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/ble_abi.h"
 #include "ble_step_core.h"
@@ -35,9 +36,14 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
                                                           uint8_t* __restrict__ terminal,
                                                           uint8_t* __restrict__ effective_action,
                                                           uint32_t* err_flags, unsigned long long* active_count,
-                                                          int64_t n, int substeps) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool in_range = i < n;
+                                                          int64_t n, int substeps, int lanes) {
+  // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
+  // idle and doubles the number of waves: an occupancy/latency experiment knob.
+  __shared__ float acs_table[4 * 13];
+  if (threadIdx.x < 4 * 13) acs_table[threadIdx.x] = kAcsEfficiency[threadIdx.x];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
+  const bool in_range = i < n && (int)threadIdx.x < lanes;
   bool live = false;
   uint32_t flags = 0;
   if (in_range) {
@@ -48,10 +54,6 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       terminal[i] = 1;
       if (effective_action) effective_action[i] = action[i];
     }
-  }
-  if (active_count) {
-    const unsigned long long m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(active_count, (unsigned long long)__popcll(m));
   }
   if (live) {
     EnvRegs s;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     }
 
     float r;
-    const int eff = agent_step(s, c, act, u, v, substeps, &r, &flags);
+    const int eff = agent_step(s, c, act, u, v, substeps, acs_table, &r, &flags);
 
     if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
       flags |= kFlagNonFinite;
@@ -91,6 +93,13 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     reward[i] = r;
     terminal[i] = s.status != kOk;
     if (effective_action) effective_action[i] = (uint8_t)eff;
+  }
+  // live-environment count: one atomic per wave, spread over BLE_COUNT_SLOTS addresses and
+  // issued last so that no load of this wave queues behind it
+  if (active_count) {
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && m)
+      atomicAdd(active_count + (blockIdx.x & (BLE_COUNT_SLOTS - 1)), (unsigned long long)__popcll(m));
   }
   report_flags(flags, err_flags);
 }
@@ -165,10 +174,9 @@ __global__ __launch_bounds__(256) void probe_atmosphere_kernel(const float* alph
   uint32_t flags = 0;
   if (i < n) {
     const double p = (double)pressure[i];
-    const AtmLayerD l = atm_select_f64((double)alpha[i], p);
-    if (!(p > l.p_top) || !(p <= 108870.8213)) flags |= kFlagPressureRange;
+    const AtmWindow w = atm_window((double)alpha[i], p, &flags);
     double h, t;
-    atm_at_pressure_f64(l, p, &h, &t);
+    atm_at_pressure_f64(w, (double)alpha[i], p, &h, &t);
     height[i] = (float)h; temperature[i] = (float)t;
   }
   report_flags(flags, err_flags);
@@ -184,10 +192,10 @@ __global__ __launch_bounds__(256) void probe_solar_kernel(const float* lat0, con
   const double b = (double)sod * (1.0 / 240.0) + 0.25 * e.eot_min + (double)lng0[i];
   double sl, cl;
   sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
-  const double oms = sun_one_minus_sin_f64(sl, cl, (double)x[i], (double)y[i], b, e.sin_decl, e.cos_decl);
+  const double oms = sun_one_minus_sin_f64(sl, cl, (double)x[i], (double)y[i], b, (double)e.sin_decl, (double)e.cos_decl);
   const SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
   el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
-  flux[i] = (float)e.flux;
+  flux[i] = e.flux;
 }
 __global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_deg, const float* pressure, float* att,
                                                                 float* power, int64_t n) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void probe_sp_volume_kernel(const float* mols_
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double v, s;
-  superpressure_volume_f64((double)mols_air[i], (double)t_int[i], (double)pressure[i], &v, &s);
+  superpressure_volume_f64((double)mols_air[i], (double)t_int[i], (double)pressure[i], d_rcp((double)pressure[i]), &v, &s);
   volume[i] = (float)v; sp[i] = (float)s;
 }
 __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* power, float* eff, float* mdot,
@@ -231,10 +239,17 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   if (i >= n) return;
   const float prm1 = pr[i] - 1.0f;
   const float w = acs_power(prm1);
-  const float e = acs_efficiency(prm1, w);
+  const float e = acs_efficiency(kAcsEfficiency, prm1, w);
   power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
 }
 
+inline int env_lanes() {
+  static const int lanes = [] {
+    const char* e = getenv("BLE_LANES_PER_WAVE");
+    return (e && atoi(e) == 32) ? 32 : 64;
+  }();
+  return lanes;
+}
 inline int launch_status() { return hipGetLastError() == hipSuccess ? BLE_OK : BLE_E_LAUNCH; }
 inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 inline bool state_ok(const ble_state_f32* st) {
@@ -264,9 +279,10 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+  const int lanes = env_lanes();
+  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
-                     active_count, n, substeps);
+                     active_count, n, substeps, lanes);
   return launch_status();
 }
 
@@ -277,11 +293,12 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
+  const int lanes = env_lanes();
   for (int k = 0; k < n_steps; ++k) {
-    hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st,
+    hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st,
                        action + (int64_t)k * n, wind_grid, grid_env_stride, (const float*)nullptr,
                        reward + (int64_t)k * n, terminal + (int64_t)k * n, (uint8_t*)nullptr, err_flags,
-                       active_count ? active_count + k : nullptr, n, substeps);
+                       active_count ? active_count + (int64_t)k * BLE_COUNT_SLOTS : nullptr, n, substeps, lanes);
   }
   return launch_status();
 }

@@ -85,6 +85,73 @@ BLE_FN double d_fma(double a, double b, double c) { return fma(a, b, c); }
 BLE_FN double d_rint(double x) { return rint(x); }
 BLE_FN double d_sqrt(double x) { return sqrt(x); }
 #endif
+// fp64 reciprocal / reciprocal-sqrt: hardware seed (v_rcp_f64 / v_rsq_f64) + Newton steps,
+// no v_div_scale/v_div_fixup ladder (inputs here are normal, positive, far from overflow).
+#if BLE_DEVICE_BUILD
+BLE_FN double d_rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }
+BLE_FN double d_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
+BLE_FN double d_frexp_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }   // [0.5, 1)
+BLE_FN int d_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+BLE_FN double d_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
+#else
+BLE_FN double d_rcp_seed(double x) { return (double)(1.0f / (float)x); }
+BLE_FN double d_rsq_seed(double x) { return (double)(1.0f / sqrtf((float)x)); }
+BLE_FN double d_frexp_mant(double x) { int e; return frexp(x, &e); }
+BLE_FN int d_frexp_exp(double x) { int e; frexp(x, &e); return e; }
+BLE_FN double d_ldexp(double x, int e) { return ldexp(x, e); }
+#endif
+BLE_FN double d_rcp(double x) {
+  double r = d_rcp_seed(x);
+  r = d_fma(d_fma(-x, r, 1.0), r, r);
+  r = d_fma(d_fma(-x, r, 1.0), r, r);
+  return r;
+}
+BLE_FN double d_rsqrt(double x) {
+  double y = d_rsq_seed(x);
+  double h = 0.5 * x;
+  y = y * d_fma(-h * y, y, 1.5);
+  y = y * d_fma(-h * y, y, 1.5);
+  return y;
+}
+BLE_FN double d_sqrt_fast(double x) {   // x > 0
+  double y = d_rsqrt(x);
+  double sq = x * y;
+  return d_fma(0.5 * y, d_fma(-sq, sq, x), sq);
+}
+// ln(x), x > 0 normal: x = m 2^e, m in [sqrt(.5), sqrt(2)); ln m = 2 atanh((m-1)/(m+1)).
+BLE_FN double d_log_fast(double x) {
+  double m = d_frexp_mant(x);
+  int e = d_frexp_exp(x);
+  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+  double sq = (m - 1.0) * d_rcp(m + 1.0);
+  double z = sq * sq;
+  double pl = 1.0 / 23.0;
+  pl = d_fma(pl, z, 1.0 / 21.0); pl = d_fma(pl, z, 1.0 / 19.0); pl = d_fma(pl, z, 1.0 / 17.0);
+  pl = d_fma(pl, z, 1.0 / 15.0); pl = d_fma(pl, z, 1.0 / 13.0); pl = d_fma(pl, z, 1.0 / 11.0);
+  pl = d_fma(pl, z, 1.0 / 9.0); pl = d_fma(pl, z, 1.0 / 7.0); pl = d_fma(pl, z, 0.2);
+  pl = d_fma(pl, z, 1.0 / 3.0);
+  double lm = d_fma(2.0 * sq * z, pl, 2.0 * sq);
+  double de = (double)e;
+  return d_fma(de, 6.93147180369123816490e-01, d_fma(de, 1.90821492927058770002e-10, lm));
+}
+// exp(t), |t| < 700
+BLE_FN double d_exp_fast(double t) {
+  double kq = d_rint(t * 1.44269504088896338700e+00);
+  double r = d_fma(kq, -6.93147180369123816490e-01, t);
+  r = d_fma(kq, -1.90821492927058770002e-10, r);
+  double pe = 1.0 / 6227020800.0;                                   // 1/13!
+  pe = d_fma(pe, r, 1.0 / 479001600.0); pe = d_fma(pe, r, 1.0 / 39916800.0); pe = d_fma(pe, r, 1.0 / 3628800.0);
+  pe = d_fma(pe, r, 1.0 / 362880.0); pe = d_fma(pe, r, 1.0 / 40320.0); pe = d_fma(pe, r, 1.0 / 5040.0);
+  pe = d_fma(pe, r, 1.0 / 720.0); pe = d_fma(pe, r, 1.0 / 120.0); pe = d_fma(pe, r, 1.0 / 24.0);
+  pe = d_fma(pe, r, 1.0 / 6.0); pe = d_fma(pe, r, 0.5); pe = d_fma(pe, r, 1.0); pe = d_fma(pe, r, 1.0);
+  return d_ldexp(pe, (int)kq);
+}
+#if defined(BLE_ABLATE) && (BLE_ABLATE & 4)
+BLE_FN double d_pow_fast(double x, double y) { return x * 0.9 + y * 1e-3; }
+#else
+BLE_FN double d_pow_fast(double x, double y) { return d_exp_fast(y * d_log_fast(x)); }
+#endif
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 BLE_FN float f_exp(float x) { return f_exp2(x * kLog2e); }
@@ -230,24 +297,29 @@ BLE_FN float atm_temperature(const AtmLayer& l, float p) {
 // Height above the boundary at pressure pb (temperature tb there), for q close to pb,
 // inside a layer of lapse rate L:  (tb/L) expm1(k log1p((q-pb)/pb)).
 BLE_FN float atm_height_rel_boundary(float q, float pb, float tb, float lapse) {
-  float lg = log1p_small((q - pb) * f_rcp(pb));
-  if (lapse == 0.0f) return -kROverG * tb * lg;
-  return tb * f_rcp(lapse) * expm1_small(-kROverG * lapse * lg);
+  const float lg = log1p_small((q - pb) * f_rcp(pb));
+  const bool iso = lapse == 0.0f;
+  const float inv_l = f_rcp(iso ? 1.0f : lapse);
+  return iso ? -kROverG * tb * lg : tb * inv_l * expm1_small(-kROverG * lapse * lg);
 }
 // H(p + d) - H(p) for |d| = 1 Pa (balloon.py:438-441), t_p = T(p).
 BLE_FN float atm_delta_height(const AtmLayer& l, float p, float d, float t_p) {
-  float q = p + d;
-  if (q > l.p_base) {  // p+1 is in the layer below (higher pressure)
-    return atm_height_rel_boundary(q, l.p_base, l.t_base, l.lapse_below) -
-           atm_height_rel_boundary(p, l.p_base, l.t_base, l.lapse);
+  const float q = p + d;
+  const float lg = log1p_small(d * f_rcp(p));
+  const bool iso = l.lapse == 0.0f;
+  const float inv_l = f_rcp(iso ? 1.0f : l.lapse);
+  float dh = iso ? -kROverG * t_p * lg : t_p * inv_l * expm1_small(l.k * lg);
+  // p and p+-1 on different sides of a layer transition (rare: only within 1 Pa of it):
+  // both heights are measured from the transition they straddle.
+  const bool below = q > l.p_base;          // p+1 is in the layer below (higher pressure)
+  const bool above = !(q > l.p_top);        // p-1 is in the layer above
+  if (__builtin_expect(below || above, 0)) {
+    const float pb = below ? l.p_base : l.p_top;
+    const float tb = below ? l.t_base : l.t_top;
+    const float lapse_q = below ? l.lapse_below : l.lapse_above;
+    dh = atm_height_rel_boundary(q, pb, tb, lapse_q) - atm_height_rel_boundary(p, pb, tb, l.lapse);
   }
-  if (!(q > l.p_top)) {  // p-1 is in the layer above
-    return atm_height_rel_boundary(q, l.p_top, l.t_top, l.lapse_above) -
-           atm_height_rel_boundary(p, l.p_top, l.t_top, l.lapse);
-  }
-  float lg = log1p_small(d * f_rcp(p));
-  if (l.lapse == 0.0f) return -kROverG * l.t_base * lg;
-  return t_p * f_rcp(l.lapse) * expm1_small(l.k * lg);
+  return dh;
 }
 // Absolute height (fp32), used by probes and by the guard band of the altitude layer.
 BLE_FN float atm_height_f32(const AtmLayer& l, float p, float t_p) {
@@ -255,77 +327,119 @@ BLE_FN float atm_height_f32(const AtmLayer& l, float p, float t_p) {
   return f_fma(t_p - l.t_base, f_rcp(l.lapse), l.h_base);
 }
 
-// fp64 restatement of Atmosphere.at_pressure(p).height for the altitude safety layer
-// (altitude_safety.py:73-111 compares it against three thresholds; the decision must
-// be bit-exact, so this follows standard_atmosphere.py:122-183 operation by operation).
-#if BLE_DEVICE_BUILD
-BLE_FN double d_pow(double x, double y) { return __ocml_pow_f64(x, y); }
-BLE_FN double d_exp(double x) { return __ocml_exp_f64(x); }
-BLE_FN double d_log(double x) { return __ocml_log_f64(x); }
-#else
-BLE_FN double d_pow(double x, double y) { return pow(x, y); }
-BLE_FN double d_exp(double x) { return exp(x); }
-BLE_FN double d_log(double x) { return log(x); }
-#endif
-// fp64 layer of Atmosphere (standard_atmosphere.py:122-183), operation by operation as
-// the reference: used once per agent step for the altitude-safety compare (bit-exact
-// decision) and as the accurate start of the incremental T(p) update in the substeps.
-struct AtmLayerD {
-  double p_base, p_top, t_base, lapse, h_base, h_top;
-  int index;
+// fp64 atmosphere window (standard_atmosphere.py:122-183).  Built once per agent step around
+// the layer i0 that contains the pre-step pressure: the two bounding transition pressures
+// (pb > pt), the temperatures there, and the lapse rates of layers i0-1, i0, i0+1.  A balloon
+// moves < 150 Pa per 10 s substep, so within one agent step it can only visit these three
+// layers; crossing a boundary (it happens every substep for a balloon floating at one --
+// the 17 km transition lies inside the operating band) costs no transcendental: T(p) is
+// re-anchored at the boundary and advanced by a short series.
+// The chain of transition pressures P_{i+1} = P_i (T_{i+1}/T_i)^(-g/(R L_i)) uses d_pow_fast.
+struct AtmWindow {
+  double pb, pt;      // pressures at the bottom (higher p) and top (lower p) of layer i0
+  double tb, tt;      // temperatures there
+  double hb;          // height at pb
+  double lapse_m1, lapse_0, lapse_p1;
+  double r_pb, r_pt;  // 1/pb, 1/pt
+  int i0;
 };
-BLE_FN AtmLayerD atm_select_f64(double alpha, double p) {
-  const double H[8] = {-610.0, 17000.0, 21000.0, 32000.0, 47000.0, 51000.0, 71000.0, 85000.0};
-  const double LO[7] = {-0.007, 0.006, 0.001, 0.0028, 0.0, -0.0028, -0.002};
-  const double HI[7] = {-0.0058, 0.005, 0.001, 0.0028, 0.0, -0.0028, -0.002};
-  const double g = 9.80665;
-  AtmLayerD l;
-  l.t_base = 300.0; l.p_base = 108870.8213; l.h_base = H[0]; l.h_top = H[1]; l.lapse = 0.0; l.p_top = 0.0; l.index = 0;
-#pragma unroll 1
-  for (int i = 0; i < 7; ++i) {
-    double lapse = (1 - alpha) * LO[i] + alpha * HI[i];
-    double t_top = l.t_base + lapse * (H[i + 1] - H[i]);
-    double p_top;
-    if (lapse == 0.0)
-      p_top = l.p_base * d_exp(-(g * (H[i + 1] - H[i])) / (kAirSpecificGasD * t_top));
-    else
-      p_top = l.p_base * d_pow(t_top / l.t_base, -g / (kAirSpecificGasD * lapse));
-    l.lapse = lapse; l.p_top = p_top; l.h_base = H[i]; l.h_top = H[i + 1]; l.index = i;
-    if (p > p_top || i == 6) break;
-    l.t_base = t_top; l.p_base = p_top;
+BLE_FN double atm_lapse_f64(int i, double alpha) {
+  switch (i) {
+    case 0: return (1 - alpha) * -0.007 + alpha * -0.0058;
+    case 1: return (1 - alpha) * 0.006 + alpha * 0.005;
+    case 2: return (1 - alpha) * 0.001 + alpha * 0.001;
+    case 3: return (1 - alpha) * 0.0028 + alpha * 0.0028;
+    case 4: return (1 - alpha) * 0.0 + alpha * 0.0;
+    case 5: return (1 - alpha) * -0.0028 + alpha * -0.0028;
+    default: return (1 - alpha) * -0.002 + alpha * -0.002;
   }
-  return l;
 }
-// height and temperature at p inside layer l (standard_atmosphere.py:135-150)
-BLE_FN void atm_at_pressure_f64(const AtmLayerD& l, double p, double* height, double* temperature) {
+BLE_FN double atm_height_f64c(int i) {
+  switch (i) {
+    case 0: return -610.0; case 1: return 17000.0; case 2: return 21000.0; case 3: return 32000.0;
+    case 4: return 47000.0; case 5: return 51000.0; case 6: return 71000.0; default: return 85000.0;
+  }
+}
+BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
   const double g = 9.80665;
+  AtmWindow w;
+  *flags |= !(p <= 108870.8213) ? kFlagPressureRange : 0u;
+  // Layers 0 and 1 (ground .. 17 km .. 21 km) hold every pressure a flying balloon can
+  // reach; their transition pressures are computed unconditionally (two pows, no
+  // divergence), the layers above only if a lane really is up there.
+  const double l0 = atm_lapse_f64(0, alpha), l1 = atm_lapse_f64(1, alpha), l2 = atm_lapse_f64(2, alpha);
+  const double t1 = 300.0 + l0 * (17000.0 - -610.0);
+  const double p1 = 108870.8213 * d_pow_fast(t1 * (1.0 / 300.0), -g * d_rcp(kAirSpecificGasD * l0));
+  const double t2 = t1 + l1 * (21000.0 - 17000.0);
+  const double p2 = p1 * d_pow_fast(t2 * d_rcp(t1), -g * d_rcp(kAirSpecificGasD * l1));
+  const bool in0 = p > p1;
+  w.i0 = in0 ? 0 : 1;
+  w.pb = in0 ? 108870.8213 : p1; w.pt = in0 ? p1 : p2;
+  w.tb = in0 ? 300.0 : t1;       w.tt = in0 ? t1 : t2;
+  w.hb = in0 ? -610.0 : 17000.0;
+  w.lapse_m1 = l0; w.lapse_0 = in0 ? l0 : l1; w.lapse_p1 = in0 ? l1 : l2;
+  if (__builtin_expect(!(p > p2), 0)) {
+    double t_base = t2, p_base = p2, lapse = l2, t_top = t2, p_top = p2;
+    int i = 2;
+#pragma unroll 1
+    for (;;) {
+      lapse = atm_lapse_f64(i, alpha);
+      const double dh = atm_height_f64c(i + 1) - atm_height_f64c(i);
+      t_top = t_base + lapse * dh;
+      if (lapse == 0.0)
+        p_top = p_base * d_exp_fast(-(g * dh) * d_rcp(kAirSpecificGasD * t_top));
+      else
+        p_top = p_base * d_pow_fast(t_top * d_rcp(t_base), -g * d_rcp(kAirSpecificGasD * lapse));
+      if (p > p_top || i == 6) break;
+      t_base = t_top; p_base = p_top; ++i;
+    }
+    if (!(p > p_top)) *flags |= kFlagPressureRange;
+    w.pb = p_base; w.pt = p_top; w.tb = t_base; w.tt = t_top; w.hb = atm_height_f64c(i); w.i0 = i;
+    w.lapse_0 = lapse;
+    w.lapse_m1 = atm_lapse_f64(i - 1, alpha);
+    w.lapse_p1 = atm_lapse_f64(i < 6 ? i + 1 : 6, alpha);
+  }
+  w.r_pb = d_rcp(w.pb); w.r_pt = d_rcp(w.pt);
+  return w;
+}
+// height and temperature at p inside layer i0 of the window (standard_atmosphere.py:135-150)
+BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, double* height, double* temperature) {
+  const double g = 9.80665;
+  (void)alpha;
+  const double lapse = w.lapse_0;
   double h;
-  if (l.lapse == 0.0)
-    h = ((-kAirSpecificGasD * l.t_base / g) * d_log(p / l.p_base) + l.h_base);
+  if (lapse == 0.0)
+    h = ((-kAirSpecificGasD * w.tb / g) * d_log_fast(p * d_rcp(w.pb)) + w.hb);
   else
-    h = ((d_pow(p / l.p_base, -kAirSpecificGasD * l.lapse / g) - 1) * l.t_base / l.lapse + l.h_base);
+    h = ((d_pow_fast(p * d_rcp(w.pb), -kAirSpecificGasD * lapse / g) - 1) * w.tb / lapse + w.hb);
   *height = h;
-  *temperature = l.t_base + l.lapse * (h - l.h_base);
+  *temperature = w.tb + lapse * (h - w.hb);
 }
 // T(p1) from T(p0) inside one layer: T1 = T0 (p1/p0)^k, k = -R_d L / g, |p1/p0 - 1| < 2e-2.
-// Series in fp64 (log1p to x^7, exp to y^6): relative error < 1e-14.
-BLE_FN double atm_temperature_advance(double t0, double p0, double p1, double lapse) {
-  double x = (p1 - p0) / p0;
-  double lg = x * d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, 1.0 / 7.0, -1.0 / 6.0), 0.2), -0.25),
-                                                 1.0 / 3.0), -0.5), 1.0);
+// rp0 = 1/p0.  Series in fp64 (log1p to x^6, expm1 to y^5): relative error < 2e-14.
+BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p1, double lapse) {
+  double x = (p1 - p0) * rp0;
+  double lg = x * d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, -1.0 / 6.0, 0.2), -0.25), 1.0 / 3.0), -0.5), 1.0);
   double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
-  double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, d_fma(y, 1.0 / 720.0, 1.0 / 120.0), 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
   return d_fma(t0, em1, t0);
 }
-
-// fp32 view of an fp64 layer (for the dH series and the probes)
-BLE_FN AtmLayer atm_layer_f32(const AtmLayerD& d, float alpha) {
+// which of the window's three layers holds p: -1 (below i0, higher pressure), 0, +1
+BLE_FN int atm_window_layer(const AtmWindow& w, double p) { return p > w.pb ? -1 : (p > w.pt ? 0 : 1); }
+// fp32 view of the layer `j` of the window (for the dH series)
+BLE_FN AtmLayer atm_layer_f32(const AtmWindow& w, int j) {
+  const float inf = __builtin_huge_valf();
   AtmLayer l;
-  l.p_base = (float)d.p_base; l.p_top = (float)d.p_top; l.t_base = (float)d.t_base; l.lapse = (float)d.lapse;
-  l.h_base = (float)d.h_base; l.k = -kROverG * l.lapse; l.index = d.index;
-  l.t_top = (float)(d.t_base + d.lapse * (d.h_top - d.h_base));
-  l.lapse_below = atm_lapse(d.index > 0 ? d.index - 1 : 0, alpha);
-  l.lapse_above = atm_lapse(d.index < 6 ? d.index + 1 : 6, alpha);
+  const float pb = (float)w.pb, pt = (float)w.pt, tb = (float)w.tb, tt = (float)w.tt;
+  l.p_base = j < 0 ? inf : (j == 0 ? pb : pt);
+  l.t_base = j == 0 ? tb : tt;
+  l.p_top = j < 0 ? pb : (j == 0 ? pt : -inf);
+  l.t_top = j < 0 ? tb : tt;
+  const float lm1 = (float)w.lapse_m1, l0 = (float)w.lapse_0, lp1 = (float)w.lapse_p1;
+  l.lapse = j < 0 ? lm1 : (j == 0 ? l0 : lp1);
+  l.lapse_below = j <= 0 ? lm1 : l0;
+  l.lapse_above = j < 0 ? l0 : lp1;
+  l.h_base = (float)w.hb; l.k = -kROverG * l.lapse; l.index = w.i0 + j;
   return l;
 }
 
@@ -447,11 +561,29 @@ BLE_FN void wind_blend(const float* __restrict__ grid, const WindQuery& wq, floa
 }
 
 // ---------------------------------------------------------------- solar
-// Time-only part of solar.solar_calculator (solar.py:65-134,170-172), fp64.
+// sin/cos of an angle given in DEGREES as fp64: reduced to [-45, 45] deg + quadrant in fp64
+// (so that the 36000 deg/century mean longitudes keep their precision), evaluated in fp32.
+BLE_FN void sincos_deg(double deg, float* s, float* c) {
+  double q = d_rint(deg * (1.0 / 90.0));
+  float r = (float)(d_fma(q, -90.0, deg) * (kPiD / 180.0));
+  float r2 = r * r;
+  float sp = r * f_fma(r2, f_fma(r2, f_fma(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), 1.0f);
+  float cp = f_fma(r2, f_fma(r2, f_fma(r2, f_fma(r2, 2.443315711809948e-5f, -1.388731625493765e-3f),
+                                       4.166664568298827e-2f), -0.5f), 1.0f);
+  int iq = (int)((long long)q & 3);
+  float ss = (iq & 1) ? cp : sp;
+  float cc = (iq & 1) ? sp : cp;
+  *s = (iq & 2) ? -ss : ss;
+  *c = ((iq + 1) & 2) ? -cc : cc;
+}
+
+// Time-only part of solar.solar_calculator (solar.py:65-134,170-172).  The Julian century
+// and the large mean angles are fp64; once reduced, the trigonometry is fp32 (the
+// equation of time and the declination need ~1e-7 absolute, not 1e-16).
 struct Ephemeris {
   double eot_min;    // degrees(equation_of_time): minutes of time (solar.py:107-115)
-  double sin_decl, cos_decl;
-  double flux;       // W/m^2
+  float sin_decl, cos_decl;
+  float flux;        // W/m^2
 };
 BLE_FN Ephemeris ephemeris(int64_t unix_s) {
   // solar.py:66-79.  julian_day_number + fraction_of_day == 2440587.5 + unix_s / 86400
@@ -459,40 +591,38 @@ BLE_FN Ephemeris ephemeris(int64_t unix_s) {
   int64_t days = unix_s / 86400;
   int64_t sod = unix_s - days * 86400;
   if (sod < 0) { sod += 86400; days -= 1; }
-  double julian_time = (2440587.5 + (double)days) + (double)sod / 86400.0;
-  double jc = (julian_time - 2451545.0) / 36525.0;
-  const double d2r = kPiD / 180.0;
-  double l0 = d2r * (280.46646 + jc * (36000.76983 + jc * 0.0003032));
-  double s2l, c2l;
-  sincos_f64(2.0 * l0, &s2l, &c2l);
-  double s4l = 2.0 * s2l * c2l;
-  double m0 = d2r * (357.52911 + jc * (35999.05029 - 0.0001537 * jc));
-  double sm, cm;
-  sincos_f64(m0, &sm, &cm);
-  double s2m = 2.0 * sm * cm;
-  double s3m = sm * (3.0 - 4.0 * sm * sm);
-  double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
-  double so, co;
-  sincos_f64(d2r * (125.04 - 1934.136 * jc), &so, &co);
-  double obl = mean_obl + d2r * (0.00256 * co);
-  double sobl, cobl;
-  sincos_f64(obl, &sobl, &cobl);
-  double tan_half = sobl / (1.0 + cobl);
-  double var_y = tan_half * tan_half;
-  double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
-  double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
-                      1.25 * ecc * ecc * s2m);
-  double eoc = d2r * (sm * (1.914602 - jc * (0.004817 + 0.000014 * jc)) + s2m * (0.019993 - 0.000101 * jc) +
-                      s3m * 0.000289);
-  double app = l0 + eoc - d2r * (0.00569 - 0.00478 * so);
-  double sa, ca;
-  sincos_f64(app, &sa, &ca);
+  const double julian_time = (2440587.5 + (double)days) + (double)sod * (1.0 / 86400.0);
+  const double jc = (julian_time - 2451545.0) * (1.0 / 36525.0);
+  const float jcf = (float)jc;
+  const double l0_deg = 280.46646 + jc * (36000.76983 + jc * 0.0003032);
+  const double m0_deg = 357.52911 + jc * (35999.05029 - 0.0001537 * jc);
+  const double om_deg = 125.04 - 1934.136 * jc;
+  float sl, cl, sm, cm, so, co;
+  sincos_deg(l0_deg, &sl, &cl);
+  sincos_deg(m0_deg, &sm, &cm);
+  sincos_deg(om_deg, &so, &co);
+  const float s2l = 2.0f * sl * cl, c2l = f_fma(cl, cl, -sl * sl);
+  const float s4l = 2.0f * s2l * c2l;
+  const float s2m = 2.0f * sm * cm;
+  const float s3m = sm * f_fma(-4.0f * sm, sm, 3.0f);
+  const float mean_obl = 23.0f + (26.0f + ((21.448f - jcf * (46.815f + jcf * (0.00059f - jcf * 0.001813f)))) * (1.0f / 60.0f)) * (1.0f / 60.0f);
+  float sobl, cobl;
+  sincos_deg((double)(mean_obl + 0.00256f * co), &sobl, &cobl);
+  const float tan_half = sobl * f_rcp(1.0f + cobl);
+  const float var_y = tan_half * tan_half;
+  const float ecc = 0.016708634f - jcf * (0.000042037f + 0.0000001267f * jcf);
+  const float eot = 4.0f * (var_y * s2l - 2.0f * ecc * sm + 4.0f * ecc * var_y * sm * c2l - 0.5f * var_y * var_y * s4l -
+                            1.25f * ecc * ecc * s2m);
+  const float eoc_deg = sm * (1.914602f - jcf * (0.004817f + 0.000014f * jcf)) + s2m * (0.019993f - 0.000101f * jcf) +
+                        s3m * 0.000289f;
+  float sa, ca;
+  sincos_deg(l0_deg + (double)(eoc_deg - (0.00569f - 0.00478f * so)), &sa, &ca);
   Ephemeris e;
-  e.eot_min = eot * (180.0 / kPiD);
+  e.eot_min = (double)(eot * kRadToDeg);
   e.sin_decl = sobl * sa;
-  e.cos_decl = d_sqrt(1.0 - e.sin_decl * e.sin_decl);
-  double r = (1 + ecc) / (1 - ecc);
-  e.flux = 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
+  e.cos_decl = f_sqrt(f_fma(-e.sin_decl, e.sin_decl, 1.0f));
+  const float r = (1.0f + ecc) * f_rcp(1.0f - ecc);
+  e.flux = 1366.0f * f_fma(0.5f * f_fma(r, r, -1.0f), cm, 1.0f);
   return e;
 }
 
@@ -509,20 +639,26 @@ BLE_FN Ephemeris ephemeris(int64_t unix_s) {
 struct SunSC { float sin_el, cos_el; };
 BLE_FN double sun_one_minus_sin_f64(double sin_lat0, double cos_lat0, double x, double y, double b_deg,
                                     double sin_decl, double cos_decl) {
-  double d2 = x * x + y * y;
-  double d = d_sqrt(d2);
-  double cos_h = 1.0, sin_h = 0.0;
-  if (d2 > 0.0) { cos_h = y / d; sin_h = x / d; }
-  double sin_a, cos_a;
-  sincos_f64(d * (1.0 / 6371000.0), &sin_a, &cos_a);
-  double sin_lat = cos_a * sin_lat0 + sin_a * cos_lat0 * cos_h;
-  double cos_lat = d_sqrt(1.0 - sin_lat * sin_lat);
-  double yy = sin_a * cos_lat0 * sin_h;
-  double xx = cos_a - sin_lat0 * sin_lat;
+  const double d2 = x * x + y * y;
+  const bool moved = d2 > 0.0;
+  const double inv_d = moved ? d_rsqrt(moved ? d2 : 1.0) : 0.0;
+  const double cos_h = moved ? y * inv_d : 1.0;      // heading = atan2(x, y); atan2(0, 0) = 0
+  const double sin_h = x * inv_d;
+  const double a = (d2 * inv_d) * (1.0 / 6371000.0);  // angle = |(x, y)| / R_earth  (< 0.2 rad)
+  const double a2 = a * a;
+  // Taylor to a^13 / a^12: |a| < 0.2 -> truncation < 1e-17
+  double sin_a = d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, 1.0 / 6227020800.0, -1.0 / 39916800.0),
+                                                         1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0) * a;
+  double cos_a = d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, d_fma(a2, 1.0 / 479001600.0, -1.0 / 3628800.0),
+                                                         1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+  const double sin_lat = cos_a * sin_lat0 + sin_a * cos_lat0 * cos_h;
+  const double cos_lat = d_sqrt_fast(d_fma(-sin_lat, sin_lat, 1.0));
+  const double yy = sin_a * cos_lat0 * sin_h;
+  const double xx = cos_a - sin_lat0 * sin_lat;
   double sin_b, cos_b;
   sincos_f64(b_deg * (kPiD / 180.0), &sin_b, &cos_b);
-  double cos_bl = (cos_b * xx - sin_b * yy) / d_sqrt(xx * xx + yy * yy);
-  double s = sin_lat * sin_decl - cos_lat * cos_decl * cos_bl;
+  const double cos_bl = (cos_b * xx - sin_b * yy) * d_rsqrt(xx * xx + yy * yy);
+  const double s = sin_lat * sin_decl - cos_lat * cos_decl * cos_bl;
   return 1.0 - s;
 }
 BLE_FN SunSC sun_from_one_minus_sin(float oms) {
@@ -534,26 +670,23 @@ BLE_FN SunSC sun_from_one_minus_sin(float oms) {
 }
 
 // Atmospheric refraction (solar.py:141-157) applied as a small rotation of (S, C).
+// Branch-free: the three formulas are evaluated and selected (they share 1/S).
 BLE_FN SunSC sun_refract(SunSC unc) {
   const float kSin85 = 0.99619472027f, kSin5 = 0.08715574443f, kSinM0575 = -0.01003547478f;
   const float s = unc.sin_el, c = unc.cos_el;
-  float refr;  // arcseconds
-  if (s > kSin85) {
-    refr = 0.0f;
-  } else if (s > kSin5) {
-    float ct = c * f_rcp(s), ct2 = ct * ct;
-    refr = ct * f_fma(ct2, f_fma(ct2, 0.000086f, -0.07f), 58.1f);
-  } else if (s > kSinM0575) {
-    float s2 = s * s;
-    float e = kRadToDeg * s * f_fma(s2, f_fma(s2, f_fma(s2, 15.0f / 336.0f, 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
-    refr = f_fma(e, f_fma(e, f_fma(e, f_fma(e, 0.711f, -12.79f), 103.4f), -518.2f), 1735.0f);
-  } else {
-    refr = -20.772f * c * f_rcp(s);
-  }
-  float dl = refr * (kDegToRad / 3600.0f);
-  float d2 = dl * dl;
-  float sd = dl * f_fma(d2, f_fma(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
-  float cd = f_fma(d2, f_fma(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+  const float ct = c * f_rcp(s), ct2 = ct * ct;                       // 1/tan(el); only used when |s| > 0.01
+  const float r_mid = ct * f_fma(ct2, f_fma(ct2, 0.000086f, -0.07f), 58.1f);
+  const float r_neg = -20.772f * ct;
+  const float s2 = s * s;
+  const float e = kRadToDeg * s * f_fma(s2, f_fma(s2, f_fma(s2, 15.0f / 336.0f, 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
+  const float r_low = f_fma(e, f_fma(e, f_fma(e, f_fma(e, 0.711f, -12.79f), 103.4f), -518.2f), 1735.0f);
+  float refr = s > kSinM0575 ? r_low : r_neg;                          // arcseconds
+  refr = s > kSin5 ? r_mid : refr;
+  refr = s > kSin85 ? 0.0f : refr;
+  const float dl = refr * (kDegToRad / 3600.0f);
+  const float d2 = dl * dl;
+  const float sd = dl * f_fma(d2, f_fma(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+  const float cd = f_fma(d2, f_fma(d2, 1.0f / 24.0f, -0.5f), 1.0f);
   SunSC r;
   r.sin_el = f_fma(s, cd, c * sd);
   r.cos_el = f_fma(c, cd, -s * sd);
@@ -562,15 +695,16 @@ BLE_FN SunSC sun_refract(SunSC unc) {
 
 constexpr float kSinMinSolarEl = -0.07396924496f;  // sin(-4.242 deg), solar.py:38
 
-// solar_atmospheric_attenuation (solar.py:177-209) from sin(el).
+// solar_atmospheric_attenuation (solar.py:177-209) from sin(el).  Branch-free.
 BLE_FN float solar_attenuation(float sin_el, float pressure, uint32_t* flags) {
-  if (pressure > 101325.0f || pressure < 0.0f) *flags |= kFlagSolarRange;
-  if (sin_el < kSinMinSolarEl) return 0.0f;
-  float t = 614.0f * sin_el;
-  float root = f_sqrt(f_fma(t, t, 1229.0f));
-  float diff = t > 0.0f ? 1229.0f * f_rcp(root + t) : root - t;   // sqrt(1229+t^2) - t without cancellation
-  float airmass = 0.34764f * (pressure * (1.0f / 101325.0f)) * diff;
-  return 0.5f * (f_exp(-0.65f * airmass) + f_exp(-0.95f * airmass));
+  *flags |= (pressure > 101325.0f || pressure < 0.0f) ? kFlagSolarRange : 0u;
+  const float t = 614.0f * sin_el;
+  const float root = f_sqrt(f_fma(t, t, 1229.0f));
+  // sqrt(1229 + t^2) - t, written without cancellation for t > 0
+  const float diff = t > 0.0f ? 1229.0f * f_rcp(root + t) : root - t;
+  const float airmass = 0.34764f * (pressure * (1.0f / 101325.0f)) * diff;
+  const float att = 0.5f * (f_exp(-0.65f * airmass) + f_exp(-0.95f * airmass));
+  return sin_el < kSinMinSolarEl ? 0.0f : att;
 }
 // solar_power (solar.py:515-536) with balloon_shadow (:212-236) folded in.
 BLE_FN float solar_power(float sin_el, float cos_el, float attenuation) {
@@ -592,7 +726,7 @@ constexpr float kStefanBoltzmann = 0.000000056704f;
 BLE_FN float absorptivity_ir(float t) { return f_fma(0.000232f, t - 210.0f, 0.04587f); }
 BLE_FN float total_absorptivity(float a, uint32_t* flags) {   // reflectivity 0.0291
   float f = a * f_fma(1.0f - a - 0.0291f, 1.0f / (1.0f - 0.0291f), 1.0f);
-  if (f < 0.0f || f > 1.0f) *flags |= kFlagAbsorptivity;
+  *flags |= (f < 0.0f || f > 1.0f) ? kFlagAbsorptivity : 0u;
   return f;
 }
 constexpr float kSolarAbsorptivityTotal =
@@ -640,43 +774,49 @@ BLE_FN void superpressure_volume(float mols_air, float t_int, float p, float* vo
 
 // fp64 variant for the vertical-dynamics chain (see ble_step_core.h): the buoyancy
 // difference rho V - m is an unstable map near float equilibrium, so V must be good to ~1e-9.
-BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, double* volume, double* sp) {
-  double vu = ((6830.0 + mols_air) * kGasConstantD * t_int / p);
-  if (vu <= 1804.0) { *volume = vu; *sp = 0.0; return; }
+BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, double rp, double* volume, double* sp) {
+  // rp = 1/p.  Fully inflated branch: V from the quadratic (balloon.py:596-604); the
+  // superpressure then follows from the envelope model V = V0 + dV/dp * sp, which is the
+  // same root written without the division p Vu / V (relative difference ~1e-14).
+  double vu = ((6830.0 + mols_air) * kGasConstantD * t_int) * rp;
   double b = -(1804.0 - 0.0199 * p);
-  double c = -(0.0199 * vu * p);
-  double v = 0.5 * (-b + d_sqrt(b * b - 4 * c));
-  *volume = v;
-  *sp = (p * vu / v - p);
+  double c4 = 4.0 * 0.0199 * vu * p;
+  double v = 0.5 * (d_sqrt_fast(d_fma(b, b, c4)) - b);
+  bool slack = vu <= 1804.0;
+  *volume = slack ? vu : v;
+  *sp = slack ? 0.0 : (v - 1804.0) * (1.0 / 0.0199);
 }
 
 // ---------------------------------------------------------------- ACS
 // acs.py:24-68.  prm1 = pressure_ratio - 1.
 BLE_FN float acs_power(float prm1) {
-  // interp1d([1.0,1.05,1.2,1.25,1.35] -> [100,100,300,400,400], extrapolate): flat end segments
-  if (prm1 <= 0.05f) return 100.0f;
-  if (prm1 <= 0.2f) return f_fma(prm1 - 0.05f, 200.0f / 0.15f, 100.0f);
-  if (prm1 <= 0.25f) return f_fma(prm1 - 0.2f, 100.0f / 0.05f, 300.0f);
-  return 400.0f;
+  // interp1d([1.0,1.05,1.2,1.25,1.35] -> [100,100,300,400,400], extrapolate): flat end
+  // segments; branch-free as a clamp of the two ramps
+  const float seg1 = f_fma(prm1 - 0.05f, 200.0f / 0.15f, 100.0f);    // 1.05 .. 1.2
+  const float seg2 = f_fma(prm1 - 0.2f, 100.0f / 0.05f, 300.0f);     // 1.2 .. 1.25
+  const float w = prm1 <= 0.2f ? seg1 : seg2;
+  return f_clamp(w, 100.0f, 400.0f);
 }
+// Fan-efficiency table acs.py:31-41, rows = power 100/200/300/400 W, columns = pressure
+// ratio 1.05 .. 1.35 step 0.025.  `tab` points at 4 x 13 floats (LDS copy in the kernel).
 #if BLE_DEVICE_BUILD
 __device__ __constant__
 #else
 static
 #endif
-const float kAcsEfficiency[4][13] = {
-    {0.4f, 0.4f, 0.3f, 0.2f, 0.2f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
-    {0.4f, 0.3f, 0.3f, 0.30f, 0.25f, 0.23f, 0.20f, 0.15f, 0.12f, 0.10f, 0.0f, 0.0f, 0.0f},
-    {0.0f, 0.3f, 0.25f, 0.25f, 0.25f, 0.20f, 0.20f, 0.20f, 0.2f, 0.15f, 0.13f, 0.12f, 0.11f},
-    {0.0f, 0.23f, 0.23f, 0.23f, 0.23f, 0.23f, 0.20f, 0.20f, 0.20f, 0.18f, 0.16f, 0.15f, 0.13f}};
-BLE_FN float acs_efficiency(float prm1, float power) {
+const float kAcsEfficiency[4 * 13] = {
+    0.4f, 0.4f, 0.3f, 0.2f, 0.2f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+    0.4f, 0.3f, 0.3f, 0.30f, 0.25f, 0.23f, 0.20f, 0.15f, 0.12f, 0.10f, 0.0f, 0.0f, 0.0f,
+    0.0f, 0.3f, 0.25f, 0.25f, 0.25f, 0.20f, 0.20f, 0.20f, 0.2f, 0.15f, 0.13f, 0.12f, 0.11f,
+    0.0f, 0.23f, 0.23f, 0.23f, 0.23f, 0.23f, 0.20f, 0.20f, 0.20f, 0.18f, 0.16f, 0.15f, 0.13f};
+BLE_FN float acs_efficiency(const float* tab, float prm1, float power) {
   float fx = f_clamp((prm1 - 0.05f) * 40.0f, 0.0f, 12.0f);     // 13 nodes, step 0.025
   float fy = f_clamp((power - 100.0f) * 0.01f, 0.0f, 3.0f);    // 4 nodes, step 100 W
   int ix = (int)fx; ix = ix > 11 ? 11 : ix;
   int iy = (int)fy; iy = iy > 2 ? 2 : iy;
   float wx = fx - (float)ix, wy = fy - (float)iy;
-  float z00 = kAcsEfficiency[iy][ix], z01 = kAcsEfficiency[iy][ix + 1];
-  float z10 = kAcsEfficiency[iy + 1][ix], z11 = kAcsEfficiency[iy + 1][ix + 1];
+  const float* r0 = tab + iy * 13 + ix;
+  float z00 = r0[0], z01 = r0[1], z10 = r0[13], z11 = r0[14];
   float lo = f_fma(wx, z01 - z00, z00), hi = f_fma(wx, z11 - z10, z10);
   return f_fma(wy, hi - lo, lo);
 }

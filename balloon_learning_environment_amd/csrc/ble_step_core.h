@@ -16,6 +16,13 @@
 #pragma once
 #include "ble_physics.h"
 
+// Timing-ablation switches for kernel analysis builds only (-DBLE_ABLATE=<bits>); the
+// product is always built with 0.  1: one ephemeris  2: no sun nodes  4: no atmosphere pows
+// 8: no reward sun  16: no safety layers
+#ifndef BLE_ABLATE
+#define BLE_ABLATE 0
+#endif
+
 namespace ble {
 
 struct EnvRegs {
@@ -32,26 +39,34 @@ struct EnvConst {
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
 BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float v, int substeps,
-                      float* reward, uint32_t* flags) {
+                      const float* acs_table, float* reward, uint32_t* flags) {
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   double p = (double)s.p;
-  AtmLayerD layer_d = atm_select_f64((double)c.alpha, p);
-  if (!(p > layer_d.p_top) || !(p <= 108870.8213)) *flags |= kFlagPressureRange;
+  const AtmWindow win = atm_window((double)c.alpha, p, flags);
   double altitude, t_at_p;
-  atm_at_pressure_f64(layer_d, p, &altitude, &t_at_p);
-  AtmLayer layer = atm_layer_f32(layer_d, c.alpha);
+  atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
+  int lay = 0;                                   // p is in the window's centre layer by construction
+  AtmLayer layer = atm_layer_f32(win, 0);
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
+#if BLE_ABLATE & 16
+  int eff = action; (void)altitude;
+#else
   int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
   eff = envelope_safety(eff, s.sp, &s.env_fsm);
   eff = altitude_safety(eff, altitude, &s.alt_fsm);
+#endif
 
   // ---- per-step constants
   const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
   const Ephemeris e0 = ephemeris(t0);
+#if BLE_ABLATE & 1
+  const Ephemeris e1 = e0;
+#else
   const Ephemeris e1 = ephemeris(t0 + (int64_t)(10 * substeps));
+#endif
   const double inv_n = 1.0 / (double)substeps;
-  const float fl0 = (float)e0.flux, dfl = (float)((e1.flux - e0.flux) * inv_n);
+  const float fl0 = e0.flux, dfl = (e1.flux - e0.flux) * (float)inv_n;
   // Solar geometry: 1 - sin(el_uncorrected) at substep indices 0, n/2, n in fp64, then a
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
   float oms_c0, oms_c1, oms_c2;
@@ -65,10 +80,14 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
     sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &sl0, &cl0);
     const double x0 = (double)s.x, y0 = (double)s.y;
     const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, b0, e0.sin_decl, e0.cos_decl);
-    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, 0.5 * (b0 + b2),
-                                            0.5 * (e0.sin_decl + e1.sin_decl), 0.5 * (e0.cos_decl + e1.cos_decl));
-    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, b2, e1.sin_decl, e1.cos_decl);
+    const double sd0 = (double)e0.sin_decl, cd0 = (double)e0.cos_decl, sd1 = (double)e1.sin_decl, cd1 = (double)e1.cos_decl;
+#if BLE_ABLATE & 2
+    const double f0 = 0.3 + 1e-9 * x0, f1 = 0.31 + 1e-9 * dx, f2 = 0.32 + 1e-9 * b2 + sl0 * 0 + cl0 * 0 + sd0 * 0 + cd0 * 0 + sd1 * 0 + cd1 * 0 + y0 * 0 + dy * 0;
+#else
+    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, b0, sd0, cd0);
+    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, 0.5 * (b0 + b2), 0.5 * (sd0 + sd1), 0.5 * (cd0 + cd1));
+    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, b2, sd1, cd1);
+#endif
     const double m = 0.5 * (double)substeps;
     oms_c0 = (float)f0;
     oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
@@ -87,6 +106,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
 #pragma unroll 1
   for (; k < substeps; ++k) {
     const float pf = (float)p, t_ambf = (float)t_amb, t_intf = (float)t_int, volf = (float)vol, spf = (float)sp;
+    const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
     const float fk = (float)k;
     const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
@@ -112,20 +132,20 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
-    superpressure_volume_f64(n_air, t_int, p, &vol_new, &sp_new);
+    superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new);
     if (sp_new > 2380.0) status = kBurst;
     if (sp_new <= 0.0) status = kZeroPressure;
 
-    // ---- step 5: ACS (balloon.py:487-519)
-    acs_w = 0.0f; mdot = 0.0f;
-    if (eff == kUp) {
+    // ---- step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane
+    {
       const float valve_area = (float)(kPiD * 0.04 * 0.04 / 4.0);
       const float gas_density = (spf + pf) * kAirMolarOverR * f_rcp(t_intf);
-      mdot = -0.62f * valve_area * f_sqrt(2.0f * spf * gas_density);
-    } else if (eff == kDown) {
-      const float prm1 = f_max(spf, 0.0f) * f_rcp(pf);      // pressure_ratio - 1 (balloon.py:247-250)
-      acs_w = acs_power(prm1);
-      mdot = acs_efficiency(prm1, acs_w) * acs_w * (1.0f / 3600.0f);
+      const float mdot_up = -0.62f * valve_area * f_sqrt(2.0f * spf * gas_density);
+      const float prm1 = f_max(spf, 0.0f) * (float)rp;       // pressure_ratio - 1 (balloon.py:247-250)
+      const float w_down = acs_power(prm1);
+      const float mdot_down = acs_efficiency(acs_table, prm1, w_down) * w_down * (1.0f / 3600.0f);
+      acs_w = eff == kDown ? w_down : 0.0f;
+      mdot = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0f);
     }
     double n_air_new = n_air + (double)(mdot * (float)(kStride / kAirMolarMassD));
     n_air_new = n_air_new > 0.0 ? n_air_new : 0.0;
@@ -141,15 +161,19 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
     x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
     y = f_fma(v, kStride, y);
     t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
-    // T(p_new) for the next substep: stay in the layer -> incremental, else re-select
-    if (p_new <= layer_d.p_base && p_new > layer_d.p_top) {
-      t_at_p = atm_temperature_advance(t_at_p, p, p_new, layer_d.lapse);
-    } else {
-      layer_d = atm_select_f64((double)c.alpha, p_new);
-      if (!(p_new > layer_d.p_top) || !(p_new <= 108870.8213)) *flags |= kFlagPressureRange;
-      double h_unused;
-      atm_at_pressure_f64(layer_d, p_new, &h_unused, &t_at_p);
-      layer = atm_layer_f32(layer_d, c.alpha);
+    // T(p_new) for the next substep: advance inside the layer, or re-anchor at the boundary
+    // that was crossed (no transcendental either way; see AtmWindow)
+    {
+      const int lay_new = atm_window_layer(win, p_new);
+      const bool same = lay_new == lay;
+      const bool low_pair = (lay + lay_new) < 0;            // crossing pb (else pt)
+      const double anchor_p = same ? p : (low_pair ? win.pb : win.pt);
+      const double anchor_rp = same ? rp : (low_pair ? win.r_pb : win.r_pt);
+      const double anchor_t = same ? t_at_p : (low_pair ? win.tb : win.tt);
+      const double lapse_new = lay_new < 0 ? win.lapse_m1 : (lay_new == 0 ? win.lapse_0 : win.lapse_p1);
+      t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_new);
+      lay = lay_new;
+      layer = atm_layer_f32(win, lay_new);
     }
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (status != kOk) { ++k; break; }     // balloon.py:327-328
@@ -163,7 +187,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
 
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
   float r = reward_distance(s.x, s.y);
-  if (action == kDown) {   // last_command is the RAW action (balloon.py:286)
+  if (action == kDown && !(BLE_ABLATE & 8)) {   // last_command is the RAW action (balloon.py:286)
     const float fk = (float)k;
     const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
     const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p, flags));

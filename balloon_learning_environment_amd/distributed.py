@@ -1,0 +1,77 @@
+"""Multi-GPU sharding: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Environments are independent (no cross-env term anywhere in the transition), so the env
+index range is partitioned contiguously across ranks and the per-step data path needs no
+collective.  Exactly two exchanges exist:
+  * the decoded wind grid (317 520 B) is broadcast from rank 0 once per episode batch;
+  * rewards / terminals are gathered back to every rank (all_gather) every
+    `gather_every` agent steps, on a side stream so that it overlaps the next steps.
+The helpers are device-agnostic so that the N>1 logic is covered by gloo tests on CPU.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
+  """Contiguous [lo, hi) slice of the env index range owned by `rank` (sizes differ by <= 1)."""
+  base, rem = divmod(n_global, world)
+  lo = rank * base + min(rank, rem)
+  return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_grid(grid: torch.Tensor, src: int = 0) -> torch.Tensor:
+  """Rank `src` owns the wind grid (21,21,10,9,2) float32; everyone gets a copy in place."""
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist.broadcast(grid, src=src)
+  return grid
+
+
+class OutputGatherer:
+  """Gathers [K, n_local] reward / terminal blocks from all ranks into [world, K, n_local].
+
+  With equal shard sizes (the bench and the tests) this is one all_gather_into_tensor per
+  dtype; it is issued on `stream` (a side stream on GPU) after waiting for the producer.
+  """
+
+  def __init__(self, k: int, n_local: int, device, world: Optional[int] = None):
+    self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    self.reward = torch.zeros((self.world, k, n_local), dtype=torch.float32, device=device)
+    self.terminal = torch.zeros((self.world, k, n_local), dtype=torch.uint8, device=device)
+    self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+    self._pending: List = []
+
+  def gather(self, reward_block: torch.Tensor, terminal_block: torch.Tensor) -> None:
+    if self.world == 1:
+      self.reward[0].copy_(reward_block); self.terminal[0].copy_(terminal_block)
+      return
+    if self.stream is not None:
+      self.stream.wait_stream(torch.cuda.current_stream(reward_block.device))
+      with torch.cuda.stream(self.stream):
+        dist.all_gather_into_tensor(self.reward.view(-1, self.reward.shape[-1]), reward_block)
+        dist.all_gather_into_tensor(self.terminal.view(-1, self.terminal.shape[-1]), terminal_block)
+        reward_block.record_stream(self.stream); terminal_block.record_stream(self.stream)
+    else:
+      dist.all_gather_into_tensor(self.reward.view(-1, self.reward.shape[-1]), reward_block)
+      dist.all_gather_into_tensor(self.terminal.view(-1, self.terminal.shape[-1]), terminal_block)
+
+  def wait(self) -> None:
+    if self.stream is not None:
+      torch.cuda.current_stream(self.reward.device).wait_stream(self.stream)
+
+
+def max_over_ranks(value: float, device) -> float:
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return value
+  t = torch.tensor([value], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())
+
+
+def sum_over_ranks(value: float, device) -> float:
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return value
+  t = torch.tensor([value], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  return float(t.item())

@@ -16,6 +16,7 @@ from balloon_learning_environment_amd import device as dev
 
 GRID_SHAPE = (21, 21, 10, 9, 2)  # generative/vae.py:30-38 FieldShape.grid_shape()
 SUBSTEPS = 18                    # constants.AGENT_TIME_STEP (180 s) / 10 s stride
+COUNT_SLOTS = 64                 # BLE_COUNT_SLOTS in include/ble_abi.h
 
 
 class ReferenceError_(Exception):
@@ -52,7 +53,7 @@ class VecSimulator:
       self.terminal = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
       self.effective_action = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
       self.err_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
-      self.active_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+      self.active_slots = torch.zeros(COUNT_SLOTS, dtype=torch.int64, device=self.device)
     self.grid: Optional[torch.Tensor] = None
     self.grid_env_stride = 0
     self._struct = dev.state_struct(self.state)
@@ -95,7 +96,7 @@ class VecSimulator:
     code = self.lib.ble_step_f32(ctypes.byref(self._struct), action.data_ptr(), self.grid.data_ptr(),
                                  self.grid_env_stride, dev.ptr(noise_uv), self.reward.data_ptr(),
                                  self.terminal.data_ptr(), self.effective_action.data_ptr(),
-                                 self.err_flags.data_ptr(), self.active_count.data_ptr(), self.n, substeps,
+                                 self.err_flags.data_ptr(), self.active_slots.data_ptr(), self.n, substeps,
                                  dev.stream_ptr(self.device))
     _lib.check(code, 'ble_step_f32')
     return self.reward, self.terminal
@@ -108,12 +109,18 @@ class VecSimulator:
     assert rewards.dtype == torch.float32 and tuple(rewards.shape) == (k, self.n) and rewards.is_contiguous()
     assert terminals.dtype == torch.uint8 and tuple(terminals.shape) == (k, self.n) and terminals.is_contiguous()
     if active_counts is not None:
-      assert active_counts.dtype == torch.int64 and active_counts.numel() == k
+      assert active_counts.dtype == torch.int64 and tuple(active_counts.shape) == (k, COUNT_SLOTS)
+      assert active_counts.is_contiguous()
     code = self.lib.ble_step_n_f32(ctypes.byref(self._struct), actions.data_ptr(), self.grid.data_ptr(),
                                    self.grid_env_stride, rewards.data_ptr(), terminals.data_ptr(),
                                    self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k,
                                    dev.stream_ptr(self.device))
     _lib.check(code, 'ble_step_n_f32')
+
+  @property
+  def active_count(self) -> torch.Tensor:
+    """Total number of envs stepped so far (sum of the counter slots), a 0-d device tensor."""
+    return self.active_slots.sum()
 
   def check_errors(self) -> None:
     """Synchronises and raises what the reference would have raised (see raise_for_flags)."""

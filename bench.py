@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the vectorised BLE transition on MI355X.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the headline config): 65 536 environments PER GPU,
+random policy, one decoded wind grid shared by all environments (synthetic N(0, 5^2) m/s
+float32 field, seed 0), initial conditions drawn like BalloonArena.reset
+(reset_host.sample_initial_state).  One "step" = one agent step (180 s = 18 x 10 s
+substeps + wind lookup + 3 safety layers + reward/terminal) of every environment of the
+rank = one launch of ble_step_kernel.  Weak scaling: per-GPU work is fixed; with N > 1 the
+grid is broadcast once over RCCL and rewards/terminals are all_gathered every 32 steps on
+a side stream (inside the timed region).  Terminated environments are frozen by the kernel
+and are NOT counted: value = (sum over timed steps of live environments) / seconds.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGORITHMIC_BYTES_PER_ENV_STEP = 280      # 152 B state + 128 B grid gather
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+GATHER_EVERY = 32
+
+
+def cpu_baseline(state, actions, field, seconds_target=12.0):
+  """Times the CPU oracle (oracle/ble_oracle.c, fp64 restatement pinned to the reference)
+  on the host cores of this box.  A reported baseline, not the optimisation target."""
+  sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+  import numpy as np
+  import oracle
+  cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  n = min(state['x'].size, 8192)
+  ost = oracle.new_state(n)
+  for k in oracle.FLOAT_FIELDS:
+    ost[k][:] = state[k][:n].astype(np.float64)
+  for k in oracle.U8_FIELDS:
+    ost[k][:] = state[k][:n]
+  ost['start_unix'][:] = state['start_unix'][:n]; ost['time_elapsed_s'][:] = state['time_elapsed_s'][:n]
+  ost['sunrise_h'][:] = state['start_unix'][:n] + state['sunrise_h_rel'][:n]
+  ost['sunset'][:] = state['start_unix'][:n] + state['sunset_rel'][:n]
+  oracle.step(ost, actions[0][:n], field=field, threads=cores)   # warm-up (page in, spin up threads)
+  steps = 0; live = 0; t0 = time.perf_counter()
+  while True:
+    live += int((ost['status'] == 0).sum())
+    oracle.step(ost, actions[(steps + 1) % len(actions)][:n], field=field, threads=cores)
+    steps += 1
+    if time.perf_counter() - t0 > seconds_target or steps >= 400:
+      break
+  dt = time.perf_counter() - t0
+  return {'value': live / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+          'sample': f'{n} envs x {steps} agent steps of the same workload, fp64 C oracle with OpenMP over envs, {dt:.1f} s'}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--envs-per-gpu', type=int, default=65536)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--active-count', action='store_true', help='analysis only: use the in-kernel live-env counter')
+  ap.add_argument('--substeps', type=int, default=18, help='analysis only: physics substeps per agent step (18 = the metric)')
+  args = ap.parse_args()
+
+  import numpy as np
+  import torch
+  import torch.distributed as dist
+  from balloon_learning_environment_amd import distributed as bdist
+  from balloon_learning_environment_amd import reset_host
+  from balloon_learning_environment_amd import vec_state
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+  assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=device)   # RCCL
+
+  n = args.envs_per_gpu
+  k_total = args.steps + args.warmup
+  # ---- synthetic inputs (host, seeded), then resident in HBM before the timed region
+  state = reset_host.sample_initial_state(n, seed=1000 + rank)
+  sim = vec_state.VecSimulator(n, device)
+  sim.set_state(state)
+  grid = torch.zeros(vec_state.GRID_SHAPE, dtype=torch.float32, device=device)
+  field = None
+  if rank == 0:
+    field = (np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).astype(np.float32)
+    grid.copy_(torch.from_numpy(field))
+  bdist.broadcast_grid(grid, src=0)                     # once per field, over xGMI when world > 1
+  sim.set_grid(grid)
+  gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
+  actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
+  rewards = torch.zeros((k_total, n), dtype=torch.float32, device=device)
+  terminals = torch.zeros((k_total, n), dtype=torch.uint8, device=device)
+  active = torch.zeros((k_total, vec_state.COUNT_SLOTS), dtype=torch.int64, device=device)
+  gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world) if world > 1 else None
+
+  def run(k0, k1):
+    k = k0
+    while k < k1:
+      c = min(GATHER_EVERY, k1 - k)
+      sim.step_n(actions[k:k + c], rewards[k:k + c], terminals[k:k + c], active[k:k + c] if args.active_count else None, substeps=args.substeps)
+      if gatherer is not None and c == GATHER_EVERY:
+        gatherer.gather(rewards[k:k + c], terminals[k:k + c])
+      k += c
+    if gatherer is not None:
+      gatherer.wait()
+
+  run(0, args.warmup)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()            # the kernels are launched on torch's current stream
+  run(args.warmup, k_total)
+  ev1.record()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  elapsed = bdist.max_over_ranks(elapsed, device)
+  sim.check_errors()
+
+  # live environments per step: an env is stepped iff it was not terminal after the previous
+  # step (terminated envs are frozen by the kernel); counted after the timed region
+  live_per_step = n - terminals[args.warmup - 1:k_total - 1].to(torch.int64).sum(dim=1) if args.warmup > 0 else None
+  if live_per_step is None:
+    live_per_step = torch.cat([torch.tensor([n], device=device), n - terminals[:k_total - 1].to(torch.int64).sum(dim=1)])
+  if args.active_count:
+    assert torch.equal(active[args.warmup:].sum(dim=1), live_per_step), 'in-kernel counter disagrees'
+  live_steps = float(live_per_step.sum().item())
+  live_steps_all = bdist.sum_over_ranks(live_steps, device)
+  value = live_steps_all / elapsed
+  kernel_ms = ev0.elapsed_time(ev1) / args.steps          # avg launch duration incl. inter-launch gaps
+  bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (live_steps / args.steps)
+  achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+  traffic = None
+  pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  if os.path.exists(pmc_path):
+    try:
+      traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch')
+    except Exception:
+      traffic = None
+
+  if rank == 0:
+    out = {
+        'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
+        'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{n} vectorised envs per GPU, random policy, one decoded wind grid '
+                               '(BASELINE.json configs[2]: 65 536 envs, 1xMI355X headline)',
+                   'envs_per_gpu': n, 'global_envs': n * world, 'substeps_per_step': args.substeps,
+                   'live_env_fraction_end': float(live_per_step[-1].item()) / n,
+                   'parallelism': f'env-sharded x{world}, grid broadcast once, reward/terminal all_gather every {GATHER_EVERY} steps'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'kernel': 'ble_step_kernel', 'kernel_ms': kernel_ms,
+                     'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
+                     'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)'},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      acts = actions[:64].cpu().numpy()
+      out['cpu_baseline'] = cpu_baseline(state, list(acts), field)
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -55,6 +55,7 @@ extern "C" {
 #define BLE_GRID_NP 10 /* pressure, 5000..14000 Pa step 1000 */
 #define BLE_GRID_NT 9  /* time, 0..48 h step 6 */
 #define BLE_GRID_FLOATS (BLE_GRID_NX * BLE_GRID_NY * BLE_GRID_NP * BLE_GRID_NT * 2) /* 79380 */
+#define BLE_COUNT_SLOTS 64 /* width of the live-environment counter, see ble_step_f32 */
 
 /*
  * Per-environment simulator state, struct of device arrays.
@@ -125,8 +126,10 @@ int ble_device_count(void);
  *   reward        n floats out;  terminal  n bytes out (status != OK after the step)
  *   effective_action  optional n bytes out: the action after the three safety layers
  *   err_flags     optional device uint32, BLE_FLAG_* OR-ed in
- *   active_count  optional device uint64, incremented by the number of envs that were
- *                 actually stepped (status == OK on entry)
+ *   active_count  optional device uint64[BLE_COUNT_SLOTS]: the number of envs that were
+ *                 actually stepped (status == OK on entry) is ADDED, spread over the slots
+ *                 (one same-address atomic per wave would serialise 1 024 waves for ~11 us);
+ *                 the caller sums the slots
  * Envs whose status != OK on entry are skipped: state untouched, reward 0, terminal 1
  * (the reference raises AssertionError, balloon.py:288-290; the host mirror does too).
  */
@@ -138,7 +141,8 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
 /*
  * `n_steps` consecutive agent steps enqueued by one host call (no host round trip
  * between them).  action / reward / terminal are [n_steps][n] row-major;
- * active_count, if given, is [n_steps].  Same semantics per step as ble_step_f32.
+ * active_count, if given, is [n_steps][BLE_COUNT_SLOTS].  Same semantics per step as
+ * ble_step_f32.
  */
 int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid,
                    int64_t grid_env_stride, float* reward, uint8_t* terminal, uint32_t* err_flags,

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round.  Run on the GPU box from the repo root:
+#   bash profiles/run_profile.sh r01
+# Kernel trace (+stats) and PMC counters are collected in SEPARATE runs; PMC passes never
+# combine with sys/hip/hsa/memory-copy tracing.  Raw output goes to gpurun_out/ (scratch);
+# profiles/summarize.py turns it into the committed profiles/<tag>_*.json / .md files.
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+run_pmc () {  # name, counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/$name.log 2>&1
+}
+run_pmc pmc_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+run_pmc pmc_sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH
+run_pmc pmc_f64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32
+run_pmc pmc_misc SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VSKIPPED
+run_pmc pmc_fetch FETCH_SIZE TCC_MISS_sum
+run_pmc pmc_write WRITE_SIZE TCC_HIT_sum
+find $OUT -name "*.csv" | head -40

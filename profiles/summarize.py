@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 CSV output of profiles/run_profile.sh into committed evidence.
+
+  python profiles/summarize.py r01      # reads gpurun_out/prof_r01, writes profiles/r01_*.{json,md}
+Per-launch averages for ble_step_kernel only.  HBM traffic follows the microarch guide:
+FETCH_SIZE / WRITE_SIZE are in KiB... here reported by rocprofv3 in KB units of 1024 B;
+on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads (x2 correction
+applies to 16 B/lane streaming reads only; this kernel's reads are 4 B/lane and 8 B gathers,
+so both the raw and the x2 figure are recorded).
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag):
+  base = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
+  out = {'tag': tag, 'kernel': 'ble_step_kernel'}
+  # kernel stats
+  with open(os.path.join(base, 'trace', 'trace_kernel_stats.csv')) as f:
+    rows = list(csv.DictReader(f))
+  md = ['| kernel | calls | avg us | min us | max us | % |', '|---|---|---|---|---|---|']
+  for r in rows[:8]:
+    name = r['Name'][:70]
+    md.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
+              f"{float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
+    if 'ble_step_kernel' in r['Name']:
+      out['kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
+                             'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3}
+  counters = collections.defaultdict(list)
+  meta = {}
+  for name in sorted(os.listdir(base)):
+    p = os.path.join(base, name, f'{name}_counter_collection.csv')
+    if not os.path.exists(p):
+      continue
+    with open(p) as f:
+      for r in csv.DictReader(f):
+        if 'ble_step_kernel' not in r['Kernel_Name']:
+          continue
+        counters[r['Counter_Name']].append(float(r['Counter_Value']))
+        meta = {'grid': int(r['Grid_Size']), 'wg': int(r['Workgroup_Size']), 'vgpr': int(r['VGPR_Count']),
+                'agpr': int(r['Accum_VGPR_Count']), 'sgpr': int(r['SGPR_Count']), 'scratch': int(r['Scratch_Size']),
+                'lds': int(r['LDS_Block_Size'])}
+  out['dispatch'] = meta
+  avg = {k: sum(v) / len(v) for k, v in counters.items()}
+  out['pmc_per_launch'] = avg
+  waves = avg.get('SQ_WAVES', 0) or 1
+  d = {}
+  if 'SQ_INSTS_VALU' in avg:
+    d['valu_insts_per_wave'] = avg['SQ_INSTS_VALU'] / waves
+    d['salu_insts_per_wave'] = avg.get('SQ_INSTS_SALU', 0) / waves
+    d['vmem_insts_per_wave'] = avg.get('SQ_INSTS_VMEM', 0) / waves
+    d['wave_cycles_per_wave_quad'] = avg.get('SQ_WAVE_CYCLES', 0) / waves
+  for k in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_TRANS_F64',
+            'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_TRANS_F32',
+            'SQ_INSTS_VALU_CVT', 'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_INT64', 'SQ_INSTS_BRANCH'):
+    if k in avg:
+      d[k.replace('SQ_INSTS_', '').lower() + '_per_wave'] = avg[k] / waves
+  if 'SQ_ACTIVE_INST_VALU' in avg and 'SQ_WAIT_INST_ANY' in avg:
+    d['active_inst_valu_quad'] = avg['SQ_ACTIVE_INST_VALU'] / waves
+    d['active_inst_any_quad'] = avg.get('SQ_ACTIVE_INST_ANY', 0) / waves
+    d['wait_inst_any_quad'] = avg['SQ_WAIT_INST_ANY'] / waves
+    d['wait_any_quad'] = avg.get('SQ_WAIT_ANY', 0) / waves
+  out['derived'] = d
+  if 'FETCH_SIZE' in avg or 'WRITE_SIZE' in avg:
+    fetch = avg.get('FETCH_SIZE', 0.0) * 1024.0
+    write = avg.get('WRITE_SIZE', 0.0) * 1024.0
+    out['hbm'] = {'fetch_bytes_raw': fetch, 'write_bytes_raw': write, 'hbm_bytes_per_launch': fetch + write,
+                  'hbm_bytes_per_launch_fetch_x2': 2 * fetch + write,
+                  'tcc_hit': avg.get('TCC_HIT_sum'), 'tcc_miss': avg.get('TCC_MISS_sum')}
+    json.dump({'hbm_bytes_per_launch': fetch + write, 'source': f'profiles/{tag}_summary.json'},
+              open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
+  json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'), 'w'), indent=1)
+  with open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.md'), 'w') as f:
+    f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 100 --warmup 10` ({tag})\n\n')
+    f.write('\n'.join(md) + '\n\n')
+    f.write('## ble_step_kernel PMC (per launch averages; separate --pmc passes)\n\n```json\n')
+    f.write(json.dumps({k: out[k] for k in ('dispatch', 'derived', 'hbm') if k in out}, indent=1))
+    f.write('\n```\n')
+  print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+  main(sys.argv[1] if len(sys.argv) > 1 else 'r01')

@@ -26,7 +26,7 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
     if (wind_uv) { u = wind_uv[2 * i]; v = wind_uv[2 * i + 1]; }
     else { WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed); wind_blend(wind_grid, wq, &u, &v); }
     uint32_t flags = 0; float r;
-    int eff = agent_step(s, c, action[i], u, v, substeps, &r, &flags);
+    int eff = agent_step(s, c, action[i], u, v, substeps, kAcsEfficiency, &r, &flags);
     flags_all |= flags;
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
     st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;
@@ -49,10 +49,10 @@ extern "C" void emul_solar(int64_t n, const float* lat0, const float* lng0, cons
     int64_t sod = t[i] % 86400; if (sod < 0) sod += 86400;
     double b = (double)sod / 240.0 + 0.25 * e.eot_min + (double)lng0[i];
     double sl, cl; sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
-    double oms = sun_one_minus_sin_f64(sl, cl, x[i], y[i], b, e.sin_decl, e.cos_decl);
+    double oms = sun_one_minus_sin_f64(sl, cl, x[i], y[i], b, (double)e.sin_decl, (double)e.cos_decl);
     SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
     el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
-    flux[i] = (float)e.flux;
+    flux[i] = e.flux;
   }
 }
 
