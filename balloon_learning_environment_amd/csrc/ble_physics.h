@@ -424,6 +424,52 @@ BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p
   double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
   return d_fma(t0, em1, t0);
 }
+// three-way pick on VALUES (kept in registers; a select between struct members makes the
+// compiler spill the struct to scratch and index it)
+BLE_FN double pick3(int j, double m1, double c0, double p1) {
+  double r = c0;
+  r = j < 0 ? m1 : r;
+  r = j > 0 ? p1 : r;
+  return r;
+}
+// Height relative to a layer transition (pressure pb, temperature tb) for q within a few Pa
+// of it, inside a layer of lapse rate L (fp64 version of atm_height_rel_boundary).
+BLE_FN double atm_height_rel_boundary_f64(double q, double pb, double r_pb, double tb, double lapse) {
+  const double x = (q - pb) * r_pb;
+  const double lg = x * d_fma(x, d_fma(x, d_fma(x, -0.25, 1.0 / 3.0), -0.5), 1.0);
+  if (lapse == 0.0) return (-kAirSpecificGasD / 9.80665) * tb * lg;
+  const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
+  const double em1 = y * d_fma(y, d_fma(y, d_fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+  return tb * em1 / lapse;
+}
+// 1 / (H(p + d) - H(p)), d = +-1 Pa (balloon.py:438-442), fp64.  j = layer of p in the
+// window, t_p = T(p), rp = 1/p.  The cancellation-free form
+//   dH = (T(p)/L) expm1(k log1p(d/p)),  k = -R_d L / g
+// replaces the difference of two ~17 km heights; when p and p + d lie on different sides
+// of a layer transition both heights are measured from that transition.
+BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double p, double rp, double d, double t_p) {
+  const double x = d * rp;
+  const double lg = x * d_fma(x, d_fma(x, d_fma(x, -0.25, 1.0 / 3.0), -0.5), 1.0);
+  const bool iso = lapse == 0.0;
+  const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
+  const double em1 = y * d_fma(y, d_fma(y, d_fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+  // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
+  double inv = iso ? d_rcp((-kAirSpecificGasD / 9.80665) * t_p * lg) : lapse * d_rcp(t_p * em1);
+  const double q = p + d;
+  const bool below = (j >= 0) && (j == 0 ? q > w.pb : q > w.pt);     // q in the layer with higher pressure
+  const bool above = (j <= 0) && (j == 0 ? !(q > w.pt) : !(q > w.pb));
+  if (__builtin_expect(below || above, 0)) {
+    // transition that separates p and q, and the lapse rate on q's side
+    const bool at_pb = (j == 0) ? below : (j < 0);
+    const double pb = at_pb ? w.pb : w.pt, r_pb = at_pb ? w.r_pb : w.r_pt, tb = at_pb ? w.tb : w.tt;
+    const double lapse_q = pick3(below ? j - 1 : j + 1, w.lapse_m1, w.lapse_0, w.lapse_p1);
+    const double dh = atm_height_rel_boundary_f64(q, pb, r_pb, tb, lapse_q) -
+                      atm_height_rel_boundary_f64(p, pb, r_pb, tb, lapse);
+    inv = 1.0 / dh;
+  }
+  return inv;
+}
+
 // which of the window's three layers holds p: -1 (below i0, higher pressure), 0, +1
 BLE_FN int atm_window_layer(const AtmWindow& w, double p) { return p > w.pb ? -1 : (p > w.pt ? 0 : 1); }
 // fp32 view of the layer `j` of the window (for the dH series)

@@ -46,7 +46,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
   double altitude, t_at_p;
   atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
   int lay = 0;                                   // p is in the window's centre layer by construction
-  AtmLayer layer = atm_layer_f32(win, 0);
+  const double lapse_m1 = win.lapse_m1, lapse_c0 = win.lapse_0, lapse_p1 = win.lapse_p1;
+  double lapse_cur = lapse_c0;                   // lapse rate of the layer holding p
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
 #if BLE_ABLATE & 16
@@ -112,18 +113,24 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
     const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
     const float flux = f_fma(fk, dfl, fl0);
 
-    // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445)
-    const float rho = pf * kAirMolarOverR * f_rcp(t_ambf);
-    const float v23 = f_exp2((2.0f / 3.0f) * f_log2(volf));
-    const float drag = kEnvelopeCod * v23;
-    // rho V - m = (p V M/R - m T) / T : the cancelling numerator in fp64
+    // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
+    // equilibrium d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error
+    // in the increment itself is amplified past the parity bar within a few substeps.
+    const float rho = pf * kAirMolarOverR * f_rcp(t_ambf);                 // fp32 copy for the thermal model
+    const float lv = f_log2(volf);
+    const float v23 = f_exp2((2.0f / 3.0f) * lv);                           // V^(2/3), fp32 (thermal model)
+    // rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
     const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
     const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
-    const float diff = (float)num * f_rcp(t_ambf);
-    const float dir = num >= 0.0 ? 1.0f : -1.0f;
-    const float dh_dt = dir * f_sqrt(fabsf(2.0f * diff * kGravity * f_rcp(rho * drag)));
-    const float dh = atm_delta_height(layer, pf, dir, (float)t_at_p);
-    const double p_new = p + (double)(dir * f_rcp(dh) * dh_dt * kStride);
+    const double dir = num >= 0.0 ? 1.0 : -1.0;
+    // 1/drag = 4 V^(-2/3): V^(-1/3) by one Newton step  y <- y (4 - V y^3) / 3  from an fp32 seed
+    double yc = (double)f_exp2((-1.0f / 3.0f) * lv);
+    yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
+    // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
+    const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * (dir * num) * rp * (yc * yc);
+    const double dh_dt = arg > 0.0 ? d_sqrt_fast(arg) : 0.0;
+    const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, p, rp, dir, t_at_p);
+    const double p_new = d_fma(inv_dh * dh_dt, 10.0, p);                    // dir * dir == 1
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, flags);
@@ -170,10 +177,9 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
       const double anchor_p = same ? p : (low_pair ? win.pb : win.pt);
       const double anchor_rp = same ? rp : (low_pair ? win.r_pb : win.r_pt);
       const double anchor_t = same ? t_at_p : (low_pair ? win.tb : win.tt);
-      const double lapse_new = lay_new < 0 ? win.lapse_m1 : (lay_new == 0 ? win.lapse_0 : win.lapse_p1);
+      const double lapse_new = pick3(lay_new, lapse_m1, lapse_c0, lapse_p1);
       t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_new);
-      lay = lay_new;
-      layer = atm_layer_f32(win, lay_new);
+      lay = lay_new; lapse_cur = lapse_new;
     }
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (status != kOk) { ++k; break; }     // balloon.py:327-328

@@ -1,0 +1,178 @@
+"""Host view of one environment's balloon state (reference: env/balloon/balloon.py:66-250).
+
+`BalloonState` here is a plain record that mirrors the reference dataclass' attribute
+names and unit types; it is materialised from / written back to row i of the device
+state (include/ble_abi.h) by the arena.  The transition itself never runs on these
+objects -- it runs in libble_hip.so.
+"""
+import dataclasses
+import datetime as dt
+import enum
+import math
+
+import numpy as np
+
+from balloon_learning_environment_amd import reset_host
+from balloon_learning_environment_amd.env.balloon import control
+from balloon_learning_environment_amd.utils import units
+
+
+class BalloonStatus(enum.Enum):
+  OK = 0
+  OUT_OF_POWER = 1
+  BURST = 2
+  ZEROPRESSURE = 3
+
+
+@dataclasses.dataclass
+class LatLng:
+  """Minimal stand-in for s2sphere.LatLng (value type, degrees)."""
+  lat_deg: float
+  lng_deg: float
+
+  @classmethod
+  def from_degrees(cls, lat, lng): return cls(float(lat), float(lng))
+
+  def lat(self): return _Angle(math.radians(self.lat_deg))
+  def lng(self): return _Angle(math.radians(self.lng_deg))
+
+
+@dataclasses.dataclass
+class _Angle:
+  radians: float
+
+  @property
+  def degrees(self): return math.degrees(self.radians)
+
+
+@dataclasses.dataclass
+class SafetyLayerView:
+  """What tests/agents read from a safety layer: its paused flag and FSM state code."""
+  navigation_is_paused: bool
+  state_code: int = 0
+
+
+@dataclasses.dataclass
+class BalloonState:
+  center_latlng: LatLng
+  date_time: dt.datetime
+  time_elapsed: dt.timedelta = dt.timedelta()
+  # flight-vehicle constants (balloon.py:156-173); fixed in the kernel
+  envelope_volume_base: float = 1804
+  envelope_volume_dv_pressure: float = 0.0199
+  envelope_mass: float = 68.5
+  envelope_max_superpressure: float = 2380
+  envelope_cod: float = 0.25
+  payload_mass: float = 92.5
+  nighttime_power_load: units.Power = dataclasses.field(default_factory=lambda: units.Power(watts=183.7))
+  daytime_power_load: units.Power = dataclasses.field(default_factory=lambda: units.Power(watts=120.4))
+  acs_valve_hole_diameter: units.Distance = dataclasses.field(default_factory=lambda: units.Distance(m=0.04))
+  battery_capacity: units.Energy = dataclasses.field(default_factory=lambda: units.Energy(watt_hours=3058.56))
+  # state (balloon.py:175-198)
+  x: units.Distance = dataclasses.field(default_factory=lambda: units.Distance(m=0))
+  y: units.Distance = dataclasses.field(default_factory=lambda: units.Distance(m=0))
+  pressure: float = 6000.0
+  ambient_temperature: float = 206.0
+  mols_lift_gas: float = 6830.0
+  mols_air: float = 0.0
+  internal_temperature: float = 206.0
+  envelope_volume: float = 1804.0
+  superpressure: float = 0.0
+  acs_power: units.Power = dataclasses.field(default_factory=lambda: units.Power(watts=0))
+  acs_mass_flow: float = 0.0
+  solar_charging: units.Power = dataclasses.field(default_factory=lambda: units.Power(watts=0))
+  power_load: units.Power = dataclasses.field(default_factory=lambda: units.Power(watts=0))
+  battery_charge: units.Energy = dataclasses.field(default_factory=lambda: units.Energy(watt_hours=2905.6))
+  last_command: control.AltitudeControlCommand = control.AltitudeControlCommand.STAY
+  status: BalloonStatus = BalloonStatus.OK
+  upwelling_infrared: float = 250.0
+  # safety layers (views of the FSM bytes / clocks held on the device)
+  power_safety_layer: SafetyLayerView = dataclasses.field(default_factory=lambda: SafetyLayerView(False))
+  envelope_safety_layer: SafetyLayerView = dataclasses.field(default_factory=lambda: SafetyLayerView(False))
+  altitude_safety_layer: SafetyLayerView = dataclasses.field(default_factory=lambda: SafetyLayerView(False))
+  sunrise_with_hysteresis: dt.datetime = None
+  sunset: dt.datetime = None
+
+  @property
+  def latlng(self) -> LatLng:  # balloon.py:217-220
+    lat, lng = reset_host.latlng_from_offset(np.array([math.radians(self.center_latlng.lat_deg)]),
+                                             np.array([math.radians(self.center_latlng.lng_deg)]),
+                                             np.array([self.x.m]), np.array([self.y.m]))
+    return LatLng(math.degrees(lat[0]), math.degrees(lng[0]))
+
+  @property
+  def battery_soc(self) -> float:
+    return self.battery_charge / self.battery_capacity
+
+  @property
+  def excess_energy(self) -> bool:  # balloon.py:231-238
+    ll = self.latlng
+    el, _ = reset_host.solar_calculator(np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)]),
+                                        np.array([int(self.date_time.timestamp())]))
+    return bool(solar_power_watts(float(el[0]), self.pressure) > self.daytime_power_load.watts and
+                self.battery_soc > 0.99)
+
+  @property
+  def navigation_is_paused(self) -> bool:
+    return (self.power_safety_layer.navigation_is_paused or self.envelope_safety_layer.navigation_is_paused or
+            self.altitude_safety_layer.navigation_is_paused)
+
+  @property
+  def pressure_ratio(self) -> float:
+    return (self.pressure + max(self.superpressure, 0.0)) / self.pressure
+
+
+def solar_power_watts(el_deg: float, pressure: float) -> float:
+  """solar.solar_power (solar.py:515-536), host scalar (used by excess_energy / reward mirror)."""
+  att = float(reset_host.solar_atmospheric_attenuation(np.array([el_deg]), np.array([pressure]))[0])
+
+  def shadow(h):
+    return 0.4392 if el_deg >= math.degrees(math.atan2(math.sqrt(h * (10.41603 + h)), 8.69275)) else 1.0
+  return 210.0 * att * (4 * math.cos(math.radians(el_deg - 35)) * shadow(3.3) +
+                        2 * math.cos(math.radians(el_deg - 65)) * shadow(2.7))
+
+
+# ---- row <-> BalloonState ----------------------------------------------------------------
+def state_from_row(row: dict) -> BalloonState:
+  """`row`: {field: python scalar} for one env, fields of ble_state_f32."""
+  start = int(row['start_unix'])
+  now = start + int(row['time_elapsed_s'])
+  return BalloonState(
+      center_latlng=LatLng(float(row['center_lat_deg']), float(row['center_lng_deg'])),
+      date_time=units.datetime_from_timestamp(now), time_elapsed=dt.timedelta(seconds=int(row['time_elapsed_s'])),
+      x=units.Distance(m=float(row['x'])), y=units.Distance(m=float(row['y'])), pressure=float(row['pressure']),
+      ambient_temperature=float(row['ambient_temperature']), mols_air=float(row['mols_air']),
+      internal_temperature=float(row['internal_temperature']), envelope_volume=float(row['envelope_volume']),
+      superpressure=float(row['superpressure']), acs_power=units.Power(watts=float(row['acs_power'])),
+      acs_mass_flow=float(row['acs_mass_flow']), solar_charging=units.Power(watts=float(row['solar_charging'])),
+      power_load=units.Power(watts=float(row['power_load'])),
+      battery_charge=units.Energy(watt_hours=float(row['battery_charge'])),
+      last_command=control.AltitudeControlCommand(int(row['last_command'])), status=BalloonStatus(int(row['status'])),
+      upwelling_infrared=float(row['upwelling_infrared']),
+      power_safety_layer=SafetyLayerView(bool(row['power_paused']), int(row['power_paused'])),
+      envelope_safety_layer=SafetyLayerView(int(row['env_fsm']) != 0, int(row['env_fsm'])),
+      altitude_safety_layer=SafetyLayerView(int(row['alt_fsm']) != 0, int(row['alt_fsm'])),
+      sunrise_with_hysteresis=units.datetime_from_timestamp(start + int(row['sunrise_h_rel'])),
+      sunset=units.datetime_from_timestamp(start + int(row['sunset_rel'])))
+
+
+def row_from_state(s: BalloonState, alpha: float) -> dict:
+  now = int(s.date_time.timestamp())
+  elapsed = int(s.time_elapsed.total_seconds())
+  start = now - elapsed
+  if s.sunrise_with_hysteresis is None or s.sunset is None:
+    ll = s.latlng
+    sr, ss = reset_host.next_sunrise_sunset(np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)]),
+                                            np.array([now]))
+    sunrise_h, sunset = int(sr[0]) + 1800, int(ss[0])
+  else:
+    sunrise_h, sunset = int(s.sunrise_with_hysteresis.timestamp()), int(s.sunset.timestamp())
+  return dict(x=s.x.m, y=s.y.m, pressure=s.pressure, ambient_temperature=s.ambient_temperature,
+              internal_temperature=s.internal_temperature, envelope_volume=s.envelope_volume,
+              superpressure=s.superpressure, mols_air=s.mols_air, battery_charge=s.battery_charge.watt_hours,
+              acs_power=s.acs_power.watts, acs_mass_flow=s.acs_mass_flow, solar_charging=s.solar_charging.watts,
+              power_load=s.power_load.watts, center_lat_deg=s.center_latlng.lat_deg,
+              center_lng_deg=s.center_latlng.lng_deg, upwelling_infrared=s.upwelling_infrared, alpha=alpha,
+              start_unix=start, time_elapsed_s=elapsed, sunrise_h_rel=sunrise_h - start, sunset_rel=sunset - start,
+              status=s.status.value, last_command=int(s.last_command), alt_fsm=s.altitude_safety_layer.state_code,
+              env_fsm=s.envelope_safety_layer.state_code, power_paused=int(s.power_safety_layer.navigation_is_paused))

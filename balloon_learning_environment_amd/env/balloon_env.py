@@ -1,0 +1,116 @@
+"""BalloonEnv (env/balloon_env.py:106-300): the gym-style RL surface over the HIP arena."""
+import math
+import time
+from typing import Any, Callable, Dict, Mapping, Optional, Tuple, Union
+
+import numpy as np
+
+from balloon_learning_environment_amd.env import balloon_arena
+from balloon_learning_environment_amd.env import features
+from balloon_learning_environment_amd.env import grid_based_wind_field
+from balloon_learning_environment_amd.env import grid_wind_field_sampler
+from balloon_learning_environment_amd.env import simulator_data
+from balloon_learning_environment_amd.env.balloon import balloon
+from balloon_learning_environment_amd.env.balloon import control
+from balloon_learning_environment_amd.utils import units
+
+
+def perciatelli_reward_function(simulator_state: simulator_data.SimulatorState, *, station_keeping_radius_km: float = 50.0,
+                                reward_dropoff: float = 0.4, reward_halflife: float = 100.0) -> float:
+  """Host restatement of env/balloon_env.py:44-102 for callers that pass their own
+  reward_function / non-default parameters; the default path uses the kernel's reward."""
+  b = simulator_state.balloon_state
+  radius = units.Distance(km=station_keeping_radius_km)
+  distance = units.relative_distance(b.x, b.y)
+  if distance <= radius:
+    reward = 1.0
+  else:
+    reward = reward_dropoff * math.exp(-0.69314718056 / reward_halflife * (distance - radius).kilometers)
+  if b.last_command == control.AltitudeControlCommand.DOWN and not b.excess_energy:
+    scale = min(max((b.acs_power.watts - 100.0) / (300.0 - 100.0), 0.0), 1.0)
+    reward *= 0.95 - 0.3 * scale
+  return reward
+
+
+def generative_wind_field_factory(device='cuda:0'):
+  """The reference's default is the VAE sampler (weights absent); this is the synthetic stand-in."""
+  return grid_based_wind_field.GridBasedWindField(grid_wind_field_sampler.GaussianFieldSampler(), device)
+
+
+class BalloonEnv:
+  """Old-gym (0.21) 4-tuple API like the reference."""
+  metadata: Dict[str, Any] = {}
+
+  def __init__(self, *, station_keeping_radius_km: float = 50.0,
+               arena: Optional[balloon_arena.BalloonArenaInterface] = None,
+               reward_function: Callable[[simulator_data.SimulatorState], float] = perciatelli_reward_function,
+               feature_constructor_factory: Callable = features.StateFeatureConstructor,
+               wind_field_factory: Callable = generative_wind_field_factory, seed: Optional[int] = None,
+               renderer=None):
+    self.radius = units.Distance(km=station_keeping_radius_km)
+    self._reward_fn = reward_function
+    self._use_kernel_reward = (reward_function is perciatelli_reward_function and station_keeping_radius_km == 50.0)
+    self._global_iteration = 0
+    self.arena = arena if arena is not None else balloon_arena.BalloonArena(feature_constructor_factory, wind_field_factory())
+    self._renderer = renderer
+    self.reset(seed=seed if seed is not None else int(time.time() * 1e6) % (2 ** 31))
+
+  def step(self, action: int) -> Tuple[np.ndarray, float, bool, Mapping[str, Any]]:
+    command = control.AltitudeControlCommand(action)
+    observation = self.arena.step(command)
+    assert isinstance(observation, np.ndarray)
+    simulator_state = self.arena.get_simulator_state()
+    if self._renderer is not None:
+      self._renderer.step(simulator_state)
+    kernel_reward = getattr(self.arena, 'last_reward', None)
+    reward = kernel_reward if (self._use_kernel_reward and kernel_reward is not None) else self._reward_fn(simulator_state)
+    info = self._get_info(simulator_state.balloon_state)
+    is_terminal = info['out_of_power'] or info['envelope_burst'] or info['zeropressure']
+    self._global_iteration += 1
+    return observation, reward, is_terminal, info
+
+  def reset(self, *, seed: Optional[int] = None, return_info: bool = False):
+    if seed is not None:
+      self.seed(seed)
+    self._rng = np.random.Generator(np.random.Philox(self._rng.integers(0, 2 ** 31)))
+    observation = self.arena.reset(int(self._rng.integers(0, 2 ** 31)))
+    if return_info:
+      return observation, self._get_info(self.get_simulator_state().balloon_state)
+    return observation
+
+  def render(self, mode: str = 'human'):
+    return None if self._renderer is None else self._renderer.render(mode)
+
+  def close(self) -> None:
+    pass
+
+  def seed(self, seed: int) -> None:
+    self._rng = np.random.Generator(np.random.Philox(int(seed)))
+
+  @property
+  def unwrapped(self): return self
+
+  @property
+  def action_space(self): return features.Discrete(3)
+
+  @property
+  def observation_space(self): return self.arena.feature_constructor.observation_space
+
+  @property
+  def reward_range(self): return (0.0, 1.0)
+
+  def get_simulator_state(self) -> simulator_data.SimulatorState:
+    return self.arena.get_simulator_state()
+
+  def _get_info(self, balloon_state: balloon.BalloonState) -> Dict[str, Any]:
+    return {'out_of_power': balloon_state.status == balloon.BalloonStatus.OUT_OF_POWER,
+            'envelope_burst': balloon_state.status == balloon.BalloonStatus.BURST,
+            'zeropressure': balloon_state.status == balloon.BalloonStatus.ZEROPRESSURE,
+            'time_elapsed': balloon_state.time_elapsed}
+
+  def __str__(self): return 'BalloonEnv'
+  def __enter__(self): return self
+
+  def __exit__(self, *args):
+    self.close()
+    return False

@@ -1,0 +1,51 @@
+"""GridBasedWindField (env/grid_based_wind_field.py:28-187): lookups run in libble_hip.so."""
+import ctypes
+import datetime as dt
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from balloon_learning_environment_amd import _lib
+from balloon_learning_environment_amd import device as dev
+from balloon_learning_environment_amd.env import grid_wind_field_sampler
+from balloon_learning_environment_amd.env import wind_field
+from balloon_learning_environment_amd.utils import units
+
+
+class GridBasedWindField(wind_field.WindField):
+  def __init__(self, wind_field_sampler: grid_wind_field_sampler.GridWindFieldSampler, device='cuda:0'):
+    self._wind_field_sampler = wind_field_sampler
+    self.field_shape = wind_field_sampler.field_shape
+    self.device = dev.require_gpu(device)
+    self.field = None          # host copy (numpy), like the reference attribute
+    self.grid = None           # device tensor (21,21,10,9,2) float32
+
+  def reset_forecast(self, key, date_time: dt.datetime) -> None:
+    self.set_field(self._wind_field_sampler.sample_field(key, date_time))
+
+  def set_field(self, field) -> None:
+    self.field = np.ascontiguousarray(field, np.float32)
+    assert self.field.shape == tuple(self.field_shape.grid_shape())
+    self.grid = torch.from_numpy(self.field).to(self.device)
+
+  def get_forecast(self, x: units.Distance, y: units.Distance, pressure: float,
+                   elapsed_time: dt.timedelta) -> wind_field.WindVector:
+    if self.grid is None:
+      raise RuntimeError('Must call reset before get_forecast.')
+    return self.get_forecast_column(x, y, [pressure], elapsed_time)[0]
+
+  def get_forecast_column(self, x, y, pressures: Sequence[float], elapsed_time) -> List[wind_field.WindVector]:
+    if self.grid is None:
+      raise RuntimeError('Must call reset before get_forecast.')
+    lib = _lib.lib()
+    n = len(pressures)
+    xs = torch.full((n,), float(x.m), dtype=torch.float32, device=self.device)
+    ys = torch.full((n,), float(y.m), dtype=torch.float32, device=self.device)
+    ps = torch.tensor(np.asarray(pressures, np.float32), device=self.device)
+    ts = torch.full((n,), int(elapsed_time.total_seconds()), dtype=torch.int32, device=self.device)
+    u = torch.empty(n, dtype=torch.float32, device=self.device); v = torch.empty_like(u)
+    _lib.check(lib.ble_forecast_f32(self.grid.data_ptr(), 0, xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), ts.data_ptr(),
+                                    u.data_ptr(), v.data_ptr(), n, dev.stream_ptr(self.device)), 'ble_forecast_f32')
+    u, v = u.cpu().numpy(), v.cpu().numpy()
+    return [wind_field.WindVector(units.Velocity(mps=float(a)), units.Velocity(mps=float(b))) for a, b in zip(u, v)]

@@ -1,0 +1,114 @@
+"""Host-side logic and the C-ABI surface, CPU only (no compute calls without a GPU)."""
+import ctypes
+import datetime as dt
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from balloon_learning_environment_amd import _abi, _lib
+from balloon_learning_environment_amd.env.balloon import balloon, control
+from balloon_learning_environment_amd.env import balloon_env, simulator_data
+from balloon_learning_environment_amd.utils import units
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
+  declared = set(re.findall(r'^int (ble_\w+)\(', header, re.M))
+  assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+  path = _lib.build()                     # hipcc cross-compiles gfx950 without a GPU
+  out = subprocess.check_output(['nm', '-D', '--defined-only', path]).decode()
+  exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+  assert declared <= exported
+  lib = ctypes.CDLL(path)                 # loads on a CPU-only box (libamdhip64 is present)
+  assert lib.ble_abi_version() == _lib.ABI_VERSION
+
+
+def test_state_struct_matches_header_order():
+  header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
+  body = header[header.index('typedef struct ble_state_f32 {'):header.index('} ble_state_f32;')]
+  names = re.findall(r'\*\s*(\w+);', body)
+  assert tuple(names) == _abi.FIELD_NAMES
+  assert ctypes.sizeof(_abi.BleStateF32) == 8 * len(_abi.FIELD_NAMES)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+  monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+  monkeypatch.setattr(_lib, '_lib', None)
+  with pytest.raises(_lib.BleLibraryError, match='no CPU fallback'):
+    _lib.lib()
+
+
+def test_no_cpu_path_without_gpu():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  from balloon_learning_environment_amd import vec_state
+  with pytest.raises(RuntimeError, match='no CPU path'):
+    vec_state.VecSimulator(4, 'cuda:0')
+  with pytest.raises(RuntimeError, match='no CPU path'):
+    vec_state.VecSimulator(4, 'cpu')
+
+
+def test_product_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'balloon_learning_environment_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.h', '.hip')):
+        src = open(os.path.join(dirpath, f)).read()
+        assert 'import oracle' not in src and 'libble_oracle' not in src and 'ble_oracle' not in src, f
+
+
+def test_units_behave_like_the_reference():
+  d = units.Distance(km=1.5) + units.Distance(feet=1000.0)
+  assert d.m == pytest.approx(1500 + 304.8)
+  assert (units.Velocity(mps=3.0) * dt.timedelta(seconds=10)).m == 30.0
+  assert (units.Power(watts=360.0) * dt.timedelta(seconds=10)).watt_hours == pytest.approx(1.0)
+  assert units.Energy(watt_hours=5.0) / units.Energy(watt_hours=10.0) == 0.5
+  assert units.relative_distance(units.Distance(m=3.0), units.Distance(m=4.0)).m == 5.0
+  with pytest.raises(NotImplementedError):
+    _ = units.Distance(m=1.0) + 3.0
+  assert units.datetime(2013, 9, 21, 18).timestamp() == 1379786400
+
+
+def test_balloon_state_row_roundtrip_and_properties():
+  row = dict(x=1234.5, y=-777.0, pressure=8123.0, ambient_temperature=201.0, internal_temperature=215.0,
+             envelope_volume=1810.0, superpressure=1234.0, mols_air=1500.0, battery_charge=2900.0, acs_power=100.0,
+             acs_mass_flow=0.01, solar_charging=300.0, power_load=220.4, center_lat_deg=2.5, center_lng_deg=-70.0,
+             upwelling_infrared=260.0, alpha=0.5, start_unix=1364203532, time_elapsed_s=360, sunrise_h_rel=5000,
+             sunset_rel=40000, status=0, last_command=0, alt_fsm=1, env_fsm=3, power_paused=1)
+  s = balloon.state_from_row(row)
+  assert s.x.m == 1234.5 and s.time_elapsed == dt.timedelta(seconds=360) and s.status == balloon.BalloonStatus.OK
+  assert s.navigation_is_paused and s.altitude_safety_layer.navigation_is_paused
+  assert s.pressure_ratio == pytest.approx((8123.0 + 1234.0) / 8123.0)   # balloon_test.py:85-91 semantics
+  s.superpressure = -52.0
+  assert s.pressure_ratio == 1.0
+  s.superpressure = 1234.0
+  back = balloon.row_from_state(s, 0.5)
+  for k, v in row.items():
+    assert back[k] == pytest.approx(v), k
+  # latlng follows the oracle's spherical offset
+  lat, lng = oracle.latlng_from_offset(np.radians(2.5), np.radians(-70.0), 1234.5, -777.0)
+  assert s.latlng.lat_deg == pytest.approx(np.degrees(lat[0]), abs=1e-12)
+  assert s.latlng.lng_deg == pytest.approx(np.degrees(lng[0]), abs=1e-12)
+
+
+@pytest.mark.parametrize('x,y,batt,acs_w,cmd,t', [
+    (1000.0, -1000.0, 2900.0, 0.0, 1, '2013-03-25T12:00:00'),
+    (60000.0, 20000.0, 2900.0, 0.0, 1, '2013-03-25T12:00:00'),
+    (0.0, 0.0, 1000.0, 250.0, 0, '2013-03-25T00:00:00'),
+    (120000.0, 0.0, 3050.0, 100.0, 0, '2013-03-25T12:00:00'),
+])
+def test_host_reward_mirror_matches_oracle(x, y, batt, acs_w, cmd, t):
+  now = dt.datetime.fromisoformat(t).replace(tzinfo=dt.timezone.utc)
+  s = balloon.BalloonState(center_latlng=balloon.LatLng(0.0, 0.0), date_time=now, x=units.Distance(m=x),
+                           y=units.Distance(m=y), pressure=8000.0, battery_charge=units.Energy(watt_hours=batt),
+                           acs_power=units.Power(watts=acs_w), last_command=control.AltitudeControlCommand(cmd))
+  got = balloon_env.perciatelli_reward_function(simulator_data.SimulatorState(s, None, simulator_data.Atmosphere(0.5)))
+  ref = oracle.reward_only(x, y, 8000.0, batt, acs_w, cmd, 0.0, 0.0, int(now.timestamp()), 0)
+  assert got == pytest.approx(ref, rel=1e-12)
