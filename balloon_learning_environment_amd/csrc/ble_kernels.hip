@@ -68,16 +68,15 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     c.ir = st.upwelling_infrared[i]; c.alpha = st.alpha[i]; c.start_unix = st.start_unix[i];
     const int act = action[i];
 
-    // wind at the PRE-step position/time (balloon_arena.py:194,270-275)
-    float u, v;
-    {
-      const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
-      wind_blend(wind_grid + i * grid_env_stride, wq, &u, &v);
-      if (noise_uv) { u += noise_uv[2 * i]; v += noise_uv[2 * i + 1]; }
-    }
+    // wind at the PRE-step position/time (balloon_arena.py:194,270-275): gather now, blend later
+    const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+    WindCorners corners;
+    wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
+    float nu = 0.0f, nv = 0.0f;
+    if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
 
     float r;
-    const int eff = agent_step(s, c, act, u, v, substeps, acs_table, &r, &flags);
+    const int eff = agent_step(s, c, act, corners, wq, nu, nv, substeps, acs_table, &r, &flags);
 
     if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
       flags |= kFlagNonFinite;
@@ -243,6 +242,28 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
 }
 
+}  // namespace
+// fp64 primitive probe (test-only entry point): op 0 rcp seed, 1 d_rcp, 2 rsq seed, 3 d_rsqrt,
+// 4 d_sqrt_fast, 5 d_log_fast, 6 d_exp_fast, 7 sin (sincos_f64), 8 cos (sincos_f64)
+__global__ __launch_bounds__(256) void probe_f64_kernel(const double* x, double* y, int op, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  double r = 0.0, t = 0.0;
+  switch (op) {
+    case 0: r = d_rcp_seed(v); break;
+    case 1: r = d_rcp(v); break;
+    case 2: r = d_rsq_seed(v); break;
+    case 3: r = d_rsqrt(v); break;
+    case 4: r = d_sqrt_fast(v); break;
+    case 5: r = d_log_fast(v); break;
+    case 6: r = d_exp_fast(v); break;
+    case 7: sincos_f64(v, &r, &t); break;
+    default: sincos_f64(v, &t, &r); break;
+  }
+  y[i] = r;
+}
+namespace {
 inline int env_lanes() {
   static const int lanes = [] {
     const char* e = getenv("BLE_LANES_PER_WAVE");
@@ -380,6 +401,13 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
   hipLaunchKernelGGL(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
                      pressure, volume, superpressure, n);
   return launch_status();
+}
+
+int ble_probe_f64_prims(const double* x, double* y, int op, int64_t n, void* stream) {
+  if (!x || !y || n < 0 || op < 0 || op > 8) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(probe_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, op, n);
+  return hipGetLastError() == hipSuccess ? BLE_OK : BLE_E_LAUNCH;
 }
 
 int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency, float* mass_flow, int64_t n,

@@ -85,8 +85,10 @@ BLE_FN double d_fma(double a, double b, double c) { return fma(a, b, c); }
 BLE_FN double d_rint(double x) { return rint(x); }
 BLE_FN double d_sqrt(double x) { return sqrt(x); }
 #endif
-// fp64 reciprocal / reciprocal-sqrt: hardware seed (v_rcp_f64 / v_rsq_f64) + Newton steps,
-// no v_div_scale/v_div_fixup ladder (inputs here are normal, positive, far from overflow).
+// fp64 reciprocal / reciprocal-sqrt: hardware seed (v_rcp_f64 / v_rsq_f64, measured 4.3e-8 /
+// 5.0e-8 relative on gfx950) + ONE Newton step -> ~2e-15 / 4e-15 relative.  That is five
+// orders below what the vertical chain needs (1e-10) and avoids both the second step and the
+// v_div_scale/v_div_fixup ladder (inputs here are normal, positive, far from overflow).
 #if BLE_DEVICE_BUILD
 BLE_FN double d_rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }
 BLE_FN double d_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
@@ -102,16 +104,11 @@ BLE_FN double d_ldexp(double x, int e) { return ldexp(x, e); }
 #endif
 BLE_FN double d_rcp(double x) {
   double r = d_rcp_seed(x);
-  r = d_fma(d_fma(-x, r, 1.0), r, r);
-  r = d_fma(d_fma(-x, r, 1.0), r, r);
-  return r;
+  return d_fma(d_fma(-x, r, 1.0), r, r);
 }
 BLE_FN double d_rsqrt(double x) {
   double y = d_rsq_seed(x);
-  double h = 0.5 * x;
-  y = y * d_fma(-h * y, y, 1.5);
-  y = y * d_fma(-h * y, y, 1.5);
-  return y;
+  return y * d_fma(-0.5 * x * y, y, 1.5);
 }
 BLE_FN double d_sqrt_fast(double x) {   // x > 0
   double y = d_rsqrt(x);
@@ -448,11 +445,11 @@ BLE_FN double atm_height_rel_boundary_f64(double q, double pb, double r_pb, doub
 // replaces the difference of two ~17 km heights; when p and p + d lie on different sides
 // of a layer transition both heights are measured from that transition.
 BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double p, double rp, double d, double t_p) {
-  const double x = d * rp;
-  const double lg = x * d_fma(x, d_fma(x, d_fma(x, -0.25, 1.0 / 3.0), -0.5), 1.0);
+  const double x = d * rp;                      // |x| ~ 1e-4: log1p to x^3 (next term 2.5e-13 relative)
+  const double lg = x * d_fma(x, d_fma(x, 1.0 / 3.0, -0.5), 1.0);
   const bool iso = lapse == 0.0;
-  const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
-  const double em1 = y * d_fma(y, d_fma(y, d_fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+  const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;   // |y| ~ 2e-5: expm1 to y^3
+  const double em1 = y * d_fma(y, d_fma(y, 1.0 / 6.0, 0.5), 1.0);
   // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
   double inv = iso ? d_rcp((-kAirSpecificGasD / 9.80665) * t_p * lg) : lapse * d_rcp(t_p * em1);
   const double q = p + d;
@@ -585,25 +582,42 @@ BLE_FN WindQuery wind_query(float x_m, float y_m, float pressure, int32_t elapse
   wind_axis(t_h, 0.0f, 1.0f / 6.0f, 6.0f, 9, &wq.it, &wq.wt);
   return wq;
 }
-// 16-corner blend.  Each (x, y, p) corner is 4 contiguous floats (t, t+1) x (u, v).
-BLE_FN void wind_blend(const float* __restrict__ grid, const WindQuery& wq, float* u, float* v) {
-  float au = 0.0f, av = 0.0f;
+// 16-corner gather + blend.  Each (x, y, p) corner is 4 contiguous floats (t, t+1) x (u, v):
+// 8 x 16 B per query.  The gather is split from the blend so that the kernel can issue the
+// loads as soon as the state has arrived and blend after the per-step constants.
+struct WindCorners { float c[8][4]; };
+BLE_FN void wind_gather(const float* __restrict__ grid, const WindQuery& wq, WindCorners* out) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float* cell = grid + ((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + (wq.ip + c)) * 9 + wq.it) * 2;
+        float* o = out->c[a * 4 + b * 2 + c];
+        o[0] = cell[0]; o[1] = cell[1]; o[2] = cell[2]; o[3] = cell[3];
+      }
+}
+BLE_FN void wind_blend_corners(const WindCorners& wc, const WindQuery& wq, float* u, float* v) {
+  float au = 0.0f, av = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float* o = wc.c[a * 4 + b * 2 + c];
         float w3 = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (c ? wq.wp : 1.0f - wq.wp);
         float w0 = w3 * (1.0f - wq.wt), w1 = w3 * wq.wt;
-        float u0 = cell[0], v0 = cell[1], u1 = cell[2], v1 = cell[3];
-        au = f_fma(u0, w0, au); av = f_fma(v0, w0, av);
-        au = f_fma(u1, w1, au); av = f_fma(v1, w1, av);
+        au = f_fma(o[0], w0, au); av = f_fma(o[1], w0, av);
+        au = f_fma(o[2], w1, au); av = f_fma(o[3], w1, av);
       }
-    }
-  }
   *u = au; *v = av;
+}
+BLE_FN void wind_blend(const float* __restrict__ grid, const WindQuery& wq, float* u, float* v) {
+  WindCorners wc;
+  wind_gather(grid, wq, &wc);
+  wind_blend_corners(wc, wq, u, v);
 }
 
 // ---------------------------------------------------------------- solar

@@ -38,8 +38,11 @@ struct EnvConst {
 
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
-BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float v, int substeps,
-                      const float* acs_table, float* reward, uint32_t* flags) {
+// The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
+// blend happens after the per-step constants so that the gather's latency is covered.
+BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorners& corners, const WindQuery& wq,
+                      float noise_u, float noise_v, int substeps, const float* acs_table, float* reward,
+                      uint32_t* flags) {
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   double p = (double)s.p;
   const AtmWindow win = atm_window((double)c.alpha, p, flags);
@@ -68,6 +71,9 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, float u, float 
 #endif
   const double inv_n = 1.0 / (double)substeps;
   const float fl0 = e0.flux, dfl = (e1.flux - e0.flux) * (float)inv_n;
+  float u, v;
+  wind_blend_corners(corners, wq, &u, &v);         // wind at the PRE-step position/time
+  u += noise_u; v += noise_v;                      // WindField.get_ground_truth = forecast + noise
   // Solar geometry: 1 - sin(el_uncorrected) at substep indices 0, n/2, n in fp64, then a
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
   float oms_c0, oms_c1, oms_c2;

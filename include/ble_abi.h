@@ -197,6 +197,11 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
 int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency,
                       float* mass_flow, int64_t n, void* stream);
 
+/* The kernel's own fp64 primitives (reciprocal / rsqrt seeds and refinements, log, exp,
+ * sincos), element-wise on device doubles.  op: 0 rcp seed, 1 rcp, 2 rsq seed, 3 rsqrt,
+ * 4 sqrt, 5 log, 6 exp, 7 sin, 8 cos.  Test-only. */
+int ble_probe_f64_prims(const double* x, double* y, int op, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,11 +22,17 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
     s.t_elapsed = st->time_elapsed_s[i]; s.sunrise_h = st->sunrise_h_rel[i]; s.sunset = st->sunset_rel[i];
     s.status = st->status[i]; s.alt_fsm = st->alt_fsm[i]; s.env_fsm = st->env_fsm[i]; s.paused = st->power_paused[i];
     EnvConst c{st->center_lat_deg[i], st->center_lng_deg[i], st->upwelling_infrared[i], st->alpha[i], st->start_unix[i]};
-    float u, v;
-    if (wind_uv) { u = wind_uv[2 * i]; v = wind_uv[2 * i + 1]; }
-    else { WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed); wind_blend(wind_grid, wq, &u, &v); }
+    WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+    WindCorners wc;
+    float nu = 0.0f, nv = 0.0f;
+    if (wind_uv) {  // fixed wind: zero grid + the wind as the additive term
+      for (int a = 0; a < 8; ++a) for (int b = 0; b < 4; ++b) wc.c[a][b] = 0.0f;
+      nu = wind_uv[2 * i]; nv = wind_uv[2 * i + 1];
+    } else {
+      wind_gather(wind_grid, wq, &wc);
+    }
     uint32_t flags = 0; float r;
-    int eff = agent_step(s, c, action[i], u, v, substeps, kAcsEfficiency, &r, &flags);
+    int eff = agent_step(s, c, action[i], wc, wq, nu, nv, substeps, kAcsEfficiency, &r, &flags);
     flags_all |= flags;
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
     st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;

@@ -468,3 +468,29 @@ def test_balloon_env_gym_surface(ble):
 
 def units_distance(s):
   return (s.x.km ** 2 + s.y.km ** 2) ** 0.5
+
+
+def test_fp64_primitives_on_device(ble):
+  """The kernel's libm-free fp64 primitives, measured on the hardware."""
+  from balloon_learning_environment_amd import _lib
+  lib = _lib.lib()
+  rng = np.random.default_rng(0)
+
+  def run(op, x):
+    xd = _dev(x, np.float64); yd = torch.empty_like(xd)
+    _call(lib, 'ble_probe_f64_prims', xd, yd, op, x.size, None)
+    return yd.cpu().numpy()
+
+  x = np.concatenate([rng.uniform(0.5, 2.0, 4000), rng.uniform(1e-3, 1e6, 4000), 10.0 ** rng.uniform(-8, 8, 2000)])
+  rel = lambda a, b: np.abs(a - b) / np.abs(b)
+  seed_rcp = rel(run(0, x), 1.0 / x).max(); seed_rsq = rel(run(2, x), 1.0 / np.sqrt(x)).max()
+  print(f'v_rcp_f64 seed rel err {seed_rcp:.3g}, v_rsq_f64 seed rel err {seed_rsq:.3g}')
+  assert seed_rcp < 1e-7 and seed_rsq < 1e-7          # one Newton step from these seeds: ~1e-14
+  assert rel(run(1, x), 1.0 / x).max() < 1e-14
+  assert rel(run(3, x), 1.0 / np.sqrt(x)).max() < 2e-14
+  assert rel(run(4, x), np.sqrt(x)).max() < 1e-15
+  assert np.abs(run(5, x) - np.log(x)).max() < 1e-13 and rel(run(5, x[x > 1.1]), np.log(x[x > 1.1])).max() < 2e-14
+  t = rng.uniform(-40, 40, 8000)
+  assert rel(run(6, t), np.exp(t)).max() < 2e-15
+  a = rng.uniform(-200, 200, 8000)
+  assert np.abs(run(7, a) - np.sin(a)).max() < 3e-16 and np.abs(run(8, a) - np.cos(a)).max() < 3e-16
