@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void probe_solar_kernel(const float* lat0, con
   const double b = (double)sod * (1.0 / 240.0) + 0.25 * e.eot_min + (double)lng0[i];
   double sl, cl;
   sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
-  const double oms = sun_one_minus_sin_f64(sl, cl, (double)x[i], (double)y[i], b, (double)e.sin_decl, (double)e.cos_decl);
+  double sb, cb;
+  sincos_f64(b * (kPiD / 180.0), &sb, &cb);
+  const double oms = sun_one_minus_sin_f64(sl, cl, (double)x[i], (double)y[i], sb, cb, (double)e.sin_decl, (double)e.cos_decl);
   const SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
   el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
   flux[i] = e.flux;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_
   double s, c;
   sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
   uint32_t flags = 0;
-  const float a = solar_attenuation((float)s, pressure[i], &flags);
+  const float a = solar_attenuation((float)s, pressure[i]);
   att[i] = a;
   power[i] = solar_power((float)s, (float)c, a);
 }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume,
   if (i < n) {
     double s, c;
     sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
-    const float att = solar_attenuation((float)s, pressure[i], &flags);
+    const float att = solar_attenuation((float)s, pressure[i]);
     const float rho = pressure[i] * kAirMolarOverR * f_rcp(t_amb[i]);
     const float v23 = f_exp2((2.0f / 3.0f) * f_log2(volume[i]));
     dtdt[i] = thermal_dtdt(v23, t_int[i], t_amb[i], rho, flux[i] * att, earth_heat_per_area(ir[i], &flags), &flags);

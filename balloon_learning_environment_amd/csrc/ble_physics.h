@@ -444,7 +444,8 @@ BLE_FN double atm_height_rel_boundary_f64(double q, double pb, double r_pb, doub
 //   dH = (T(p)/L) expm1(k log1p(d/p)),  k = -R_d L / g
 // replaces the difference of two ~17 km heights; when p and p + d lie on different sides
 // of a layer transition both heights are measured from that transition.
-BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double p, double rp, double d, double t_p) {
+BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double cur_hi, double cur_lo,
+                                       double p, double rp, double d, double t_p) {
   const double x = d * rp;                      // |x| ~ 1e-4: log1p to x^3 (next term 2.5e-13 relative)
   const double lg = x * d_fma(x, d_fma(x, 1.0 / 3.0, -0.5), 1.0);
   const bool iso = lapse == 0.0;
@@ -453,8 +454,9 @@ BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, 
   // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
   double inv = iso ? d_rcp((-kAirSpecificGasD / 9.80665) * t_p * lg) : lapse * d_rcp(t_p * em1);
   const double q = p + d;
-  const bool below = (j >= 0) && (j == 0 ? q > w.pb : q > w.pt);     // q in the layer with higher pressure
-  const bool above = (j <= 0) && (j == 0 ? !(q > w.pt) : !(q > w.pb));
+  // cur_hi / cur_lo: the transition pressures that bound the layer of p (+-inf if unknown/far)
+  const bool below = q > cur_hi;            // q in the layer with higher pressure
+  const bool above = !(q > cur_lo);
   if (__builtin_expect(below || above, 0)) {
     // transition that separates p and q, and the lapse rate on q's side
     const bool at_pb = (j == 0) ? below : (j < 0);
@@ -644,14 +646,25 @@ struct Ephemeris {
   double eot_min;    // degrees(equation_of_time): minutes of time (solar.py:107-115)
   float sin_decl, cos_decl;
   float flux;        // W/m^2
+  // time derivatives per second (analytic; the per-step change is <= 2e-3 deg so the
+  // linear term is exact to ~1e-9): d(eot_min)/dt, d(sin_decl)/dt, d(cos_decl)/dt, d(flux)/dt
+  float eot_min_rate, sin_decl_rate, cos_decl_rate, flux_rate;
 };
 BLE_FN Ephemeris ephemeris(int64_t unix_s) {
   // solar.py:66-79.  julian_day_number + fraction_of_day == 2440587.5 + unix_s / 86400
   // (exact identity for the Gregorian formula at :71-75; verified against the oracle).
-  int64_t days = unix_s / 86400;
-  int64_t sod = unix_s - days * 86400;
-  if (sod < 0) { sod += 86400; days -= 1; }
-  const double julian_time = (2440587.5 + (double)days) + (double)sod * (1.0 / 86400.0);
+  double julian_time;
+  if (__builtin_expect(unix_s >= 0 && unix_s < 4294967296LL, 1)) {   // 1970 .. 2106: 32-bit arithmetic
+    const uint32_t t = (uint32_t)unix_s;
+    const uint32_t days = t / 86400u;
+    const uint32_t sod = t - days * 86400u;
+    julian_time = (2440587.5 + (double)days) + (double)sod * (1.0 / 86400.0);
+  } else {
+    int64_t days = unix_s / 86400;
+    int64_t sod = unix_s - days * 86400;
+    if (sod < 0) { sod += 86400; days -= 1; }
+    julian_time = (2440587.5 + (double)days) + (double)sod * (1.0 / 86400.0);
+  }
   const double jc = (julian_time - 2451545.0) * (1.0 / 36525.0);
   const float jcf = (float)jc;
   const double l0_deg = 280.46646 + jc * (36000.76983 + jc * 0.0003032);
@@ -662,9 +675,9 @@ BLE_FN Ephemeris ephemeris(int64_t unix_s) {
   sincos_deg(m0_deg, &sm, &cm);
   sincos_deg(om_deg, &so, &co);
   const float s2l = 2.0f * sl * cl, c2l = f_fma(cl, cl, -sl * sl);
-  const float s4l = 2.0f * s2l * c2l;
-  const float s2m = 2.0f * sm * cm;
-  const float s3m = sm * f_fma(-4.0f * sm, sm, 3.0f);
+  const float s4l = 2.0f * s2l * c2l, c4l = f_fma(c2l, c2l, -s2l * s2l);
+  const float s2m = 2.0f * sm * cm, c2m = f_fma(cm, cm, -sm * sm);
+  const float s3m = sm * f_fma(-4.0f * sm, sm, 3.0f), c3m = cm * f_fma(4.0f * cm, cm, -3.0f);
   const float mean_obl = 23.0f + (26.0f + ((21.448f - jcf * (46.815f + jcf * (0.00059f - jcf * 0.001813f)))) * (1.0f / 60.0f)) * (1.0f / 60.0f);
   float sobl, cobl;
   sincos_deg((double)(mean_obl + 0.00256f * co), &sobl, &cobl);
@@ -682,7 +695,20 @@ BLE_FN Ephemeris ephemeris(int64_t unix_s) {
   e.sin_decl = sobl * sa;
   e.cos_decl = f_sqrt(f_fma(-e.sin_decl, e.sin_decl, 1.0f));
   const float r = (1.0f + ecc) * f_rcp(1.0f - ecc);
-  e.flux = 1366.0f * f_fma(0.5f * f_fma(r, r, -1.0f), cm, 1.0f);
+  const float half_r2m1 = 0.5f * f_fma(r, r, -1.0f);
+  e.flux = 1366.0f * f_fma(half_r2m1, cm, 1.0f);
+  // rates: L0' and M' in rad/s (the obliquity, eccentricity and nutation terms move < 1e-9 deg per step)
+  const float per_s = (float)(kPiD / 180.0 / (36525.0 * 86400.0));
+  const float lp = (36000.76983f + 0.0006064f * jcf) * per_s;
+  const float mp = (35999.05029f - 0.0003074f * jcf) * per_s;
+  const float eot_rate = 4.0f * (2.0f * var_y * c2l * lp - 2.0f * ecc * cm * mp +
+                                 4.0f * ecc * var_y * (cm * c2l * mp - 2.0f * sm * s2l * lp) -
+                                 2.0f * var_y * var_y * c4l * lp - 2.5f * ecc * ecc * c2m * mp);
+  e.eot_min_rate = eot_rate * kRadToDeg;
+  const float eoc_rate = kDegToRad * mp * (cm * (1.914602f - jcf * 0.004817f) + 2.0f * c2m * 0.019993f + 3.0f * c3m * 0.000289f);
+  e.sin_decl_rate = sobl * ca * (lp + eoc_rate);
+  e.cos_decl_rate = -e.sin_decl * e.sin_decl_rate * f_rcp(e.cos_decl);
+  e.flux_rate = -1366.0f * half_r2m1 * sm * mp;
   return e;
 }
 
@@ -692,12 +718,13 @@ BLE_FN Ephemeris ephemeris(int64_t unix_s) {
 //   heading = atan2(x, y)            -> cos/sin(heading) = y/d, x/d
 //   d_lng   = atan2(yy, xx)          -> cos/sin(B + d_lng) by rotating (cos B, sin B)
 //   hour_angle = (B + d_lng) -+ 180  -> cos(hour_angle) = -cos(B + d_lng)   (solar.py:113-120)
-// b_deg = 360 frac_day + eot/4 + lng0 [deg].
+// (sin_b, cos_b) of b = 360 frac_day + eot/4 + lng0 [deg]; the three nodes of a step share
+// one sincos and rotate by the half-step angle.
 // Within one agent step x, y move linearly (constant wind) and the ephemeris is linear,
 // so S(t) is smooth: agent_step evaluates this at 3 nodes and interpolates quadratically
 // (|error| <= |d3S/dt3| h^3 * 0.064 <= 1.8e-8, and ~0 around local noon where d3S/dt3 -> 0).
 struct SunSC { float sin_el, cos_el; };
-BLE_FN double sun_one_minus_sin_f64(double sin_lat0, double cos_lat0, double x, double y, double b_deg,
+BLE_FN double sun_one_minus_sin_f64(double sin_lat0, double cos_lat0, double x, double y, double sin_b, double cos_b,
                                     double sin_decl, double cos_decl) {
   const double d2 = x * x + y * y;
   const bool moved = d2 > 0.0;
@@ -715,8 +742,6 @@ BLE_FN double sun_one_minus_sin_f64(double sin_lat0, double cos_lat0, double x, 
   const double cos_lat = d_sqrt_fast(d_fma(-sin_lat, sin_lat, 1.0));
   const double yy = sin_a * cos_lat0 * sin_h;
   const double xx = cos_a - sin_lat0 * sin_lat;
-  double sin_b, cos_b;
-  sincos_f64(b_deg * (kPiD / 180.0), &sin_b, &cos_b);
   const double cos_bl = (cos_b * xx - sin_b * yy) * d_rsqrt(xx * xx + yy * yy);
   const double s = sin_lat * sin_decl - cos_lat * cos_decl * cos_bl;
   return 1.0 - s;
@@ -755,9 +780,9 @@ BLE_FN SunSC sun_refract(SunSC unc) {
 
 constexpr float kSinMinSolarEl = -0.07396924496f;  // sin(-4.242 deg), solar.py:38
 
-// solar_atmospheric_attenuation (solar.py:177-209) from sin(el).  Branch-free.
-BLE_FN float solar_attenuation(float sin_el, float pressure, uint32_t* flags) {
-  *flags |= (pressure > 101325.0f || pressure < 0.0f) ? kFlagSolarRange : 0u;
+// solar_atmospheric_attenuation (solar.py:177-209) from sin(el).  Branch-free.  The
+// reference's pressure range check (:194-197) is done by the caller once per agent step.
+BLE_FN float solar_attenuation(float sin_el, float pressure) {
   const float t = 614.0f * sin_el;
   const float root = f_sqrt(f_fma(t, t, 1229.0f));
   // sqrt(1229 + t^2) - t, written without cancellation for t > 0

@@ -44,13 +44,16 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
                       float noise_u, float noise_v, int substeps, const float* acs_table, float* reward,
                       uint32_t* flags) {
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
+  const float p0_in = s.p;
   double p = (double)s.p;
   const AtmWindow win = atm_window((double)c.alpha, p, flags);
   double altitude, t_at_p;
   atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
   int lay = 0;                                   // p is in the window's centre layer by construction
   const double lapse_m1 = win.lapse_m1, lapse_c0 = win.lapse_0, lapse_p1 = win.lapse_p1;
+  const double kInf = (double)__builtin_huge_valf();
   double lapse_cur = lapse_c0;                   // lapse rate of the layer holding p
+  double cur_hi = win.pb, cur_lo = win.pt;       // transition pressures bounding that layer
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
 #if BLE_ABLATE & 16
@@ -64,13 +67,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   // ---- per-step constants
   const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
   const Ephemeris e0 = ephemeris(t0);
-#if BLE_ABLATE & 1
-  const Ephemeris e1 = e0;
-#else
-  const Ephemeris e1 = ephemeris(t0 + (int64_t)(10 * substeps));
-#endif
-  const double inv_n = 1.0 / (double)substeps;
-  const float fl0 = e0.flux, dfl = (e1.flux - e0.flux) * (float)inv_n;
+  const float step_s = (float)(10 * substeps);
+  const float fl0 = e0.flux, dfl = e0.flux_rate * 10.0f;
   float u, v;
   wind_blend_corners(corners, wq, &u, &v);         // wind at the PRE-step position/time
   u += noise_u; v += noise_v;                      // WindField.get_ground_truth = forecast + noise
@@ -78,22 +76,32 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
   float oms_c0, oms_c1, oms_c2;
   {
-    int64_t sod = t0 % 86400;
-    if (sod < 0) sod += 86400;
     // hour-angle base B = 360 frac_day + eot/4 + lng0  [deg]  (solar.py:113-116)
-    const double b0 = (double)sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)c.lng0_deg;
-    const double b2 = b0 + (double)substeps * (10.0 / 240.0) + 0.25 * (e1.eot_min - e0.eot_min);
+    double sod;
+    if (__builtin_expect(t0 >= 0 && t0 < 4294967296LL, 1)) sod = (double)((uint32_t)t0 % 86400u);
+    else { int64_t m = t0 % 86400; sod = (double)(m < 0 ? m + 86400 : m); }
+    const double b0 = sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)c.lng0_deg;
+    const double half_db = 0.5 * ((double)step_s * (1.0 / 240.0) + 0.25 * (double)(e0.eot_min_rate * step_s));  // deg
+    double sb0, cb0;
+    sincos_f64(b0 * (kPiD / 180.0), &sb0, &cb0);
+    // rotate by the half-step angle (0.375 deg): Taylor
+    const double hr = half_db * (kPiD / 180.0), h2 = hr * hr;
+    const double sh = hr * d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double ch = d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    const double sb1 = sb0 * ch + cb0 * sh, cb1 = cb0 * ch - sb0 * sh;
+    const double sb2 = sb1 * ch + cb1 * sh, cb2 = cb1 * ch - sb1 * sh;
     double sl0, cl0;
     sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &sl0, &cl0);
     const double x0 = (double)s.x, y0 = (double)s.y;
     const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-    const double sd0 = (double)e0.sin_decl, cd0 = (double)e0.cos_decl, sd1 = (double)e1.sin_decl, cd1 = (double)e1.cos_decl;
+    const double sd0 = (double)e0.sin_decl, cd0 = (double)e0.cos_decl;
+    const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = 0.5 * (double)(e0.cos_decl_rate * step_s);
 #if BLE_ABLATE & 2
-    const double f0 = 0.3 + 1e-9 * x0, f1 = 0.31 + 1e-9 * dx, f2 = 0.32 + 1e-9 * b2 + sl0 * 0 + cl0 * 0 + sd0 * 0 + cd0 * 0 + sd1 * 0 + cd1 * 0 + y0 * 0 + dy * 0;
+    const double f0 = 0.3 + 1e-9 * x0, f1 = 0.31 + 1e-9 * dx, f2 = 0.32 + sl0 * 0 + cl0 * 0 + sd0 * 0 + cd0 * 0 + hsd * 0 + hcd * 0 + y0 * 0 + dy * 0 + sb2 * 0 + cb2 * 0;
 #else
-    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, b0, sd0, cd0);
-    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, 0.5 * (b0 + b2), 0.5 * (sd0 + sd1), 0.5 * (cd0 + cd1));
-    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, b2, sd1, cd1);
+    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, sb0, cb0, sd0, cd0);
+    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, sb1, cb1, sd0 + hsd, cd0 + hcd);
+    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, sb2, cb2, sd0 + 2.0 * hsd, cd0 + 2.0 * hcd);
 #endif
     const double m = 0.5 * (double)substeps;
     oms_c0 = (float)f0;
@@ -135,11 +143,11 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
     const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * (dir * num) * rp * (yc * yc);
     const double dh_dt = arg > 0.0 ? d_sqrt_fast(arg) : 0.0;
-    const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, p, rp, dir, t_at_p);
+    const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, cur_hi, cur_lo, p, rp, dir, t_at_p);
     const double p_new = d_fma(inv_dh * dh_dt, 10.0, p);                    // dir * dir == 1
 
     // ---- step 3: temperatures (balloon.py:451-467)
-    const float att = solar_attenuation(sun.sin_el, pf, flags);
+    const float att = solar_attenuation(sun.sin_el, pf);
     const float dtdt = thermal_dtdt(v23, t_intf, t_ambf, rho, flux * att, q_earth, flags);
     const double t_int_new = t_int + (double)(dtdt * kStride);
 
@@ -174,18 +182,22 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
     y = f_fma(v, kStride, y);
     t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
-    // T(p_new) for the next substep: advance inside the layer, or re-anchor at the boundary
-    // that was crossed (no transcendental either way; see AtmWindow)
+    // T(p_new) for the next substep: advance inside the layer; if a transition was crossed
+    // (cold branch) re-anchor at it first -- no transcendental either way (see AtmWindow)
     {
-      const int lay_new = atm_window_layer(win, p_new);
-      const bool same = lay_new == lay;
-      const bool low_pair = (lay + lay_new) < 0;            // crossing pb (else pt)
-      const double anchor_p = same ? p : (low_pair ? win.pb : win.pt);
-      const double anchor_rp = same ? rp : (low_pair ? win.r_pb : win.r_pt);
-      const double anchor_t = same ? t_at_p : (low_pair ? win.tb : win.tt);
-      const double lapse_new = pick3(lay_new, lapse_m1, lapse_c0, lapse_p1);
-      t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_new);
-      lay = lay_new; lapse_cur = lapse_new;
+      double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
+      if (__builtin_expect(p_new > cur_hi || !(p_new > cur_lo), 0)) {
+        const int lay_new = atm_window_layer(win, p_new);
+        const bool low_pair = (lay + lay_new) < 0;            // crossing pb (else pt)
+        anchor_p = low_pair ? win.pb : win.pt;
+        anchor_rp = low_pair ? win.r_pb : win.r_pt;
+        anchor_t = low_pair ? win.tb : win.tt;
+        lay = lay_new;
+        lapse_cur = pick3(lay_new, lapse_m1, lapse_c0, lapse_p1);
+        cur_hi = lay_new < 0 ? kInf : (lay_new == 0 ? win.pb : win.pt);
+        cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
+      }
+      t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_cur);
     }
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (status != kOk) { ++k; break; }     // balloon.py:327-328
@@ -197,12 +209,15 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   s.t_elapsed += 10 * k;
   s.status = (uint8_t)status;
 
+  // solar_atmospheric_attenuation's range check (solar.py:194-197); p moves < 3 kPa per step
+  *flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
+
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
   float r = reward_distance(s.x, s.y);
   if (action == kDown && !(BLE_ABLATE & 8)) {   // last_command is the RAW action (balloon.py:286)
     const float fk = (float)k;
     const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
-    const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p, flags));
+    const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p));
     const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
     if (!excess) {
       const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);

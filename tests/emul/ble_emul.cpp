@@ -55,7 +55,8 @@ extern "C" void emul_solar(int64_t n, const float* lat0, const float* lng0, cons
     int64_t sod = t[i] % 86400; if (sod < 0) sod += 86400;
     double b = (double)sod / 240.0 + 0.25 * e.eot_min + (double)lng0[i];
     double sl, cl; sincos_f64((double)lat0[i] * (kPiD / 180.0), &sl, &cl);
-    double oms = sun_one_minus_sin_f64(sl, cl, x[i], y[i], b, (double)e.sin_decl, (double)e.cos_decl);
+    double sb, cb; sincos_f64(b * (kPiD / 180.0), &sb, &cb);
+    double oms = sun_one_minus_sin_f64(sl, cl, x[i], y[i], sb, cb, (double)e.sin_decl, (double)e.cos_decl);
     SunSC sun = sun_refract(sun_from_one_minus_sin((float)oms));
     el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
     flux[i] = e.flux;
@@ -66,7 +67,7 @@ extern "C" void emul_solar_power(int64_t n, const float* el_deg, const float* p,
   for (int64_t i = 0; i < n; ++i) {
     double s, c; sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
     uint32_t fl = 0;
-    att[i] = solar_attenuation((float)s, p[i], &fl);
+    att[i] = solar_attenuation((float)s, p[i]);
     power[i] = solar_power((float)s, (float)c, att[i]);
   }
 }
@@ -74,4 +75,5 @@ extern "C" void emul_solar_power(int64_t n, const float* el_deg, const float* p,
 extern "C" void emul_ephemeris(int64_t t, double* out4) {
   Ephemeris e = ephemeris(t);
   out4[0] = e.eot_min; out4[1] = e.sin_decl; out4[2] = e.cos_decl; out4[3] = e.flux;
+  out4[4] = e.eot_min_rate; out4[5] = e.sin_decl_rate; out4[6] = e.cos_decl_rate; out4[7] = e.flux_rate;
 }
