@@ -28,6 +28,12 @@ __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags
   }
 }
 
+// `n_steps` consecutive agent steps of the rank's environments in ONE launch: the state is
+// loaded once, stays in registers across the steps and is stored once; per step only the
+// action byte is read, the 16 wind-grid corners are gathered and reward / terminal are
+// written.  n_steps == 1 is the plain BalloonArena.step; n_steps > 1 serves ble_step_n_f32
+// (rollouts whose actions are known up front, e.g. the random policy of the headline config).
+// action / reward / terminal are [n_steps][n]; active_count is [n_steps][BLE_COUNT_SLOTS].
 __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
                                                           int64_t grid_env_stride,
@@ -36,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
                                                           uint8_t* __restrict__ terminal,
                                                           uint8_t* __restrict__ effective_action,
                                                           uint32_t* err_flags, unsigned long long* active_count,
-                                                          int64_t n, int substeps, int lanes) {
+                                                          int64_t n, int substeps, int lanes, int n_steps) {
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   __shared__ float acs_table[4 * 13];
@@ -44,61 +50,68 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
   const bool in_range = i < n && (int)threadIdx.x < lanes;
-  bool live = false;
   uint32_t flags = 0;
+  EnvRegs s;
+  EnvConst c;
+  bool live = false;
   if (in_range) {
-    const uint8_t status = st.status[i];
-    live = status == kOk;
-    if (!live) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
-      reward[i] = 0.0f;
-      terminal[i] = 1;
-      if (effective_action) effective_action[i] = action[i];
-    }
-  }
-  if (live) {
-    EnvRegs s;
+    // every load is issued up front, unconditionally (one memory round trip)
+    s.status = st.status[i];
     s.x = st.x[i]; s.y = st.y[i]; s.p = st.pressure[i]; s.t_amb = st.ambient_temperature[i];
     s.t_int = st.internal_temperature[i]; s.vol = st.envelope_volume[i]; s.sp = st.superpressure[i];
     s.n_air = st.mols_air[i]; s.batt = st.battery_charge[i];
     s.acs_power = 0.0f; s.mdot = 0.0f; s.charge = 0.0f; s.load = 0.0f;
     s.t_elapsed = st.time_elapsed_s[i]; s.sunrise_h = st.sunrise_h_rel[i]; s.sunset = st.sunset_rel[i];
-    s.status = kOk; s.alt_fsm = st.alt_fsm[i]; s.env_fsm = st.env_fsm[i]; s.paused = st.power_paused[i];
-    EnvConst c;
+    s.alt_fsm = st.alt_fsm[i]; s.env_fsm = st.env_fsm[i]; s.paused = st.power_paused[i];
     c.lat0_deg = st.center_lat_deg[i]; c.lng0_deg = st.center_lng_deg[i];
     c.ir = st.upwelling_infrared[i]; c.alpha = st.alpha[i]; c.start_unix = st.start_unix[i];
-    const int act = action[i];
-
-    // wind at the PRE-step position/time (balloon_arena.py:194,270-275): gather now, blend later
-    const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
-    WindCorners corners;
-    wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
-    float nu = 0.0f, nv = 0.0f;
-    if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
-
-    float r;
-    const int eff = agent_step(s, c, act, corners, wq, nu, nv, substeps, acs_table, &r, &flags);
-
-    if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
-      flags |= kFlagNonFinite;
-
+    live = s.status == kOk;
+  }
+  const bool was_live = live;
+  int last_act = 0;
+#pragma unroll 1
+  for (int k = 0; k < n_steps; ++k) {
+    const int64_t o = (int64_t)k * n + i;
+    if (live) {
+      const int act = action[o];
+      last_act = act;
+      // wind at the PRE-step position/time (balloon_arena.py:194,270-275): gather now, blend later
+      const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+      WindCorners corners;
+      wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
+      float nu = 0.0f, nv = 0.0f;
+      if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
+      float r;
+      const int eff = agent_step(s, c, act, corners, wq, nu, nv, substeps, acs_table, &r, &flags);
+      if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
+        flags |= kFlagNonFinite;
+      reward[o] = r;
+      terminal[o] = s.status != kOk;
+      if (effective_action) effective_action[o] = (uint8_t)eff;
+    } else if (in_range) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
+      reward[o] = 0.0f;
+      terminal[o] = 1;
+      if (effective_action) effective_action[o] = action[o];
+    }
+    // live-environment count: one atomic per wave, spread over BLE_COUNT_SLOTS addresses and
+    // issued after the step so that no load of this wave queues behind it
+    if (active_count) {
+      const unsigned long long m = __ballot(live);
+      if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(active_count + (int64_t)k * BLE_COUNT_SLOTS + (blockIdx.x & (BLE_COUNT_SLOTS - 1)),
+                  (unsigned long long)__popcll(m));
+    }
+    live = live && s.status == kOk;
+  }
+  if (was_live) {
     st.x[i] = s.x; st.y[i] = s.y; st.pressure[i] = s.p; st.ambient_temperature[i] = s.t_amb;
     st.internal_temperature[i] = s.t_int; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp;
     st.mols_air[i] = s.n_air; st.battery_charge[i] = s.batt;
     st.acs_power[i] = s.acs_power; st.acs_mass_flow[i] = s.mdot; st.solar_charging[i] = s.charge;
     st.power_load[i] = s.load;
     st.time_elapsed_s[i] = s.t_elapsed; st.sunrise_h_rel[i] = s.sunrise_h; st.sunset_rel[i] = s.sunset;
-    st.status[i] = s.status; st.last_command[i] = (uint8_t)act;
+    st.status[i] = s.status; st.last_command[i] = (uint8_t)last_act;
     st.alt_fsm[i] = s.alt_fsm; st.env_fsm[i] = s.env_fsm; st.power_paused[i] = s.paused;
-    reward[i] = r;
-    terminal[i] = s.status != kOk;
-    if (effective_action) effective_action[i] = (uint8_t)eff;
-  }
-  // live-environment count: one atomic per wave, spread over BLE_COUNT_SLOTS addresses and
-  // issued last so that no load of this wave queues behind it
-  if (active_count) {
-    const unsigned long long m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m)
-      atomicAdd(active_count + (blockIdx.x & (BLE_COUNT_SLOTS - 1)), (unsigned long long)__popcll(m));
   }
   report_flags(flags, err_flags);
 }
@@ -305,7 +318,7 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
   const int lanes = env_lanes();
   hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
-                     active_count, n, substeps, lanes);
+                     active_count, n, substeps, lanes, 1);
   return launch_status();
 }
 
@@ -316,13 +329,11 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
+  if (n_steps == 0) return BLE_OK;
   const int lanes = env_lanes();
-  for (int k = 0; k < n_steps; ++k) {
-    hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st,
-                       action + (int64_t)k * n, wind_grid, grid_env_stride, (const float*)nullptr,
-                       reward + (int64_t)k * n, terminal + (int64_t)k * n, (uint8_t*)nullptr, err_flags,
-                       active_count ? active_count + (int64_t)k * BLE_COUNT_SLOTS : nullptr, n, substeps, lanes);
-  }
+  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+                     wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
+                     active_count, n, substeps, lanes, n_steps);
   return launch_status();
 }
 

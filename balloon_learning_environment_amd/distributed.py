@@ -4,7 +4,7 @@ Environments are independent (no cross-env term anywhere in the transition), so 
 index range is partitioned contiguously across ranks and the per-step data path needs no
 collective.  Exactly two exchanges exist:
   * the decoded wind grid (317 520 B) is broadcast from rank 0 once per episode batch;
-  * rewards / terminals are gathered back to every rank (all_gather) every
+  * rewards / terminals are gathered back to rank 0 (point-to-point `gather`) every
     `gather_every` agent steps, on a side stream so that it overlaps the next steps.
 The helpers are device-agnostic so that the N>1 logic is covered by gloo tests on CPU.
 """
@@ -29,18 +29,32 @@ def broadcast_grid(grid: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 
 class OutputGatherer:
-  """Gathers [K, n_local] reward / terminal blocks from all ranks into [world, K, n_local].
+  """Collects [K, n_local] reward / terminal blocks of every rank on rank `dst`.
 
-  With equal shard sizes (the bench and the tests) this is one all_gather_into_tensor per
-  dtype; it is issued on `stream` (a side stream on GPU) after waiting for the producer.
+  `dist.gather` (point-to-point sends over the direct xGMI links; 5 B per env-step per
+  sender), not all_gather: a ring all_gather would push world x the volume through every
+  single link, and only the learner rank consumes the data.  Issued on a side stream after
+  waiting for the producer so that it overlaps the following steps.
   """
 
-  def __init__(self, k: int, n_local: int, device, world: Optional[int] = None):
-    self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-    self.reward = torch.zeros((self.world, k, n_local), dtype=torch.float32, device=device)
-    self.terminal = torch.zeros((self.world, k, n_local), dtype=torch.uint8, device=device)
+  def __init__(self, k: int, n_local: int, device, world: Optional[int] = None, dst: int = 0):
+    initialized = dist.is_available() and dist.is_initialized()
+    self.world = world if world is not None else (dist.get_world_size() if initialized else 1)
+    self.rank = dist.get_rank() if initialized else 0
+    self.dst = dst
+    self.is_dst = self.rank == dst
+    rows = self.world if self.is_dst else 0
+    self.reward = torch.zeros((rows, k, n_local), dtype=torch.float32, device=device)
+    self.terminal = torch.zeros((rows, k, n_local), dtype=torch.uint8, device=device)
     self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
-    self._pending: List = []
+
+  def _gather(self, reward_block, terminal_block):
+    if self.is_dst:
+      dist.gather(reward_block, [self.reward[r] for r in range(self.world)], dst=self.dst)
+      dist.gather(terminal_block, [self.terminal[r] for r in range(self.world)], dst=self.dst)
+    else:
+      dist.gather(reward_block, None, dst=self.dst)
+      dist.gather(terminal_block, None, dst=self.dst)
 
   def gather(self, reward_block: torch.Tensor, terminal_block: torch.Tensor) -> None:
     if self.world == 1:
@@ -49,12 +63,10 @@ class OutputGatherer:
     if self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream(reward_block.device))
       with torch.cuda.stream(self.stream):
-        dist.all_gather_into_tensor(self.reward.view(-1, self.reward.shape[-1]), reward_block)
-        dist.all_gather_into_tensor(self.terminal.view(-1, self.terminal.shape[-1]), terminal_block)
+        self._gather(reward_block, terminal_block)
         reward_block.record_stream(self.stream); terminal_block.record_stream(self.stream)
     else:
-      dist.all_gather_into_tensor(self.reward.view(-1, self.reward.shape[-1]), reward_block)
-      dist.all_gather_into_tensor(self.terminal.view(-1, self.terminal.shape[-1]), terminal_block)
+      self._gather(reward_block, terminal_block)
 
   def wait(self) -> None:
     if self.stream is not None:

@@ -10,9 +10,10 @@ random policy, one decoded wind grid shared by all environments (synthetic N(0, 
 float32 field, seed 0), initial conditions drawn like BalloonArena.reset
 (reset_host.sample_initial_state).  One "step" = one agent step (180 s = 18 x 10 s
 substeps + wind lookup + 3 safety layers + reward/terminal) of every environment of the
-rank = one launch of ble_step_kernel.  Weak scaling: per-GPU work is fixed; with N > 1 the
-grid is broadcast once over RCCL and rewards/terminals are all_gathered every 32 steps on
-a side stream (inside the timed region).  Terminated environments are frozen by the kernel
+rank; ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (the
+random policy's actions are known up front, so the state stays in registers between steps).  Weak scaling: per-GPU work is fixed; with N > 1 the
+grid is broadcast once over RCCL and rewards/terminals are gathered to rank 0 every 32
+steps on a side stream (inside the timed region).  Terminated environments are frozen by the kernel
 and are NOT counted: value = (sum over timed steps of live environments) / seconds.
 Prints ONE JSON line on rank 0.
 """
@@ -82,10 +83,15 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
   assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
+  dev_index = local_rank % torch.cuda.device_count()   # (== local_rank on a real multi-GPU node)
+  torch.cuda.set_device(dev_index)
+  device = torch.device('cuda', dev_index)
   if world > 1:
-    dist.init_process_group('nccl', device_id=device)   # RCCL
+    backend = os.environ.get('BLE_DIST_BACKEND', 'nccl')   # nccl = RCCL over xGMI; gloo only for single-GPU smoke tests
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=device)
+    else:
+      dist.init_process_group(backend)
 
   n = args.envs_per_gpu
   k_total = args.steps + args.warmup
@@ -146,8 +152,10 @@ def main():
   live_steps = float(live_per_step.sum().item())
   live_steps_all = bdist.sum_over_ranks(live_steps, device)
   value = live_steps_all / elapsed
-  kernel_ms = ev0.elapsed_time(ev1) / args.steps          # avg launch duration incl. inter-launch gaps
-  bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (live_steps / args.steps)
+  # one launch of ble_step_kernel = up to GATHER_EVERY consecutive agent steps (state kept in registers)
+  n_launches = -(-args.steps // GATHER_EVERY)
+  kernel_ms = ev0.elapsed_time(ev1) / n_launches         # avg launch duration incl. inter-launch gaps
+  bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (live_steps / n_launches)
   achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
   traffic = None
   pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -167,10 +175,11 @@ def main():
                                '(BASELINE.json configs[2]: 65 536 envs, 1xMI355X headline)',
                    'envs_per_gpu': n, 'global_envs': n * world, 'substeps_per_step': args.substeps,
                    'live_env_fraction_end': float(live_per_step[-1].item()) / n,
-                   'parallelism': f'env-sharded x{world}, grid broadcast once, reward/terminal all_gather every {GATHER_EVERY} steps'},
+                   'parallelism': f'env-sharded x{world}, grid broadcast once, reward/terminal gather to rank 0 every {GATHER_EVERY} steps'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'kernel': 'ble_step_kernel', 'kernel_ms': kernel_ms,
+                     'kernel': 'ble_step_kernel', 'kernel_ms': kernel_ms, 'agent_steps_per_launch': args.steps / n_launches,
+                     'kernel_us_per_agent_step': 1e3 * kernel_ms * n_launches / args.steps,
                      'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
                      'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)'},
     }

@@ -139,8 +139,9 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
                  int64_t n, int substeps, void* stream);
 
 /*
- * `n_steps` consecutive agent steps enqueued by one host call (no host round trip
- * between them).  action / reward / terminal are [n_steps][n] row-major;
+ * `n_steps` consecutive agent steps in ONE kernel launch: the state stays in registers
+ * between the steps (loaded once, stored once); per step only the action is read and
+ * reward / terminal are written.  action / reward / terminal are [n_steps][n] row-major;
  * active_count, if given, is [n_steps][BLE_COUNT_SLOTS].  Same semantics per step as
  * ble_step_f32.
  */

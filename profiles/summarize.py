@@ -76,7 +76,7 @@ def main(tag):
               open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
   json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'), 'w'), indent=1)
   with open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.md'), 'w') as f:
-    f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 100 --warmup 10` ({tag})\n\n')
+    f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 192 --warmup 32` (one launch = 32 agent steps) ({tag})\n\n')
     f.write('\n'.join(md) + '\n\n')
     f.write('## ble_step_kernel PMC (per launch averages; separate --pmc passes)\n\n```json\n')
     f.write(json.dumps({k: out[k] for k in ('dispatch', 'derived', 'hbm') if k in out}, indent=1))

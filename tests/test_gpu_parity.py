@@ -494,3 +494,33 @@ def test_fp64_primitives_on_device(ble):
   assert rel(run(6, t), np.exp(t)).max() < 2e-15
   a = rng.uniform(-200, 200, 8000)
   assert np.abs(run(7, a) - np.sin(a)).max() < 3e-16 and np.abs(run(8, a) - np.cos(a)).max() < 3e-16
+
+
+def test_fused_rollout_equals_single_steps(ble):
+  """ble_step_n_f32 (K steps in one launch, state in registers) == K x ble_step_f32, bit for bit."""
+  from balloon_learning_environment_amd import reset_host
+  n, k = 4096, 7
+  init = reset_host.sample_initial_state(n, seed=5)
+  # make a few environments terminate inside the rollout
+  init['battery_charge'][:64] = 0.2
+  field = (np.random.default_rng(1).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(2).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  a = ble.VecSimulator(n); a.set_state(init); a.set_grid(field)
+  b = ble.VecSimulator(n); b.set_state(init); b.set_grid(field)
+  rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
+  cnt = torch.zeros((k, ble.COUNT_SLOTS), dtype=torch.int64).cuda()
+  a.step_n(acts, rew, term, cnt)
+  rb, tb = [], []
+  for j in range(k):
+    r, t = b.step(acts[j].contiguous())
+    rb.append(r.clone()); tb.append(t.clone())
+  torch.cuda.synchronize()
+  sa, sb = a.get_state(), b.get_state()
+  for name in sa:
+    np.testing.assert_array_equal(sa[name], sb[name], err_msg=name)
+  np.testing.assert_array_equal(rew.cpu().numpy(), torch.stack(rb).cpu().numpy())
+  np.testing.assert_array_equal(term.cpu().numpy(), torch.stack(tb).cpu().numpy())
+  assert (sa['status'] != 0).sum() > 0
+  live_per_step = cnt.sum(dim=1).cpu().numpy()
+  expect = np.concatenate([[n], n - torch.stack(tb).cpu().numpy()[:-1].sum(axis=1)])
+  np.testing.assert_array_equal(live_per_step, expect)
