@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "../../include/ble_abi.h"
+#include "ble_reset.h"
 #include "ble_step_core.h"
 
 using namespace ble;
@@ -257,6 +258,72 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
 }
 
+// Episode reset for the lanes selected by `mask` (all lanes if mask == nullptr).
+// sample != 0: draw the initial conditions (utils/sampling.py, balloon_arena.py:228-268) from
+// Philox(seed, env, episode[i]); sample == 0: keep x, y, pressure, centre lat/lng, IR, alpha,
+// start_unix as they are.  Then the Newton cold start (stable_init.py:132-157), the sunrise /
+// sunset search of PowerSafetyLayer.__init__ and fresh clocks / FSMs / battery (balloon.py:175-215).
+__global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, const uint8_t* __restrict__ mask,
+                                                           unsigned long long seed, uint32_t* episode, int sample,
+                                                           uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n && (mask == nullptr || mask[i] != 0)) {
+    float alpha, x, y, p, lat0, lng0, ir;
+    int64_t start;
+    if (sample) {
+      const uint32_t ep = episode ? episode[i] : 0u;
+      if (episode) episode[i] = ep + 1u;
+      Philox g = philox_init(seed, (uint64_t)i, ep);
+      alpha = (float)philox_uniform(g);                                                  // standard_atmosphere.py:82
+      start = 1293840000LL + (int64_t)(philox_uniform(g) * (double)(1419984000LL - 1293840000LL));   // sampling.py:65-83
+      const double ga = philox_gamma(g, 1.2), gb = philox_gamma(g, 2.0);                // Beta(1.2, 2.0)
+      const double radius = 200000.0 * (ga / (ga + gb));                                // balloon_arena.py:153-154,246-247
+      double sn, cs;
+      sincos_f64(2.0 * kPiD * philox_uniform(g), &sn, &cs);
+      x = (float)(cs * radius); y = (float)(sn * radius);
+      lat0 = (float)(-10.0 + 20.0 * philox_uniform(g));                                 // sampling.py:37-62
+      lng0 = (float)(-175.0 + 350.0 * philox_uniform(g));
+      // pressure ~ U[6500, P(50 000 ft)]  (sampling.py:86-117; at_height standard_atmosphere.py:89-120, layer 0)
+      const double l0 = atm_lapse_f64(0, (double)alpha);
+      const double t_h = 300.0 + l0 * (15240.0 - -610.0);
+      const double p_max = 108870.8213 * d_pow_fast(t_h / 300.0, -9.80665 / (kAirSpecificGasD * l0));
+      p = (float)(6500.0 + (p_max - 6500.0) * philox_uniform(g));
+      // upwelling IR: 315 * sigmoid(N(2, 315)), rejected below 225 (sampling.py:120-152, as written)
+      double irs = 315.0;
+#pragma unroll 1
+      for (int it = 0; it < 64; ++it) {
+        const double z = 2.0 + 315.0 * philox_normal(g);
+        irs = z > 700.0 ? 315.0 : (z < -700.0 ? 0.0 : 315.0 / (1.0 + d_exp_fast(-z)));
+        if (irs >= 225.0) break;
+      }
+      ir = (float)irs;
+      const_cast<float*>(st.alpha)[i] = alpha; st.x[i] = x; st.y[i] = y; st.pressure[i] = p;
+      const_cast<float*>(st.center_lat_deg)[i] = lat0; const_cast<float*>(st.center_lng_deg)[i] = lng0;
+      const_cast<float*>(st.upwelling_infrared)[i] = ir; const_cast<int64_t*>(st.start_unix)[i] = start;
+    } else {
+      alpha = st.alpha[i]; x = st.x[i]; y = st.y[i]; p = st.pressure[i]; lat0 = st.center_lat_deg[i];
+      lng0 = st.center_lng_deg[i]; ir = st.upwelling_infrared[i]; start = st.start_unix[i];
+    }
+    SunSite site;
+    latlng_f64((double)lat0, (double)lng0, (double)x, (double)y, &site.sin_lat, &site.cos_lat, &site.lng_deg);
+    double flux;
+    const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, start, &flux);
+    const StableParams sp = stable_params((double)alpha, (double)p, el, flux, (double)ir, &flags);
+    int64_t sunrise, sunset;
+    next_sunrise_sunset(site, start, &sunrise, &sunset);
+    st.ambient_temperature[i] = (float)sp.t_amb; st.internal_temperature[i] = (float)sp.t_int;
+    st.mols_air[i] = (float)sp.mols_air; st.envelope_volume[i] = (float)sp.volume; st.superpressure[i] = (float)sp.sp;
+    st.battery_charge[i] = 2905.6f;                                                      // balloon.py:195
+    st.acs_power[i] = 0.0f; st.acs_mass_flow[i] = 0.0f; st.solar_charging[i] = 0.0f; st.power_load[i] = 0.0f;
+    st.time_elapsed_s[i] = 0;
+    st.sunrise_h_rel[i] = (int32_t)(sunrise + 1800 - start);                             // power_safety.py:43-48
+    st.sunset_rel[i] = (int32_t)(sunset - start);
+    st.status[i] = kOk; st.last_command[i] = kStay; st.alt_fsm[i] = 0; st.env_fsm[i] = 0; st.power_paused[i] = 0;
+  }
+  report_flags(flags, err_flags);
+}
+
 }  // namespace
 // fp64 primitive probe (test-only entry point): op 0 rcp seed, 1 d_rcp, 2 rsq seed, 3 d_rsqrt,
 // 4 d_sqrt_fast, 5 d_log_fast, 6 d_exp_fast, 7 sin (sincos_f64), 8 cos (sincos_f64)
@@ -413,6 +480,15 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
   if (n == 0) return BLE_OK;
   hipLaunchKernelGGL(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
                      pressure, volume, superpressure, n);
+  return launch_status();
+}
+
+int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,
+                  int sample, uint32_t* err_flags, int64_t n, void* stream) {
+  if (!state_ok(st) || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  hipLaunchKernelGGL(ble_reset_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, mask, seed,
+                     episode, sample, err_flags, n);
   return launch_status();
 }
 

@@ -1,0 +1,271 @@
+// ble_reset.h -- per-lane episode reset, fp64, one lane per environment.
+//
+// Device counterpart of BalloonArena.reset / _initialize_balloon
+// (env/balloon_arena.py:161-182,228-268):
+//   * draws of the initial conditions (utils/sampling.py:37-152) from a counter-based
+//     Philox4x32-10 stream keyed by (seed, environment, episode) -- the reference draws from
+//     JAX threefry (absent, parity unpinned), so only the DISTRIBUTIONS match;
+//   * the Newton cold start (env/balloon/stable_init.py:40-157);
+//   * PowerSafetyLayer.__init__'s sunrise / sunset search
+//     (env/balloon/power_safety.py:40-41 -> env/balloon/solar.py:239-483).
+// The deterministic part (cold start, sunrise search) is parity-tested against the oracle:
+// the search compares elevations of neighbouring 3-minute samples near the solar
+// extremum, where they differ by ~1e-5 deg, so the solar calculator here is full fp64
+// (the mixed-precision one of the transition kernel is not good enough for it).
+// Runs once per episode (960 agent steps), off the hot path.
+#pragma once
+#include "ble_physics.h"
+
+namespace ble {
+
+// ---------------------------------------------------------------- fp64 asin (fdlibm e_asin.c rational form)
+BLE_FN double d_asin(double x) {
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+               pio4_hi = 7.85398163397448278999e-01;
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  const double ax = fabs(x);
+  if (ax < 0.5) {
+    const double t = x * x;
+    const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+    const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+    return x + x * (p / q);
+  }
+  const double w = 1.0 - ax;
+  const double t = w * 0.5;
+  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+  const double s = sqrt(t);
+  const double r = p / q;
+  double res;
+  if (ax >= 0.975) {
+    res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
+  } else {
+    // split s into a head with 32 zero low bits (fdlibm) to keep the subtraction exact
+    union { double d; uint64_t u; } cv;
+    cv.d = s; cv.u &= 0xffffffff00000000ULL;
+    const double df = cv.d;
+    const double c = (t - df * df) / (s + df);
+    const double pp = 2.0 * s * r - (pio2_lo - 2.0 * c);
+    const double qq = pio4_hi - 2.0 * df;
+    res = pio4_hi - (pp - qq);
+  }
+  return x > 0 ? res : -res;
+}
+
+// ---------------------------------------------------------------- full fp64 solar calculator
+// solar.solar_calculator (solar.py:43-174): elevation [deg] (refraction corrected) and flux.
+BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
+  int64_t days = unix_s / 86400;
+  int64_t sod = unix_s - days * 86400;
+  if (sod < 0) { sod += 86400; days -= 1; }
+  const double frac = (double)sod / 86400.0;
+  const double jc = (((2440587.5 + (double)days) + frac) - 2451545.0) / 36525.0;
+  const double d2r = kPiD / 180.0;
+  const double l0 = d2r * (280.46646 + jc * (36000.76983 + jc * 0.0003032));
+  double s2l, c2l;
+  sincos_f64(2.0 * l0, &s2l, &c2l);
+  const double s4l = 2.0 * s2l * c2l;
+  const double m0 = d2r * (357.52911 + jc * (35999.05029 - 0.0001537 * jc));
+  double sm, cm;
+  sincos_f64(m0, &sm, &cm);
+  const double s2m = 2.0 * sm * cm, s3m = sm * (3.0 - 4.0 * sm * sm);
+  const double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
+  double so, co;
+  sincos_f64(d2r * (125.04 - 1934.136 * jc), &so, &co);
+  const double obl = mean_obl + d2r * (0.00256 * co);
+  double sobl, cobl;
+  sincos_f64(obl, &sobl, &cobl);
+  const double th = sobl / (1.0 + cobl), var_y = th * th;
+  const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
+  const double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
+                            1.25 * ecc * ecc * s2m);
+  // cos(hour_angle) = -cos(radians(1440 frac + degrees(eot) + 4 lng) / 4)   (solar.py:113-120)
+  double sh, ch;
+  sincos_f64(d2r * (360.0 * frac + 0.25 * (eot * (180.0 / kPiD)) + lng_deg), &sh, &ch);
+  const double eoc = d2r * (sm * (1.914602 - jc * (0.004817 + 0.000014 * jc)) + s2m * (0.019993 - 0.000101 * jc) + s3m * 0.000289);
+  double sa, ca;
+  sincos_f64(l0 + eoc - d2r * (0.00569 - 0.00478 * so), &sa, &ca);
+  const double sin_decl = sobl * sa;
+  const double cos_decl = sqrt(1.0 - sin_decl * sin_decl);
+  double s = sin_lat * sin_decl - cos_lat * cos_decl * ch;
+  s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
+  const double el = d_asin(s) * (180.0 / kPiD);      // 90 - degrees(acos(s))
+  const double c = sqrt(1.0 - s * s);
+  double refr;
+  if (el > 85.0) refr = 0.0;
+  else if (el > 5.0) { const double t = s / c; refr = 58.1 / t - 0.07 / (t * t * t) + 0.000086 / (t * t * t * t * t); }
+  else if (el > -0.575) refr = 1735.0 + el * (-518.2 + el * (103.4 + el * (-12.79 + el * 0.711)));
+  else refr = -20.772 / (s / c);
+  if (flux_out) { const double r = (1 + ecc) / (1 - ecc); *flux_out = 1366.0 * (1 + 0.5 * (r * r - 1) * cm); }
+  return el + refr / 3600.0;
+}
+
+// BalloonState.latlng (spherical_geometry.py:44-76) as (sin lat, cos lat, lng [deg]) in fp64.
+BLE_FN void latlng_f64(double lat0_deg, double lng0_deg, double x, double y, double* sin_lat, double* cos_lat,
+                       double* lng_deg) {
+  double sl0, cl0;
+  sincos_f64(lat0_deg * (kPiD / 180.0), &sl0, &cl0);
+  const double d = sqrt(x * x + y * y);
+  double cos_h = 1.0, sin_h = 0.0;
+  if (d > 0.0) { cos_h = y / d; sin_h = x / d; }
+  double sa, ca;
+  sincos_f64(d / 6371000.0, &sa, &ca);
+  const double sl = ca * sl0 + sa * cl0 * cos_h;
+  const double yy = sa * cl0 * sin_h, xx = ca - sl0 * sl;
+  // d_lng = atan2(yy, xx): |d_lng| < 0.2 rad here, xx > 0 -> asin of the normalised sine
+  const double d_lng = d_asin(yy / sqrt(xx * xx + yy * yy));
+  *sin_lat = sl; *cos_lat = sqrt(1.0 - sl * sl);
+  *lng_deg = lng0_deg + d_lng * (180.0 / kPiD);
+}
+
+// ---------------------------------------------------------------- sunrise / sunset search
+struct SunSite { double sin_lat, cos_lat, lng_deg; };
+BLE_FN double site_elevation(const SunSite& g, int64_t t) {
+  return solar_elevation_f64(g.sin_lat, g.cos_lat, g.lng_deg, t, nullptr);
+}
+// solar._find_solar_elevation_binary_search (solar.py:295-372); mode 0 min, 1 max, 2 |el - target|
+BLE_FN int64_t find_solar_elevation(const SunSite& g, int64_t min_t, int64_t max_t, int mode, double target) {
+  const int64_t dt = 180;
+  int64_t low = 0, high = (max_t - min_t) / dt;
+  auto obj = [&](int64_t idx) {
+    const double el = site_elevation(g, min_t + dt * idx);
+    return mode == 0 ? el : (mode == 1 ? -el : fabs(el - target));
+  };
+  double ol = obj(low), oh = obj(high);
+#pragma unroll 1
+  while (high > low + 1) {
+    const int64_t span = high - low;           // midpoint = low + span / 2.0
+    if (ol < oh) { high = low + (span + 1) / 2; oh = obj(high); }   // ceil
+    else { low = low + span / 2; ol = obj(low); }                   // floor
+  }
+  return min_t + dt * ((ol < oh) ? low : high);
+}
+// solar.get_next_sunrise_sunset (solar.py:432-483)
+BLE_FN void next_sunrise_sunset(const SunSite& g, int64_t t, int64_t* sunrise, int64_t* sunset) {
+  const int64_t h12 = 12 * 3600, h24 = 24 * 3600;
+  const bool afternoon = site_elevation(g, t + 1) < site_elevation(g, t);   // :239-256
+  const int64_t noon = afternoon ? find_solar_elevation(g, t + h12, t + h24, 1, 0.0)
+                                 : find_solar_elevation(g, t, t + h12, 1, 0.0);
+  const int64_t midnight = afternoon ? find_solar_elevation(g, t, t + h12, 0, 0.0)
+                                     : find_solar_elevation(g, t + h12, t + h24, 0, 0.0);
+  int64_t sr = find_solar_elevation(g, afternoon ? midnight : midnight - h24, noon, 2, -4.242);
+  int64_t ss = find_solar_elevation(g, afternoon ? noon - h24 : noon, midnight, 2, -4.242);
+  if (sr < t) sr += h24;
+  if (ss < t) ss += h24;
+  *sunrise = sr; *sunset = ss;
+}
+
+// ---------------------------------------------------------------- cold start (stable_init.py:40-129)
+BLE_FN double solar_attenuation_f64(double el_deg, double p) {   // solar.py:177-209
+  if (el_deg < -4.242) return 0.0;
+  double s, c;
+  sincos_f64(el_deg * (kPiD / 180.0), &s, &c);
+  const double t = 614.0 * s;
+  const double airmass = 0.34764 * (p / 101325.0) * (sqrt(1229.0 + t * t) - t);
+  return 0.5 * (d_exp_fast(-0.65 * airmass) + d_exp_fast(-0.95 * airmass));
+}
+BLE_FN double total_absorptivity_f64(double a) { return a * (1.0 + (1.0 - a - 0.0291) / (1.0 - 0.0291)); }
+BLE_FN double thermal_dtdt_f64(double volume, double t_int, double t_amb, double p, double att, double flux, double ir) {
+  const double sb = 0.000000056704;
+  const double radius = d_pow_fast(3 * volume / (4 * kPiD), 1.0 / 3);
+  const double area = 4 * kPiD * radius * radius;
+  const double q_solar = flux * att * 0.25 * area * total_absorptivity_f64(0.01435);
+  const double q_earth = ir * 0.4605 * area * total_absorptivity_f64(0.04587 + 0.000232 * (d_pow_fast(ir / sb, 0.25) - 210));
+  const double q_emit = sb * (t_int * t_int) * (t_int * t_int) * area * total_absorptivity_f64(0.04587 + 0.000232 * (t_int - 210));
+  const double visc = 1.458e-6 * (t_amb * sqrt(t_amb)) / (t_amb + 110.4);
+  const double cond = 0.0241 * d_pow_fast(t_amb / 273.15, 0.9);
+  const double prandtl = 0.804 - 3.25e-4 * t_amb;
+  const double rho = p * kAirMolarMassD / (kGasConstantD * t_amb);
+  const double dia = 2 * radius;
+  const double grashof = (9.80665 * rho * rho * dia * dia * dia / (t_amb * visc * visc)) * fabs(t_amb - t_int);
+  const double ra = prandtl * grashof;
+  const double nusselt = 2 + 0.457 * sqrt(sqrt(ra)) + d_pow_fast(1 + 2.69e-8 * ra, 1.0 / 12.0);
+  const double q_conv = area * (nusselt * cond / dia) * (t_amb - t_int);
+  return (q_solar + q_earth + q_conv - q_emit) / (1500 * 68.5);
+}
+struct StableParams { double t_amb, t_int, mols_air, volume, sp; };
+BLE_FN StableParams stable_params(double alpha, double p, double el_deg, double flux, double ir, uint32_t* flags) {
+  StableParams o;
+  const AtmWindow w = atm_window(alpha, p, flags);
+  double h;
+  atm_at_pressure_f64(w, alpha, p, &h, &o.t_amb);
+  double ma = ((p * kAirMolarMassD * 1804.0 / (kGasConstantD * o.t_amb) - 68.5 - 92.5 - kHeMolarMassD * 6830.0) /
+               kAirMolarMassD);
+  o.mols_air = ma > 0.0 ? ma : 0.0;
+  const double att = solar_attenuation_f64(el_deg, p);
+  double ti = 206.0;
+  const double delta = 0.01;
+#pragma unroll 1
+  for (int k = 0; k < 10; ++k) {
+    const double d1 = thermal_dtdt_f64(1804.0, ti - delta / 2, o.t_amb, p, att, flux, ir);
+    const double d2 = thermal_dtdt_f64(1804.0, ti + delta / 2, o.t_amb, p, att, flux, ir);
+    const double d2t = (d2 - d1) / delta;
+    const double mean = (d1 + d2) / 2.0;
+    if (fabs(d2t) > 0.0) ti -= mean / d2t;
+    if (fabs(mean) < 1e-5) break;
+  }
+  o.t_int = ti;
+  superpressure_volume_f64(o.mols_air, ti, p, 1.0 / p, &o.volume, &o.sp);
+  return o;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 + distributions
+struct Philox {
+  uint32_t key0, key1, c0, c1, c2, c3;
+  uint32_t out[4];
+  int have;
+};
+BLE_FN void philox_round(uint32_t* c, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+BLE_FN void philox_refill(Philox& g) {
+  uint32_t c[4] = {g.c0, g.c1, g.c2, g.c3};
+  uint32_t k0 = g.key0, k1 = g.key1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  g.out[0] = c[0]; g.out[1] = c[1]; g.out[2] = c[2]; g.out[3] = c[3];
+  g.have = 4;
+  if (++g.c0 == 0) ++g.c1;
+}
+BLE_FN Philox philox_init(uint64_t seed, uint64_t env, uint32_t episode) {
+  Philox g;
+  g.key0 = (uint32_t)seed; g.key1 = (uint32_t)(seed >> 32);
+  g.c0 = 0; g.c1 = episode; g.c2 = (uint32_t)env; g.c3 = (uint32_t)(env >> 32);
+  g.have = 0;
+  return g;
+}
+BLE_FN uint32_t philox_u32(Philox& g) {
+  if (g.have == 0) philox_refill(g);
+  return g.out[--g.have];
+}
+BLE_FN double philox_uniform(Philox& g) {   // [0, 1), 53 bits
+  const uint64_t hi = philox_u32(g), lo = philox_u32(g);
+  return (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+BLE_FN double philox_normal(Philox& g) {    // Box-Muller
+  const double u1 = 1.0 - philox_uniform(g), u2 = philox_uniform(g);
+  double s, c;
+  sincos_f64(2.0 * kPiD * u2, &s, &c);
+  return sqrt(-2.0 * d_log_fast(u1)) * c;
+}
+BLE_FN double philox_gamma(Philox& g, double shape) {   // Marsaglia-Tsang, shape >= 1
+  const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    const double x = philox_normal(g);
+    const double t = 1.0 + c * x;
+    if (t <= 0.0) continue;
+    const double v = t * t * t;
+    const double u = 1.0 - philox_uniform(g);
+    if (d_log_fast(u) < 0.5 * x * x + d - d * v + d * d_log_fast(v)) return d * v;
+  }
+  return d;
+}
+
+}  // namespace ble

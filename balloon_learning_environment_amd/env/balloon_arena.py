@@ -39,12 +39,24 @@ class VecBalloonArena:
     self._step_duration = constants.AGENT_TIME_STEP
     self.reset(seed)
 
-  def reset(self, seed: Optional[int] = None, upwelling_ir='reference') -> None:
+  def reset(self, seed: Optional[int] = None, on_device: bool = True, upwelling_ir='reference') -> None:
+    """New episodes for every env.  on_device=True: ble_reset_f32 (Philox streams on the GPU);
+    False: the NumPy host path (reset_host.py) -- same distributions, different streams."""
     seed = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
-    self._host_init = reset_host.sample_initial_state(self.num_envs, seed=seed, upwelling_ir=upwelling_ir)
-    self.sim.set_state(self._host_init)
+    self._seed = seed
+    if on_device:
+      self.sim.reset_device(seed)
+    else:
+      self.sim.set_state(reset_host.sample_initial_state(self.num_envs, seed=seed, upwelling_ir=upwelling_ir))
     self.wind_field.reset(np.array([seed], np.uint32), None)
     self.sim.set_grid(self.wind_field.grid)
+
+  def reset_terminated(self) -> int:
+    """Auto-reset: starts a new episode (same wind field) in every env whose status != OK.
+    Returns the number of envs that were reset."""
+    mask = (self.sim.state['status'] != 0).to(torch.uint8)
+    self.sim.reset_device(self._seed, mask=mask)
+    return int(mask.sum().item())
 
   def step(self, actions: torch.Tensor, noise_uv: Optional[torch.Tensor] = None):
     """actions: uint8 device tensor [N] -> (reward [N] f32, terminal [N] u8) device tensors."""

@@ -54,6 +54,7 @@ class VecSimulator:
       self.effective_action = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
       self.err_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
       self.active_slots = torch.zeros(COUNT_SLOTS, dtype=torch.int64, device=self.device)
+      self.episode = torch.zeros(self.n, dtype=torch.int32, device=self.device)   # per-env episode counter
     self.grid: Optional[torch.Tensor] = None
     self.grid_env_stride = 0
     self._struct = dev.state_struct(self.state)
@@ -81,6 +82,17 @@ class VecSimulator:
       assert tuple(g.shape) == GRID_SHAPE, g.shape
       self.grid_env_stride = 0
     self.grid = g
+
+  # ------------------------------------------------------------------ reset on the device
+  def reset_device(self, seed: int, mask: Optional[torch.Tensor] = None, sample: bool = True) -> None:
+    """BalloonArena.reset's balloon part for the envs with mask != 0 (all if None), on the GPU:
+    draws (if `sample`), Newton cold start, sunrise/sunset search, fresh clocks and FSMs."""
+    if mask is not None:
+      assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == self.n
+    code = self.lib.ble_reset_f32(ctypes.byref(self._struct), dev.ptr(mask), int(seed) & (2 ** 64 - 1),
+                                  self.episode.data_ptr(), 1 if sample else 0, self.err_flags.data_ptr(), self.n,
+                                  dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_reset_f32')
 
   # ------------------------------------------------------------------ stepping
   def step(self, action: torch.Tensor, noise_uv: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):

@@ -151,6 +151,23 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
                    void* stream);
 
 /*
+ * Episode reset on the device for the environments with mask[i] != 0 (mask NULL = all).
+ * Replaces BalloonArena.reset's balloon part (env/balloon_arena.py:161-182,228-268):
+ *   sample != 0  draw alpha, start time, position, centre lat/lng, pressure, upwelling IR with the
+ *                reference's distributions (utils/sampling.py:37-152) from a Philox4x32-10 stream
+ *                keyed by (seed, env index, episode[i]); episode[i] (optional device uint32[n]) is
+ *                then incremented.  (The reference's JAX threefry streams are not reproduced.)
+ *   sample == 0  keep x, y, pressure, center_lat/lng_deg, upwelling_infrared, alpha, start_unix.
+ * then stable_init.cold_start_to_stable_params (env/balloon/stable_init.py:132-157),
+ * PowerSafetyLayer.__init__'s sunrise/sunset search (env/balloon/power_safety.py:40-48 ->
+ * env/balloon/solar.py:432-483), battery 2905.6 Wh, clocks 0, FSMs NOMINAL, status OK.
+ * Writes the per-episode "constants" of `st` too when sample != 0 (they are const only to
+ * ble_step_f32).  The wind field is reset by the caller (new grid pointer / contents).
+ */
+int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed,
+                  uint32_t* episode, int sample, uint32_t* err_flags, int64_t n, void* stream);
+
+/*
  * GridBasedWindField.get_forecast (grid_based_wind_field.py:70-94,145-187) for n query
  * points: clamp, time boomerang, float32 query packing, 16-corner interpolation.
  */

@@ -77,3 +77,30 @@ extern "C" void emul_ephemeris(int64_t t, double* out4) {
   out4[0] = e.eot_min; out4[1] = e.sin_decl; out4[2] = e.cos_decl; out4[3] = e.flux;
   out4[4] = e.eot_min_rate; out4[5] = e.sin_decl_rate; out4[6] = e.cos_decl_rate; out4[7] = e.flux_rate;
 }
+
+// ---- reset path (ble_reset.h) on the host ----
+#include "../../balloon_learning_environment_amd/csrc/ble_reset.h"
+extern "C" void emul_reset_derive(int64_t n, const float* alpha, const float* x, const float* y, const float* p,
+                                  const float* lat0, const float* lng0, const float* ir, const int64_t* start,
+                                  double* t_amb, double* t_int, double* mols_air, double* volume, double* sp,
+                                  int64_t* sunrise, int64_t* sunset, double* el_out) {
+  for (int64_t i = 0; i < n; ++i) {
+    SunSite site;
+    latlng_f64((double)lat0[i], (double)lng0[i], (double)x[i], (double)y[i], &site.sin_lat, &site.cos_lat, &site.lng_deg);
+    double flux;
+    const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, start[i], &flux);
+    uint32_t flags = 0;
+    const StableParams s = stable_params((double)alpha[i], (double)p[i], el, flux, (double)ir[i], &flags);
+    t_amb[i] = s.t_amb; t_int[i] = s.t_int; mols_air[i] = s.mols_air; volume[i] = s.volume; sp[i] = s.sp;
+    next_sunrise_sunset(site, start[i], &sunrise[i], &sunset[i]);
+    el_out[i] = el;
+  }
+}
+extern "C" void emul_philox(uint64_t seed, uint64_t env, uint32_t episode, int64_t n, double* uniform, double* normal,
+                            double* gamma12) {
+  Philox g = philox_init(seed, env, episode);
+  for (int64_t i = 0; i < n; ++i) uniform[i] = philox_uniform(g);
+  for (int64_t i = 0; i < n; ++i) normal[i] = philox_normal(g);
+  for (int64_t i = 0; i < n; ++i) gamma12[i] = philox_gamma(g, 1.2);
+}
+extern "C" double emul_asin(double x) { return d_asin(x); }

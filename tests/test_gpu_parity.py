@@ -524,3 +524,85 @@ def test_fused_rollout_equals_single_steps(ble):
   live_per_step = cnt.sum(dim=1).cpu().numpy()
   expect = np.concatenate([[n], n - torch.stack(tb).cpu().numpy()[:-1].sum(axis=1)])
   np.testing.assert_array_equal(live_per_step, expect)
+
+
+# ---------------------------------------------------------------- device reset
+def test_device_reset_derivation_matches_oracle(ble):
+  """sample=0: cold start + sunrise search on given inputs (golden F10 + sampled) vs the oracle."""
+  from balloon_learning_environment_amd import reset_host
+  d = golden('f10_reset')
+  init = reset_host.sample_initial_state(4096, seed=31)
+  cases = [dict(alpha=d['alpha'], x=d['x'], y=d['y'], pressure=d['pressure'], center_lat_deg=d['center_lat_deg'],
+                center_lng_deg=d['center_lng_deg'], upwelling_infrared=d['upwelling_infrared'], start_unix=d['unix_s']),
+           {k: init[k] for k in ('alpha', 'x', 'y', 'pressure', 'center_lat_deg', 'center_lng_deg', 'upwelling_infrared',
+                                 'start_unix')}]
+  for c in cases:
+    n = c['x'].size
+    sim = ble.VecSimulator(n)
+    sim.set_state(c)
+    sim.state['status'].fill_(2); sim.state['time_elapsed_s'].fill_(999)      # must be overwritten
+    sim.reset_device(seed=0, sample=False)
+    torch.cuda.synchronize(); sim.check_errors()
+    got = sim.get_state()
+    f = {k: got[k].astype(np.float64) for k in ('alpha', 'x', 'y', 'pressure', 'center_lat_deg', 'center_lng_deg',
+                                                 'upwelling_infrared')}
+    ref, err = oracle.stable_init(f['pressure'], f['center_lat_deg'], f['center_lng_deg'], f['x'], f['y'], got['start_unix'],
+                                  f['upwelling_infrared'], f['alpha'])
+    assert err == 0
+    for k, v in ref.items():
+      np.testing.assert_allclose(got[k], v, rtol=2e-7, atol=1e-6, err_msg=k)      # fp32 storage of an fp64 result
+    la, lo = oracle.latlng_from_offset(np.radians(f['center_lat_deg']), np.radians(f['center_lng_deg']), f['x'], f['y'])
+    sr, ss = oracle.next_sunrise_sunset(la, lo, got['start_unix'])
+    np.testing.assert_array_equal(got['start_unix'] + got['sunrise_h_rel'], sr + 1800)
+    np.testing.assert_array_equal(got['start_unix'] + got['sunset_rel'], ss)
+    assert (got['status'] == 0).all() and (got['time_elapsed_s'] == 0).all() and (got['last_command'] == 1).all()
+    assert (got['battery_charge'] == np.float32(2905.6)).all()
+
+
+def test_device_reset_sampling_distributions_and_autoreset(ble):
+  """sample=1: the reference's initial-condition distributions (balloon_arena_test.py:56-87,
+  utils/sampling.py), determinism per (seed, env, episode), masked auto-reset."""
+  from balloon_learning_environment_amd.env import balloon_arena
+  n = 65536
+  arena = balloon_arena.VecBalloonArena(n, seed=17)
+  torch.cuda.synchronize(); arena.sim.check_errors()
+  s = arena.sim.get_state()
+  r = np.hypot(s['x'].astype(np.float64), s['y'].astype(np.float64))
+  assert r.max() <= 200_000.0 and abs(r.mean() / 200_000.0 - 1.2 / 3.2) < 0.01          # Beta(1.2, 2.0) mean
+  assert abs((r / 200_000.0).var() - (1.2 * 2.0) / (3.2 ** 2 * 4.2)) < 0.005
+  assert s['alpha'].min() >= 0 and s['alpha'].max() < 1 and abs(s['alpha'].mean() - 0.5) < 0.01
+  assert np.abs(s['center_lat_deg']).max() <= 10 and np.abs(s['center_lng_deg']).max() <= 175
+  assert s['start_unix'].min() >= 1293840000 and s['start_unix'].max() < 1419984000
+  assert (s['upwelling_infrared'] >= 225).all() and (s['upwelling_infrared'] <= 315).all()
+  p_max, _, _, _ = oracle.at_height(0.0, [15240.0])
+  assert (s['pressure'] >= 6500).all()
+  for a in (0.1, 0.5, 0.9):
+    sel = np.abs(s['alpha'] - a) < 0.01
+    pm = oracle.at_height(a, [15240.0])[0][0]
+    assert s['pressure'][sel].max() <= pm + 12 and s['pressure'][sel].max() > pm - 250
+  assert (s['status'] == 0).all() and (s['superpressure'] > 0).all()
+  # determinism: same seed -> same episodes; another seed -> different
+  arena2 = balloon_arena.VecBalloonArena(n, seed=17)
+  s2 = arena2.sim.get_state()
+  for k in s:
+    np.testing.assert_array_equal(s[k], s2[k], err_msg=k)
+  arena3 = balloon_arena.VecBalloonArena(1024, seed=18)
+  assert not np.array_equal(arena3.sim.get_state()['x'], s['x'][:1024])
+  # the derived part of a sampled reset agrees with the oracle on the sampled inputs
+  f = {k: s[k][:2048].astype(np.float64) for k in ('alpha', 'x', 'y', 'pressure', 'center_lat_deg', 'center_lng_deg', 'upwelling_infrared')}
+  ref, _ = oracle.stable_init(f['pressure'], f['center_lat_deg'], f['center_lng_deg'], f['x'], f['y'], s['start_unix'][:2048],
+                              f['upwelling_infrared'], f['alpha'])
+  np.testing.assert_allclose(s['internal_temperature'][:2048], ref['internal_temperature'], rtol=2e-7)
+  # auto-reset: terminate some lanes, reset only those, episode counter advances -> new draws
+  arena.sim.state['status'][:100] = 1
+  before = arena.sim.get_state()
+  assert arena.reset_terminated() == 100
+  after = arena.sim.get_state()
+  assert (after['status'] == 0).all() and not np.array_equal(after['x'][:100], before['x'][:100])
+  for k in after:
+    np.testing.assert_array_equal(after[k][100:], before[k][100:], err_msg=k)
+  assert (arena.sim.episode.cpu().numpy()[:100] == 2).all() and (arena.sim.episode.cpu().numpy()[100:] == 1).all()
+  # and the freshly reset arena steps fine
+  reward, terminal = arena.step(torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda'))
+  torch.cuda.synchronize(); arena.sim.check_errors()
+  assert float(reward.min()) >= 0 and float(reward.max()) <= 1

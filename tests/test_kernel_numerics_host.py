@@ -82,3 +82,60 @@ def test_random_states_and_layer_transition_chatter():
     p1 = atm.pres[:, 1]
     crossings += int(((p_before[:k] - p1[:k]) * (st['pressure'][:k] - p1[:k]) < 0).sum())
   assert crossings > 50   # the transition really is being crossed
+
+
+def test_reset_path_host_build_matches_oracle():
+  """ble_reset.h (device reset: full-fp64 solar, Newton cold start, sunrise search) built with
+  g++ against the reference's golden F10 and the oracle on 512 sampled states."""
+  import ctypes
+  e = _load_emul()
+  lib = e.lib()
+  lib.emul_asin.restype = ctypes.c_double
+  for x in np.linspace(-1, 1, 2001):
+    assert abs(lib.emul_asin(ctypes.c_double(x)) - np.arcsin(x)) < 4e-16
+  from balloon_learning_environment_amd import reset_host
+  d = golden('f10_reset')
+  init = reset_host.sample_initial_state(512, seed=21)
+  cases = [dict(alpha=d['alpha'], x=d['x'], y=d['y'], pressure=d['pressure'], lat=d['center_lat_deg'], lng=d['center_lng_deg'],
+                ir=d['upwelling_infrared'], start=d['unix_s']),
+           dict(alpha=init['alpha'], x=init['x'], y=init['y'], pressure=init['pressure'], lat=init['center_lat_deg'],
+                lng=init['center_lng_deg'], ir=init['upwelling_infrared'], start=init['start_unix'])]
+  for c in cases:
+    f32 = {k: np.ascontiguousarray(v, np.float32) for k, v in c.items() if k != 'start'}
+    start = np.ascontiguousarray(c['start'], np.int64)
+    n = start.size
+    outs = [np.empty(n) for _ in range(5)]; sr = np.empty(n, np.int64); ss = np.empty(n, np.int64); el = np.empty(n)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.emul_reset_derive(ctypes.c_int64(n), P(f32['alpha']), P(f32['x']), P(f32['y']), P(f32['pressure']), P(f32['lat']),
+                          P(f32['lng']), P(f32['ir']), P(start), *[P(o) for o in outs], P(sr), P(ss), P(el))
+    as64 = {k: v.astype(np.float64) for k, v in f32.items()}
+    ref, err = oracle.stable_init(as64['pressure'], as64['lat'], as64['lng'], as64['x'], as64['y'], start, as64['ir'], as64['alpha'])
+    assert err == 0
+    for o, k in zip(outs, ('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume', 'superpressure')):
+      np.testing.assert_allclose(o, ref[k], rtol=1e-9, atol=1e-7, err_msg=k)
+    la, lo = oracle.latlng_from_offset(np.radians(as64['lat']), np.radians(as64['lng']), as64['x'], as64['y'])
+    eo, _, _, _ = oracle.solar_calculator(la, lo, start)
+    assert np.abs(el - eo).max() < 1e-9
+    sro, sso = oracle.next_sunrise_sunset(la, lo, start)
+    np.testing.assert_array_equal(sr, sro); np.testing.assert_array_equal(ss, sso)
+
+
+def test_philox_streams_host_build():
+  import ctypes
+  e = _load_emul()
+  lib = e.lib()
+  n = 20000
+  u = np.empty(n); z = np.empty(n); g = np.empty(n)
+  P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  lib.emul_philox(ctypes.c_uint64(7), ctypes.c_uint64(3), ctypes.c_uint32(0), ctypes.c_int64(n), P(u), P(z), P(g))
+  assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+  assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+  assert abs(g.mean() - 1.2) < 0.04 and abs(g.var() - 1.2) < 0.1        # Gamma(1.2, 1)
+  u2 = np.empty(n); z2 = np.empty(n); g2 = np.empty(n)
+  lib.emul_philox(ctypes.c_uint64(7), ctypes.c_uint64(4), ctypes.c_uint32(0), ctypes.c_int64(n), P(u2), P(z2), P(g2))
+  assert abs(np.corrcoef(u, u2)[0, 1]) < 0.03                           # env streams are independent
+  # Philox4x32-10 known answer (Random123 kat_vectors: counter 0, key 0)
+  lib.emul_philox(ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_int64(2), P(u[:2]), P(z[:2]), P(g[:2]))
+  words = [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]               # out[0..3]; the stream pops from out[3]
+  hi, lo = words[3], words[2]
+  assert u[0] == (((hi << 32) | lo) >> 11) / 2.0 ** 53
