@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the vectorised BLE transition on MI355X.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 192 --warmup 32
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -63,8 +63,8 @@ def cpu_baseline(state, actions, field, seconds_target=10.0):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=200)
-  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--steps', type=int, default=192)
+  ap.add_argument('--warmup', type=int, default=32)
   ap.add_argument('--envs-per-gpu', type=int, default=65536)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--active-count', action='store_true', help='analysis only: use the in-kernel live-env counter')
