@@ -606,3 +606,21 @@ def test_device_reset_sampling_distributions_and_autoreset(ble):
   reward, terminal = arena.step(torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda'))
   torch.cuda.synchronize(); arena.sim.check_errors()
   assert float(reward.min()) >= 0 and float(reward.max()) <= 1
+
+
+@pytest.mark.parametrize('n', [1, 63, 65, 1000])
+def test_ragged_batch_sizes(ble, n):
+  """Batch sizes that do not fill a wavefront (tail lanes masked), incl. the single-env case."""
+  from balloon_learning_environment_amd import reset_host
+  total, outliers, worst = _sampled_batch_parity(ble, n, steps=3, seed=100 + n, threads=2)
+  print(f'n={n}: {total} env-steps, worst {worst:.2g}')
+  assert outliers == 0 or worst < 5e-4
+  sim = ble.VecSimulator(n)
+  sim.set_state(reset_host.sample_initial_state(n, seed=1))
+  sim.set_grid(np.zeros((21, 21, 10, 9, 2), np.float32))
+  k = 3
+  acts = torch.randint(0, 3, (k, n), dtype=torch.uint8, device='cuda')
+  rew = torch.full((k, n), -1.0, dtype=torch.float32).cuda(); term = torch.full((k, n), 9, dtype=torch.uint8).cuda()
+  sim.step_n(acts, rew, term)
+  torch.cuda.synchronize(); sim.check_errors()
+  assert float(rew.min()) >= 0.0 and int(term.max()) <= 1          # every element written, nothing beyond n touched
