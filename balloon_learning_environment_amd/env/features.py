@@ -1,15 +1,59 @@
 """FeatureConstructor interface (env/features.py:106-144).
 
-The 1099-float PerciatelliFeatureConstructor (wind-column + GP) is the next scope row after
-the transition and is not built yet.  `StateFeatureConstructor` is a small
-placeholder observation so that the gym surface is complete; agents that need Perciatelli
-features cannot drop in until that row lands.
+`PerciatelliFeatureConstructor` (env/features.py:269-581) is the single-environment host
+observation path (stage S1): 16 ambient features + a 361-level relative
+wind column from the WindGP.  The forecast column comes from the device kernel through
+`GridBasedWindField`; the GP algebra, sunrise search and pressure-range solve are host NumPy.
+`StateFeatureConstructor` is a compact raw-state observation for vectorised consumers.
 """
 import abc
+import dataclasses
+import datetime as dt
+import logging
+import math
 
 import numpy as np
 
+from balloon_learning_environment_amd import reset_host
 from balloon_learning_environment_amd.env import simulator_data
+from balloon_learning_environment_amd.env import wind_gp
+from balloon_learning_environment_amd.env.balloon import control
+from balloon_learning_environment_amd.env.balloon import power_table
+from balloon_learning_environment_amd.env.balloon import pressure_range_builder
+from balloon_learning_environment_amd.utils import constants
+from balloon_learning_environment_amd.utils import transforms
+from balloon_learning_environment_amd.utils import units
+
+TOLERANCE = units.Distance(meters=1e-5)
+
+
+def _latlng_rad(balloon_state):
+  ll = balloon_state.latlng
+  return np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)])
+
+
+def compute_solar_angle(balloon_state) -> float:
+  """Solar elevation [deg] at the balloon (env/features.py:56-70)."""
+  lat, lng = _latlng_rad(balloon_state)
+  el, _ = reset_host.solar_calculator(lat, lng, np.array([int(balloon_state.date_time.timestamp())]))
+  return float(el[0])
+
+
+def compute_sunrise_time(balloon_state) -> float:
+  """Normalised solar-cycle time (env/features.py:73-104): [sunrise, sunset] -> [0, pi],
+  [sunset, next sunrise] -> [pi, 2 pi]."""
+  now = int(balloon_state.date_time.timestamp())
+  lat, lng = _latlng_rad(balloon_state)
+  sunrise, sunset = reset_host.next_sunrise_sunset(lat, lng, np.array([now], np.int64))
+  sunrise, sunset = int(sunrise[0]), int(sunset[0])
+  day = constants.NUM_SECONDS_PER_DAY
+  assert sunrise - day <= now <= sunrise
+  assert sunset - day <= now <= sunset
+  if sunset < sunrise:       # day: sunset is next
+    sunrise -= day
+    return math.pi * (now - sunrise) / (sunset - sunrise)
+  sunset -= day              # night: sunrise is next
+  return math.pi + math.pi * (now - sunset) / (sunrise - sunset)
 
 
 class Box:
@@ -64,3 +108,161 @@ class StateFeatureConstructor(FeatureConstructor):
   @property
   def observation_space(self):
     return Box(np.full(11, -np.inf), np.full(11, np.inf))
+
+
+@dataclasses.dataclass
+class PerciatelliWindFeature:
+  uncertainty: float
+  bearing: float
+  magnitude: float
+
+  def is_valid_wind(self):
+    return self.magnitude != 1.0 or self.bearing != 1.0 or self.uncertainty != 0.0
+
+
+class NamedPerciatelliFeatures:
+  """Names for the 1099-vector (env/features.py:167-257)."""
+
+  def __init__(self, features: np.ndarray):
+    assert len(features) == 1099
+    self._winds = features[16:]
+    self.num_pressure_levels = len(self._winds) // 3
+    a = features[:16]
+    self.balloon_pressure = transforms.undo_linear_rescale_with_extrapolation(
+        a[0], constants.PERCIATELLI_PRESSURE_RANGE_MIN, constants.PERCIATELLI_PRESSURE_RANGE_MAX)
+    self.battery_charge = a[1]
+    self.solar_elevation = a[2]
+    self.sin_normalized_solar_cycle, self.cos_normalized_solar_cycle = a[3], a[4]
+    self.sin_heading_to_station, self.cos_heading_to_station = a[5], a[6]
+    self.distance_to_station = a[7]
+    # feature order is up, stay, down (the reverse of the command enum)
+    self.last_command = (control.AltitudeControlCommand.UP, control.AltitudeControlCommand.STAY,
+                         control.AltitudeControlCommand.DOWN)[int(np.argmax(a[8:11]))]
+    self.navigation_enabled, self.navigation_paused = a[11], a[12]
+    self.has_excess_energy, self.descent_cost, self.internal_pressure_ratio = a[13], a[14], a[15]
+
+  def wind_at(self, level: int) -> PerciatelliWindFeature:
+    if 0 > level >= self.num_pressure_levels:
+      raise ValueError(f'Invalid wind level: {level}')
+    return PerciatelliWindFeature(*self._winds[level * 3:level * 3 + 3])
+
+  def level_is_valid(self, level: int) -> bool: return self.wind_at(level).is_valid_wind()
+  def magnitude(self, level: int) -> float: return self.wind_at(level).magnitude
+  def bearing(self, level: int) -> float: return self.wind_at(level).bearing
+  def uncertainty(self, level: int) -> float: return self.wind_at(level).uncertainty
+
+  def wind_column_center(self) -> int:
+    assert self.num_pressure_levels % 2 == 1
+    return self.num_pressure_levels // 2
+
+
+def convert_wind_feature_to_real_wind(wind: PerciatelliWindFeature) -> PerciatelliWindFeature:
+  return PerciatelliWindFeature(wind.uncertainty,
+                                transforms.undo_linear_rescale_with_extrapolation(wind.bearing, 0.0, math.pi),
+                                transforms.undo_squash_to_unit_interval(wind.magnitude, 30.0))
+
+
+_UNREACHABLE = (0.0, 1.0, 1.0)   # certain, wrong way, infinitely fast
+
+
+class PerciatelliFeatureConstructor(FeatureConstructor):
+  """env/features.py:269-581.  `forecast` needs get_forecast / get_forecast_column."""
+
+  def __init__(self, forecast, atmosphere) -> None:
+    self.num_pressure_levels = 181
+    self.min_pressure = constants.PERCIATELLI_PRESSURE_RANGE_MIN
+    self.max_pressure = constants.PERCIATELLI_PRESSURE_RANGE_MAX
+    self.pressure_levels = np.linspace(self.min_pressure, self.max_pressure, self.num_pressure_levels)
+    self.num_features = 3 * (self.num_pressure_levels * 2 - 1) + 16
+    self.windgp = wind_gp.WindGP(forecast)
+    self._atmosphere = atmosphere
+    self._last_balloon_state = None
+
+  def observe(self, observation: simulator_data.SimulatorObservation) -> None:
+    b = observation.balloon_observation
+    self._last_balloon_state = b
+    self.windgp.observe(b.x, b.y, b.pressure, b.time_elapsed, observation.wind_at_balloon)
+
+  def get_features(self) -> np.ndarray:
+    p = self._last_balloon_state.pressure
+    if not self.is_valid_pressure(p):
+      logging.warning('Balloon pressure %.2f not fully represented by feature constructor.', p)
+    out = np.zeros(self.num_features, dtype=np.float32)
+    self._add_ambient_features(out)
+    self._add_wind_features(out)
+    return out
+
+  @property
+  def observation_space(self) -> Box:
+    low = np.zeros(self.num_features, np.float32)
+    high = np.ones(self.num_features, np.float32)
+    low[[3, 4, 5, 6]] = -1.0
+    low[15], high[15] = 1.0, np.inf
+    return Box(low, high)
+
+  def is_valid_pressure(self, pressure: float) -> bool:
+    return self.min_pressure <= pressure <= self.max_pressure
+
+  def _nearest_pressure_level(self, pressure: float) -> int:
+    pressure = min(max(pressure, self.min_pressure), self.max_pressure)
+    delta = self.pressure_levels[1] - self.pressure_levels[0]
+    level = int(round((pressure - self.min_pressure) / delta))
+    assert 0 <= level < self.num_pressure_levels
+    return level
+
+  def _add_ambient_features(self, out: np.ndarray) -> None:
+    b = self._last_balloon_state
+    out[0] = transforms.linear_rescale_with_saturation(b.pressure, self.min_pressure, self.max_pressure)
+    out[1] = b.battery_soc
+    out[2] = transforms.linear_rescale_with_saturation(compute_solar_angle(b), -90.0, 90.0)
+    cycle = compute_sunrise_time(b)
+    assert 0 <= cycle <= 2 * math.pi + 1e-6
+    out[3], out[4] = math.sin(cycle), math.cos(cycle)
+    heading = math.atan2(-b.x.kilometers, -b.y.kilometers)      # from north, increasing east
+    out[5], out[6] = math.sin(heading), math.cos(heading)
+    out[7] = transforms.squash_to_unit_interval(units.relative_distance(b.x, b.y).kilometers, 250)
+    out[8] = float(b.last_command == control.AltitudeControlCommand.UP)
+    out[9] = float(b.last_command == control.AltitudeControlCommand.STAY)
+    out[10] = float(b.last_command == control.AltitudeControlCommand.DOWN)
+    out[11] = float(b.navigation_is_paused)
+    out[12] = float(not b.navigation_is_paused)
+    out[13] = float(b.excess_energy)
+    out[14] = transforms.linear_rescale_with_saturation(power_table.lookup(b.pressure_ratio, b.battery_soc), 100, 300)
+    out[15] = b.pressure_ratio
+
+  def _add_wind_features(self, out: np.ndarray) -> None:
+    b = self._last_balloon_state
+    n = self.num_pressure_levels
+    query = np.zeros((n, 4))
+    query[:, 0], query[:, 1] = b.x.meters, b.y.meters
+    query[:, 2] = self.pressure_levels
+    query[:, 3] = b.time_elapsed.total_seconds()
+    means, deviations = self.windgp.query_batch(query)
+
+    level = self._nearest_pressure_level(b.pressure)
+    pad_above = n - level - 1                 # lower-pressure side of the relative column
+    pad_below = (2 * n - 1) - pad_above - n
+    assert pad_below >= 0
+
+    distance = units.relative_distance(b.x, b.y)
+    to_station = -np.array([b.x.meters, b.y.meters]) / (distance + TOLERANCE).meters
+    reachable = pressure_range_builder.get_pressure_range(b, self._atmosphere)
+
+    winds = means[:, 0:2]
+    speed = np.linalg.norm(winds, axis=1, ord=2)
+    winds = winds / (speed + TOLERANCE.meters).reshape(-1, 1)
+    if distance < TOLERANCE:
+      angle = np.zeros(n, np.float32)
+    else:
+      angle = np.arccos(np.clip(winds @ to_station, -1.0, 1.0))
+      angle = np.where(speed < TOLERANCE.meters, np.pi, angle)
+    angle_feat = transforms.linear_rescale_with_extrapolation(angle, 0, math.pi)
+    speed_feat = transforms.squash_to_unit_interval(speed, 30)
+
+    column = np.empty((2 * n - 1, 3), np.float32)
+    column[:] = _UNREACHABLE
+    ok = (self.pressure_levels >= reachable.min_pressure) & (self.pressure_levels <= reachable.max_pressure)
+    assert np.all((deviations[ok] >= 0.0) & (deviations[ok] <= 1.00001)), 'Uncertainty not in [0, 1].'
+    body = column[pad_above:pad_above + n]
+    body[ok, 0], body[ok, 1], body[ok, 2] = deviations[ok], angle_feat[ok], speed_feat[ok]
+    out[16:] = column.reshape(-1)

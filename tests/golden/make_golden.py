@@ -467,6 +467,57 @@ def f10_reset():
        sunset=sunset, **out)
 
 
+# ----------------------------------------------------------------------------- F11
+def f11_features(n_env=3, n_steps=45):
+  """PerciatelliFeatureConstructor (env/features.py:270-581) driven like BalloonArena: observe()
+  after every simulate_step, get_features().  The 'measured' wind is forecast + a smooth
+  pseudo-noise so that the WindGP (env/wind_gp.py) has non-zero errors to model."""
+  from balloon_learning_environment.env import features
+  rng = np.random.default_rng(11)
+  field = make_field(0)
+  feats = np.zeros((n_env, n_steps + 1, 1099), np.float32)
+  cols = {k: np.zeros((n_env, n_steps + 1)) for k in STATE_FLOATS}
+  for k in ('time_elapsed_s', 'sunrise_h', 'sunset'):
+    cols[k] = np.zeros((n_env, n_steps + 1), np.int64)
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused'):
+    cols[k] = np.zeros((n_env, n_steps + 1), np.uint8)
+  wind_meas = np.zeros((n_env, n_steps + 1, 2))
+  consts = {k: np.zeros(n_env) for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha')}
+  start_unix = np.zeros(n_env, np.int64)
+  actions = rng.integers(0, 3, (n_env, n_steps)).astype(np.uint8)
+  starts = [units.datetime(2013, 3, 25, 9, 25, 32), units.datetime(2011, 7, 1, 22, 0, 5), units.datetime(2013, 9, 21, 17, 45, 0)]
+  for j in range(n_env):
+    s = dict(lat=float(rng.uniform(-10, 10)), lng=float(rng.uniform(-175, 175)), start=starts[j % 3],
+             pressure=float(rng.uniform(7000, 10500)), x=float(rng.uniform(-1.5e5, 1.5e5)),
+             y=float(rng.uniform(-1.5e5, 1.5e5)), ir=float(rng.uniform(230, 320)), alpha=float(rng.uniform(0, 1)), tweak=None)
+    atm = ref_shims.make_atmosphere(s['alpha'])
+    wf = ref_shims.make_grid_wind_field(field)
+    b = balloon.Balloon(build_state(s, atm))
+    su = int(s['start'].timestamp()); start_unix[j] = su
+    consts['center_lat_deg'][j] = s['lat']; consts['center_lng_deg'][j] = s['lng']
+    consts['upwelling_infrared'][j] = s['ir']; consts['alpha'][j] = s['alpha']
+    fc = features.PerciatelliFeatureConstructor(wf, atm)
+
+    def measure(i):
+      w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+      nu, nv = 1.5 * np.sin(0.3 * i + j), -1.0 * np.cos(0.17 * i) + 0.2 * j
+      wind_meas[j, i] = (w.u.mps + nu, w.v.mps + nv)
+      return w, wind_field.WindVector(units.Velocity(mps=float(wind_meas[j, i, 0])), units.Velocity(mps=float(wind_meas[j, i, 1])))
+
+    for i in range(n_steps + 1):
+      if i > 0:
+        w, _ = measure(i - 1)
+        b.simulate_step(w, atm, control.AltitudeControlCommand(int(actions[j, i - 1])), dt.timedelta(minutes=3))
+      _, meas = measure(i)
+      fc.observe(simulator_data.SimulatorObservation(balloon_observation=b.state, wind_at_balloon=meas))
+      feats[j, i] = fc.get_features()
+      snap = snapshot(b.state, su)
+      for k in SNAP_KEYS:
+        cols[k][j, i] = snap[k]
+  save('f11_features', field_seed=np.int64(0), field_scale=np.float64(5.0), features=feats, wind_measured=wind_meas,
+       actions=actions, start_unix=start_unix, **consts, **cols)
+
+
 if __name__ == '__main__':
   f1_atmosphere(); f2_solar(); f3_thermal(); f4_sp_volume(); f5_acs_power_table(); f6_safety(); f7_wind()
-  f8_trajectories(); f9_arena(); f10_reset()
+  f8_trajectories(); f9_arena(); f10_reset(); f11_features()

@@ -466,6 +466,42 @@ def test_balloon_env_gym_surface(ble):
       env1.step(1)
 
 
+def test_perciatelli_features_device_forecast(ble):
+  """the 1099-feature observation with the device forecast kernel behind
+  GridBasedWindField, against the reference's PerciatelliFeatureConstructor output (F11).
+  Tolerance 2e-4 absolute: the device forecast is fp32 (~1e-6 relative on u, v) and the bearing
+  feature is arccos(.)/pi, whose error near aligned/opposed winds is sqrt(2 eps) ~ 1e-4."""
+  import test_features_host as tfh
+  from balloon_learning_environment_amd.env import grid_based_wind_field, grid_wind_field_sampler
+  g = golden('f11_features')
+  wf = grid_based_wind_field.GridBasedWindField(grid_wind_field_sampler.GaussianFieldSampler())
+  wf.set_field(tfh.field_of(g))
+  for j in range(3):
+    got = tfh.run_constructor(g, wf, j, n_steps=16)
+    want = g['features'][j, :16]
+    unreach = lambda f: (f[:, 16::3] == 0) & (f[:, 17::3] == 1) & (f[:, 18::3] == 1)
+    np.testing.assert_array_equal(unreach(got), unreach(want))
+    err = np.abs(got.astype(np.float64) - want)
+    assert err.max() <= 2e-4, (j, err.max())
+    assert np.median(err[err > 0]) < 1e-6 if (err > 0).any() else True
+
+
+def test_balloon_env_emits_perciatelli_observation(ble):
+  from balloon_learning_environment_amd.env import balloon_env, features
+  env = balloon_env.BalloonEnv(seed=7)
+  assert env.observation_space.shape == (1099,)
+  obs = env.reset()
+  assert obs.shape == (1099,) and obs.dtype == np.float32
+  for a in (2, 2, 1, 0):
+    obs, r, term, info = env.step(a)
+    assert env.observation_space.contains(obs)
+  named = features.NamedPerciatelliFeatures(obs)
+  st = env.get_simulator_state().balloon_state
+  np.testing.assert_allclose(named.balloon_pressure, st.pressure, rtol=1e-5)
+  assert int(named.last_command) == 0
+  assert named.level_is_valid(named.wind_column_center())
+
+
 def units_distance(s):
   return (s.x.km ** 2 + s.y.km ** 2) ** 0.5
 
