@@ -7,6 +7,13 @@ import ctypes
 import os
 import subprocess
 
+# One HIP runtime per process: torch ships its own libamdhip64 (SONAME libamdhip64.so.7, found
+# through torch/lib's RPATH).  Importing torch first makes libble_hip.so's NEEDED
+# libamdhip64.so.7 resolve to that already-loaded runtime, so torch's device pointers and
+# hipStream_t handles are valid in our launches.  Loaded the other way round the process gets
+# two runtimes and launches fail with hipErrorNoDevice (100).
+import torch  # noqa: F401  (must precede ctypes.CDLL(LIB_PATH))
+
 from balloon_learning_environment_amd import _abi
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -19,7 +26,7 @@ BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_forecast_f32',
+EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_forecast_f32',
            'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_f64_prims')
 
@@ -88,4 +95,5 @@ def lib():
 
 def check(code: int, what: str) -> None:
   if code != BLE_OK:
-    raise BleLibraryError(f'{what} failed with BLE error {code}')
+    hip = _lib.ble_last_hip_error() if _lib is not None else 0
+    raise BleLibraryError(f'{what} failed with BLE error {code} (hipError_t {hip})')

@@ -353,7 +353,21 @@ inline int env_lanes() {
   }();
   return lanes;
 }
-inline int launch_status() { return hipGetLastError() == hipSuccess ? BLE_OK : BLE_E_LAUNCH; }
+// hipGetLastError is per-thread and sticky: an error left behind by an unrelated runtime call
+// of the host application (torch probes pointers / peers at start-up) must not be reported as
+// ours, so every launch first drains it, and the launch's own status is kept for
+// ble_last_hip_error().
+thread_local int g_last_hip_error = 0;
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  g_last_hip_error = (int)e;
+  return e == hipSuccess ? BLE_OK : BLE_E_LAUNCH;
+}
+#define BLE_LAUNCH(...)            \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
 inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 inline bool state_ok(const ble_state_f32* st) {
   if (!st) return false;
@@ -369,6 +383,8 @@ extern "C" {
 
 int ble_abi_version(void) { return BLE_ABI_VERSION; }
 
+int ble_last_hip_error(void) { return g_last_hip_error; }
+
 int ble_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BLE_E_NO_DEVICE;
@@ -383,7 +399,7 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   const int lanes = env_lanes();
-  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+  BLE_LAUNCH(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
                      active_count, n, substeps, lanes, 1);
   return launch_status();
@@ -398,7 +414,7 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
   if (n == 0) return BLE_OK;
   if (n_steps == 0) return BLE_OK;
   const int lanes = env_lanes();
-  hipLaunchKernelGGL(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+  BLE_LAUNCH(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
                      active_count, n, substeps, lanes, n_steps);
   return launch_status();
@@ -409,7 +425,7 @@ int ble_forecast_f32(const float* wind_grid, int64_t grid_env_stride, const floa
   if (!wind_grid || !x_m || !y_m || !pressure || !elapsed_s || !u || !v || n < 0 || grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(ble_forecast_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, wind_grid,
+  BLE_LAUNCH(ble_forecast_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, wind_grid,
                      grid_env_stride, x_m, y_m, pressure, elapsed_s, u, v, n);
   return launch_status();
 }
@@ -421,7 +437,7 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(ble_forecast_column_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, wind_grid,
+  BLE_LAUNCH(ble_forecast_column_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, wind_grid,
                      grid_env_stride, x_m, y_m, elapsed_s, levels_pa, n_levels, out_uv, n);
   return launch_status();
 }
@@ -430,7 +446,7 @@ int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charg
                         int64_t n, void* stream) {
   if (!pressure_ratio || !state_of_charge || !watts || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(ble_power_table_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
+  BLE_LAUNCH(ble_power_table_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
                      state_of_charge, watts, err_flags, n);
   return launch_status();
 }
@@ -439,7 +455,7 @@ int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* h
                              uint32_t* err_flags, int64_t n, void* stream) {
   if (!alpha || !pressure || !height || !temperature || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_atmosphere_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, pressure,
+  BLE_LAUNCH(probe_atmosphere_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, pressure,
                      height, temperature, err_flags, n);
   return launch_status();
 }
@@ -449,7 +465,7 @@ int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg
   if (!center_lat_deg || !center_lng_deg || !x_m || !y_m || !unix_s || !el_deg || !flux || n < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_solar_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, center_lat_deg,
+  BLE_LAUNCH(probe_solar_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, center_lat_deg,
                      center_lng_deg, x_m, y_m, unix_s, el_deg, flux, n);
   return launch_status();
 }
@@ -458,7 +474,7 @@ int ble_probe_solar_power_f32(const float* el_deg, const float* pressure, float*
                               int64_t n, void* stream) {
   if (!el_deg || !pressure || !attenuation || !power_w || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_solar_power_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, el_deg,
+  BLE_LAUNCH(probe_solar_power_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, el_deg,
                      pressure, attenuation, power_w, n);
   return launch_status();
 }
@@ -469,7 +485,7 @@ int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* 
   if (!volume || !t_int || !t_amb || !pressure || !el_deg || !flux || !upwelling_ir || !dtdt || n < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_thermal_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, volume, t_int,
+  BLE_LAUNCH(probe_thermal_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, volume, t_int,
                      t_amb, pressure, el_deg, flux, upwelling_ir, dtdt, err_flags, n);
   return launch_status();
 }
@@ -478,7 +494,7 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
                             float* superpressure, int64_t n, void* stream) {
   if (!mols_air || !t_int || !pressure || !volume || !superpressure || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
+  BLE_LAUNCH(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
                      pressure, volume, superpressure, n);
   return launch_status();
 }
@@ -487,7 +503,7 @@ int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long lo
                   int sample, uint32_t* err_flags, int64_t n, void* stream) {
   if (!state_ok(st) || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(ble_reset_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, mask, seed,
+  BLE_LAUNCH(ble_reset_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, mask, seed,
                      episode, sample, err_flags, n);
   return launch_status();
 }
@@ -495,15 +511,15 @@ int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long lo
 int ble_probe_f64_prims(const double* x, double* y, int op, int64_t n, void* stream) {
   if (!x || !y || n < 0 || op < 0 || op > 8) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, op, n);
-  return hipGetLastError() == hipSuccess ? BLE_OK : BLE_E_LAUNCH;
+  BLE_LAUNCH(probe_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, op, n);
+  return launch_status();
 }
 
 int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency, float* mass_flow, int64_t n,
                       void* stream) {
   if (!pressure_ratio || !power_w || !efficiency || !mass_flow || n < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  hipLaunchKernelGGL(probe_acs_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
+  BLE_LAUNCH(probe_acs_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
                      power_w, efficiency, mass_flow, n);
   return launch_status();
 }

@@ -114,8 +114,33 @@ class BalloonArena(BalloonArenaInterface):
     self.last_reward = None
     self.reset(seed)
 
+  def _bind_wind_field(self) -> None:
+    """A grid-based field is interpolated inside the step kernel.  Any other WindField is
+    looked up on the host (`get_ground_truth`, env/balloon_arena.py:270-275) and handed to the
+    kernel through its additive wind input over an all-zero grid."""
+    self._grid_based = getattr(self._wind_field, 'grid', None) is not None
+    if self._grid_based:
+      self._vec.sim.set_grid(self._wind_field.grid)
+    else:
+      self._vec.sim.set_grid(torch.zeros(grid_wind_field_sampler.FieldShape().grid_shape(), dtype=torch.float32, device=self._vec.device))
+
+  def _host_wind(self) -> Optional[torch.Tensor]:
+    b = self.get_balloon_state()
+    if self._grid_based:
+      w = self._wind_field.get_wind_noise(b.x, b.y, b.pressure, b.time_elapsed)
+      if w.u.mps == 0.0 and w.v.mps == 0.0:
+        return None
+    else:
+      w = self._wind_field.get_ground_truth(b.x, b.y, b.pressure, b.time_elapsed)
+    return torch.tensor([[w.u.mps, w.v.mps]], dtype=torch.float32, device=self._vec.device)
+
   def reset(self, seed: Union[int, np.ndarray, None] = None) -> np.ndarray:
-    self._vec.reset(seed)
+    self._vec.wind_field = self._wind_field
+    seed_ = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
+    self._vec._seed = seed_
+    self._vec.sim.reset_device(seed_)
+    self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
+    self._bind_wind_field()
     self.feature_constructor = self._feature_constructor_factory(self._wind_field, self._vec.get_atmosphere())
     self.feature_constructor.observe(self.get_measurements())
     return self.feature_constructor.get_features()
@@ -127,7 +152,7 @@ class BalloonArena(BalloonArenaInterface):
     assert status == balloon.BalloonStatus.OK, (
         f'Stepping balloon after a terminal event occured. ({status.name})')
     a = torch.tensor([int(action)], dtype=torch.uint8, device=self._vec.device)
-    reward, _ = self._vec.step(a)
+    reward, _ = self._vec.step(a, self._host_wind())
     self._vec.sim.check_errors()
     self.last_reward = float(reward[0].item())
     self.feature_constructor.observe(self.get_measurements())
@@ -141,7 +166,7 @@ class BalloonArena(BalloonArenaInterface):
     self.set_balloon_state(new_state.balloon_state)
     self._wind_field = new_state.wind_field
     self._vec.wind_field = new_state.wind_field
-    self._vec.sim.set_grid(self._wind_field.grid)
+    self._bind_wind_field()
 
   def get_balloon_state(self) -> balloon.BalloonState:
     return self._vec.get_balloon_state(0)

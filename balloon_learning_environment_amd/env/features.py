@@ -67,6 +67,10 @@ class Box:
     x = np.asarray(x)
     return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
+  def sample(self, rng=np.random):
+    lo = np.where(np.isfinite(self.low), self.low, -1e6); hi = np.where(np.isfinite(self.high), self.high, 1e6)
+    return (lo + (hi - lo) * rng.random_sample(self.shape)).astype(self.dtype)
+
 
 class Discrete:
   def __init__(self, n): self.n = n

@@ -41,3 +41,17 @@ class WindField(abc.ABC):
 
   def get_ground_truth(self, x, y, pressure, elapsed_time) -> WindVector:
     return self.get_forecast(x, y, pressure, elapsed_time).add(self.get_wind_noise(x, y, pressure, elapsed_time))
+
+
+class SimpleStaticWindField(WindField):
+  """Four horizontal sheets blowing E / N / W / S by pressure band (env/wind_field.py:149-184).
+  Host-only forecast object (the reference's unit-test wind field); an arena that flies in it
+  hands the kernel the looked-up vector through the additive wind input."""
+
+  def reset_forecast(self, unused_key, unused_date_time) -> None:
+    pass
+
+  def get_forecast(self, unused_x, unused_y, pressure: float, unused_elapsed_time) -> WindVector:
+    band = int(pressure >= 8000.0) + int(pressure >= 10000.0) + int(pressure >= 12000.0)
+    u, v = ((10.0, 0.0), (0.0, 10.0), (-10.0, 0.0), (0.0, -10.0))[band]
+    return WindVector(units.Velocity(mps=u), units.Velocity(mps=v))

@@ -102,6 +102,10 @@ typedef struct ble_state_f32 {
 
 int ble_abi_version(void);
 
+/* hipError_t (as int) of the calling thread's most recent launch through this library; 0 = success.
+ * Diagnostic companion of BLE_E_LAUNCH. */
+int ble_last_hip_error(void);
+
 /* Number of visible HIP devices (>= 0) or BLE_E_NO_DEVICE. */
 int ble_device_count(void);
 

@@ -1,0 +1,150 @@
+"""The reference-shaped single-env facade on the HIP transition, driven the way the reference's
+own tests drive it (env/balloon_arena_test.py:30-86, env/balloon_env_test.py:47-242,
+env/wind_field_test.py:33-70) with the reference's unit-test wind field (SimpleStaticWindField)
+looked up on the host and handed to the kernel through the additive wind input."""
+import datetime as dt
+import random
+
+import numpy as np
+import pytest
+
+from balloon_learning_environment_amd.utils import constants, units
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def mods():
+  from balloon_learning_environment_amd import _lib
+  _lib.lib()
+  from balloon_learning_environment_amd.env import balloon_arena, balloon_env, features, wind_field
+  return balloon_arena, balloon_env, features, wind_field
+
+
+def create_arena(mods, seed=None):
+  balloon_arena, _, features, wind_field = mods
+  return balloon_arena.BalloonArena(features.PerciatelliFeatureConstructor, wind_field.SimpleStaticWindField(), seed=seed)
+
+
+def floats_of(s):
+  return (s.x.m, s.y.m, s.pressure, s.ambient_temperature, s.internal_temperature, s.envelope_volume, s.superpressure,
+          s.mols_air, s.battery_charge.watt_hours, s.date_time, s.upwelling_infrared, s.center_latlng.lat_deg)
+
+
+def test_arena_seeding(mods):
+  a1, a2 = create_arena(mods), create_arena(mods)
+  a1.reset(201); a2.reset(201)
+  assert floats_of(a1.get_simulator_state().balloon_state) == floats_of(a2.get_simulator_state().balloon_state)
+  a1.reset(np.array([0, 201], np.uint32)); a2.reset(np.array([0, 201], np.uint32))     # key-array seeding
+  assert floats_of(a1.get_simulator_state().balloon_state) == floats_of(a2.get_simulator_state().balloon_state)
+  a2.reset(202)
+  s1, s2 = a1.get_simulator_state().balloon_state, a2.get_simulator_state().balloon_state
+  assert s1.x != s2.x and s1.y != s2.y
+  a1.reset()                                                                          # random seed: no exception
+
+
+@pytest.mark.parametrize('seed', [1, 5, 28, 90, 106, 378])
+def test_arena_initial_conditions(mods, seed):
+  arena = create_arena(mods)
+  arena.reset(seed)
+  s = arena.get_simulator_state().balloon_state
+  assert units.relative_distance(s.x, s.y).km <= 200.0
+  assert constants.PERCIATELLI_PRESSURE_RANGE_MIN <= s.pressure <= constants.PERCIATELLI_PRESSURE_RANGE_MAX
+
+
+def test_env_observation_space_matches_observation(mods):
+  _, balloon_env, _, wind_field = mods
+  env = balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=0)
+  shape = env.observation_space.sample().shape
+  assert env.reset().shape == shape
+  rng = random.Random(0)
+  for _ in range(100):
+    obs, _, terminal, _ = env.step(rng.randrange(3))
+    assert obs.shape == shape
+    if terminal:
+      env.reset()
+
+
+def test_env_out_of_power(mods):
+  _, balloon_env, _, wind_field = mods
+  env = balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=0)
+  st = env.arena.get_balloon_state()
+  st.date_time = units.datetime(2021, 9, 9, 0)          # night
+  st.time_elapsed = dt.timedelta()
+  st.sunrise_with_hysteresis = st.sunset = None         # re-derived for the new date
+  env.arena.set_balloon_state(st)
+  rng = random.Random(1)
+  for _ in range(10):
+    st = env.arena.get_balloon_state()
+    st.battery_charge = st.battery_capacity * 1.0
+    env.arena.set_balloon_state(st)
+    _, _, terminal, info = env.step(rng.randrange(3))
+    assert not terminal and not info['out_of_power']
+  st = env.arena.get_balloon_state()
+  st.battery_charge = st.battery_capacity * 1e-7
+  env.arena.set_balloon_state(st)
+  _, _, terminal, info = env.step(rng.randrange(3))
+  assert terminal and info['out_of_power']
+  with pytest.raises(AssertionError):                   # balloon.py:288-290
+    env.step(1)
+
+
+def test_env_time_elapsed_and_static_wind_drift(mods):
+  _, balloon_env, _, _ = mods
+  arena = create_arena(mods, seed=1)
+  env = balloon_env.BalloonEnv(arena=arena, seed=1)
+  elapsed = dt.timedelta()
+  s0 = env.get_simulator_state().balloon_state
+  band = int(s0.pressure >= 8000) + int(s0.pressure >= 10000) + int(s0.pressure >= 12000)
+  for _ in range(10):
+    before = env.get_simulator_state().balloon_state
+    _, _, _, info = env.step(1)
+    after = env.get_simulator_state().balloon_state
+    elapsed += constants.AGENT_TIME_STEP
+    assert info['time_elapsed'] == elapsed
+    # the sheet the balloon was in at the start of the step moves it 10 m/s * 180 s (fp32 position)
+    b = int(before.pressure >= 8000) + int(before.pressure >= 10000) + int(before.pressure >= 12000)
+    du, dv = ((1800.0, 0.0), (0.0, 1800.0), (-1800.0, 0.0), (0.0, -1800.0))[b]
+    assert abs((after.x.m - before.x.m) - du) < 0.05 and abs((after.y.m - before.y.m) - dv) < 0.05
+  del band
+
+
+def test_env_seeding_trajectories(mods):
+  _, balloon_env, _, wind_field = mods
+  mk = lambda seed: balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=seed)
+  e1, e2 = mk(123), mk(123)
+  assert floats_of(e1.get_simulator_state().balloon_state) == floats_of(e2.get_simulator_state().balloon_state)
+  assert floats_of(mk(124).get_simulator_state().balloon_state) != floats_of(mk(125).get_simulator_state().balloon_state)
+  e1, e2 = mk(1), mk(1)
+  for action in (0, 0, 0, 2, 2, 2, 2, 1, 1, 1, 1, 0):
+    o1, *_ = e1.step(action); o2, *_ = e2.step(action)
+    np.testing.assert_array_equal(o1, o2)
+  assert floats_of(e1.get_simulator_state().balloon_state) == floats_of(e2.get_simulator_state().balloon_state)
+
+
+def test_feature_driven_controller_beats_random(mods):
+  """End-to-end use of the observation: a greedy controller that reads the wind column
+  (NamedPerciatelliFeatures) and moves toward the reachable level with the smallest bearing
+  error must collect more reward than a random policy in the four-sheet wind field."""
+  _, balloon_env, features, wind_field = mods
+
+  def run(policy, seed):
+    env = balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=seed)
+    obs, total = env.reset(), 0.0
+    for _ in range(120):
+      obs, r, terminal, _ = env.step(policy(obs))
+      total += r
+      if terminal:
+        break
+    return total
+
+  def greedy(obs):
+    named = features.NamedPerciatelliFeatures(obs)
+    mid = named.wind_column_center()
+    valid = [l for l in range(named.num_pressure_levels) if named.level_is_valid(l)]
+    best = min(valid, key=lambda l: (named.bearing(l), abs(l - mid)))
+    return 2 if best < mid else (0 if best > mid else 1)
+
+  rng = random.Random(3)
+  seeds = (11, 12, 13)
+  assert sum(run(greedy, s) for s in seeds) > sum(run(lambda o: rng.randrange(3), s) for s in seeds)
