@@ -468,12 +468,12 @@ def f10_reset():
 
 
 # ----------------------------------------------------------------------------- F11
-def f11_features(n_env=3, n_steps=45):
+def f11_features(n_env=3, n_steps=45, name='f11_features', rng_seed=11, keep_last=None):
   """PerciatelliFeatureConstructor (env/features.py:270-581) driven like BalloonArena: observe()
   after every simulate_step, get_features().  The 'measured' wind is forecast + a smooth
   pseudo-noise so that the WindGP (env/wind_gp.py) has non-zero errors to model."""
   from balloon_learning_environment.env import features
-  rng = np.random.default_rng(11)
+  rng = np.random.default_rng(rng_seed)
   field = make_field(0)
   feats = np.zeros((n_env, n_steps + 1, 1099), np.float32)
   cols = {k: np.zeros((n_env, n_steps + 1)) for k in STATE_FLOATS}
@@ -514,10 +514,18 @@ def f11_features(n_env=3, n_steps=45):
       snap = snapshot(b.state, su)
       for k in SNAP_KEYS:
         cols[k][j, i] = snap[k]
-  save('f11_features', field_seed=np.int64(0), field_scale=np.float64(5.0), features=feats, wind_measured=wind_meas,
+  if keep_last is not None:       # long runs: keep the feature vectors of the last steps only
+    feats = feats[:, -keep_last:]
+  save(name, field_seed=np.int64(0), field_scale=np.float64(5.0), features=feats, wind_measured=wind_meas,
        actions=actions, start_unix=start_unix, **consts, **cols)
+
+
+def f12_features_long():
+  """As F11 but 135 steps (> the WindGP's 6 h / 120-observation horizon, wind_gp.py:179-185):
+  pins the dropping of old observations.  Only the last 16 feature vectors are stored."""
+  f11_features(n_env=1, n_steps=135, name='f12_features_long', rng_seed=12, keep_last=16)
 
 
 if __name__ == '__main__':
   f1_atmosphere(); f2_solar(); f3_thermal(); f4_sp_volume(); f5_acs_power_table(); f6_safety(); f7_wind()
-  f8_trajectories(); f9_arena(); f10_reset(); f11_features()
+  f8_trajectories(); f9_arena(); f10_reset(); f11_features(); f12_features_long()

@@ -56,3 +56,21 @@ def traj_state_at(d, step, rows=None):
     st[k][:] = d[k][rows]
   st['start_unix'][:] = d['start_unix'][rows]
   return st
+
+
+def feature_row(g, j, i):
+  """Row dict (fields of ble_state_f32, float64) of env j at step i of a features fixture (F11/F12)."""
+  row = {k: float(g[k][j, i]) for k in STATE_FLOATS}
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+    row[k] = int(g[k][j, i])
+  for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+    row[k] = float(g[k][j])
+  row['start_unix'] = int(g['start_unix'][j])
+  row['sunrise_h_rel'] = int(g['sunrise_h'][j, i] - g['start_unix'][j])
+  row['sunset_rel'] = int(g['sunset'][j, i] - g['start_unix'][j])
+  return row
+
+
+def fixture_field(g):
+  import numpy as np
+  return (np.random.default_rng(int(g['field_seed'])).standard_normal((21, 21, 10, 9, 2)) * float(g['field_scale'])).astype(np.float32)

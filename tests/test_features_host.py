@@ -332,3 +332,10 @@ def test_ref_simple_static_wind_field():
   pressures = [6000.0, 9000.0, 11000.0, 13000.0]
   assert wf.get_forecast_column(zero, zero, pressures, t0) == [wf.get_forecast(zero, zero, p, t0) for p in pressures]
   assert wf.get_ground_truth(zero, zero, 9000.0, t0) == wf.get_forecast(zero, zero, 9000.0, t0)
+
+
+def test_perciatelli_features_long_horizon():
+  """F12: 136 observations -- the WindGP must drop those older than 6 h (wind_gp.py:179-185)."""
+  g = helpers.golden('f12_features_long')
+  got = run_constructor(g, OracleForecast(field_of(g)), 0, n_steps=g['x'].shape[1])
+  np.testing.assert_allclose(got[-16:], g['features'][0], rtol=0, atol=ATOL)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
+import helpers
 from helpers import (STATE_FLOATS, STATE_INTS, STATE_U8, golden, known_answers, traj_state_at, unix)
 
 KA = known_answers()
@@ -336,3 +337,34 @@ def test_f10_stable_init_and_sunrise():
     np.testing.assert_allclose(v, d[k], rtol=1e-9, atol=1e-9, err_msg=k)
   sr, ss = oracle.next_sunrise_sunset(d['balloon_lat_rad'], d['balloon_lng_rad'], d['unix_s'])
   np.testing.assert_array_equal(sr, d['sunrise']); np.testing.assert_array_equal(ss, d['sunset'])
+
+
+# ---------------------------------------------------------------------------------------------
+# Observation path oracle (oracle/features_oracle.py) vs the reference's own feature vectors.
+def _oracle_features(name, j, keep_last=None):
+  import features_oracle
+  g = helpers.golden(name)
+  field = helpers.fixture_field(g)
+  fo = features_oracle.FeatureOracle(field, g['alpha'][j])
+  n = g['x'].shape[1]
+  out = []
+  for i in range(n):
+    row = helpers.feature_row(g, j, i)
+    fu, fv = oracle.wind_forecast(field, row['x'], row['y'], row['pressure'], row['time_elapsed_s'])
+    fo.observe(row, (g['wind_measured'][j, i, 0] - fu[0], g['wind_measured'][j, i, 1] - fv[0]))
+    if keep_last is None or i >= n - keep_last:
+      out.append(fo.features())
+  return np.array(out), g['features'][j]
+
+
+@pytest.mark.parametrize('j', [0, 1, 2])
+def test_feature_oracle_matches_reference(j):
+  got, want = _oracle_features('f11_features', j)
+  assert got.shape == want.shape
+  np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+
+def test_feature_oracle_long_horizon():
+  """136 observations: the 6 h window (120 observations) must drop the oldest ones."""
+  got, want = _oracle_features('f12_features_long', 0, keep_last=16)
+  np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
