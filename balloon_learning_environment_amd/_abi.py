@@ -38,3 +38,9 @@ def state_struct(pointers):
   for name, _, ct in STATE_FIELDS:
     setattr(st, name, ctypes.cast(ctypes.c_void_p(int(pointers[name])), ctypes.POINTER(ct)))
   return st
+
+
+class BleGpHistoryF32(ctypes.Structure):
+  """struct ble_gp_history_f32."""
+  _fields_ = [('xyp', ctypes.POINTER(ctypes.c_float)), ('elapsed_s', ctypes.POINTER(ctypes.c_int32)),
+              ('err_uv', ctypes.POINTER(ctypes.c_float)), ('count', ctypes.POINTER(ctypes.c_int32))]

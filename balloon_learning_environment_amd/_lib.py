@@ -24,9 +24,11 @@ _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 ABI_VERSION = 1
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
+FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH = 64, 128
+OBS_DIM, GP_CAPACITY = 1099, 128
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_forecast_f32',
+EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_forecast_f32',
            'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_f64_prims')
 
@@ -77,6 +79,7 @@ def lib():
   l.ble_step_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]
   l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
   l.ble_reset_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
+  l.ble_observe_f32.argtypes = [st, _vp, _i64, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
   l.ble_forecast_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_forecast_column_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]

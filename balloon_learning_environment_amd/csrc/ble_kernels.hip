@@ -13,6 +13,7 @@
 #include "../../include/ble_abi.h"
 #include "ble_reset.h"
 #include "ble_step_core.h"
+#include "ble_observe.h"
 
 using namespace ble;
 
@@ -439,6 +440,20 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(ble_forecast_column_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, wind_grid,
                      grid_env_stride, x_m, y_m, elapsed_s, levels_pa, n_levels, out_uv, n);
+  return launch_status();
+}
+
+int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride, const float* noise_uv,
+                    const uint8_t* reset_mask, const ble_gp_history_f32* hist, int append, float* obs,
+                    uint32_t* err_flags, int64_t n, void* stream) {
+  if (!state_ok(st) || !wind_grid || !hist || !hist->xyp || !hist->elapsed_s || !hist->err_uv || !hist->count || !obs ||
+      n < 0 || grid_env_stride < 0)
+    return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  GpHistory h;
+  h.xyp = hist->xyp; h.elapsed_s = hist->elapsed_s; h.err_uv = hist->err_uv; h.count = hist->count;
+  BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, *st, wind_grid,
+             grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
   return launch_status();
 }
 

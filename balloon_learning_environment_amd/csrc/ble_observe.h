@@ -1,0 +1,422 @@
+// Batched observation: PerciatelliFeatureConstructor (env/features.py:269-581) for N
+// environments on the device -- one workgroup (4 waves) per environment.
+//
+//   history    ring of the last 128 (x, y, p, t; err_u, err_v) observations per env in HBM
+//   phase 0    append the new observation, compact the <= 120 observations of the 6 h window
+//              (wind_gp.py:179-185) into LDS; 721-entry solar-elevation table (fp64) filled by
+//              all lanes; T(p) at the 20 search levels; the (x, y, t)-blended pressure column
+//   phase 1    lane 0: sunrise/sunset searches on the table -> 16 ambient features
+//              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) for the
+//                      reachable pressure range (pressure_range_builder.py:203-275)
+//              waves 2-3: K = s^2 exp(-|d/ls|) + 0.05 I, packed lower triangle in LDS (fp64)
+//   phase 2    right-looking Cholesky of K in LDS (sklearn GaussianProcessRegressor.fit)
+//   phase 3    alpha = K^-1 y (two right-hand sides), one wave
+//   phase 4    181 query levels in 3 chunks of 64: V = L^-1 K*^T by forward substitution,
+//              4 lanes per query; mean = K* alpha + forecast, deviation = (s^2 - |v|^2) / s^2
+//   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
+//
+// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (L) + 62 KB (V)
+// + 7 KB -- one workgroup per CU.
+#pragma once
+#include "ble_reset.h"
+
+namespace ble {
+
+constexpr int kObsLevels = 181;
+constexpr int kObsColumn = 2 * kObsLevels - 1;      // 361
+constexpr int kObsDim = 3 * kObsColumn + 16;        // 1099
+constexpr int kGpCapacity = 128;                    // ring entries per env (BLE_GP_CAPACITY)
+constexpr int kGpMax = 120;                         // 6 h / 180 s
+constexpr int kObsBlock = 256;
+constexpr int kQueryChunk = 64;
+constexpr int kVStride = kGpMax + 1;
+constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
+constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
+constexpr double kGpNoise2 = 0.05;                  // wind_gp.py:37
+constexpr int kGpHorizonS = 6 * 3600;               // wind_gp.py:63
+constexpr uint32_t kFlagGpWindow = 64u;             // more than 120 observations inside 6 h
+constexpr uint32_t kFlagPressureSearch = 128u;      // pressure_range_builder raised ValueError
+
+struct GpHistory {
+  float* xyp;          // [n][128][3]
+  int32_t* elapsed_s;  // [n][128]
+  float* err_uv;       // [n][128][2]
+  int32_t* count;      // [n]
+};
+
+struct ObsShared {
+  double L[kGpMax * (kGpMax + 1) / 2];
+  double V[kQueryChunk * kVStride];      // phases 0-1: elevation table [721]
+  double loc[kGpMax][4];                 // x, y, p, t of the observations in the window
+  double a[kGpMax];                      // scaled squared (x, y, t) distance to the query column
+  double rhs[kGpMax][2];                 // errors, then alpha
+  double lev[20], pot[20], sp[22];
+  double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
+  float column[20];
+  int wave_count[2];
+  int n_obs;
+  int range_ok;
+};
+
+BLE_FN int tri(int i) { return i * (i + 1) / 2; }
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// interp1d(p/T -> p, linear, extrapolating) at the float ceiling (pressure_range_builder.py:236-247)
+__device__ inline double pressure_ceiling(const double* lev, const double* pot) {
+  const double target = (92.5 + 68.5 + 6830.0 * kHeMolarMassD) * kGasConstantD / (kAirMolarMassD * 1804.0);
+  int i = 0;
+  while (i < 20 && pot[i] < target) ++i;      // searchsorted(side='left')
+  i = i < 1 ? 1 : (i > 19 ? 19 : i);
+  const double slope = (lev[i] - lev[i - 1]) / (pot[i] - pot[i - 1]);
+  return slope * (target - pot[i - 1]) + lev[i - 1];
+}
+
+// _search_for_safe_pressure (:111-182) over superpressures that are already solved.
+__device__ inline double safe_pressure_search(const double* lev, const double* sp, double significant, double sp_sig,
+                                              bool upward, int* ok) {
+  const double lo = 250.0, hi = 2380.0 - 250.0;
+  if (sp_sig >= lo && sp_sig <= hi) return significant;
+  double last_p = significant, last_sp = sp_sig;
+  for (int n = 0; n < 20; ++n) {
+    const int k = upward ? n : 19 - n;
+    const double p = lev[k];
+    if (upward ? (p < significant) : (p > significant)) continue;
+    const double s = sp[k];
+    if (s > hi || s < lo) { last_p = p; last_sp = s; continue; }
+    // _compute_safe_pressure (:73-108): p1 < p2
+    const double p1 = upward ? last_p : p, s1 = upward ? last_sp : s;
+    const double p2 = upward ? p : last_p, s2 = upward ? s : last_sp;
+    double target;
+    if ((s1 < lo) != (s2 < lo)) target = lo;
+    else if ((s1 > hi) != (s2 > hi)) target = hi;
+    else { *ok = 0; return significant; }
+    if (!(p1 < p2) || s1 == s2) { *ok = 0; return significant; }
+    return fabs((target - s1) / (s2 - s1)) * (p2 - p1) + p1;
+  }
+  *ok = 0;
+  return significant;
+}
+
+__global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st, const float* __restrict__ wind_grid,
+                                                                int64_t grid_env_stride,
+                                                                const float* __restrict__ noise_uv,
+                                                                const uint8_t* __restrict__ reset_mask, GpHistory hist,
+                                                                int append, float* __restrict__ obs,
+                                                                uint32_t* err_flags, int64_t n) {
+  __shared__ ObsShared sh;
+  const int64_t env = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint32_t flags = 0;
+
+  // ---- state of this environment (uniform loads)
+  const float xf = st.x[env], yf = st.y[env], pf = st.pressure[env];
+  const int32_t elapsed = st.time_elapsed_s[env];
+  const int64_t now = st.start_unix[env] + (int64_t)elapsed;
+  const double alpha = (double)st.alpha[env];
+  const double x = (double)xf, y = (double)yf, p = (double)pf;
+  float* out = obs + env * kObsDim;
+
+  SunSite site;
+  latlng_f64((double)st.center_lat_deg[env], (double)st.center_lng_deg[env], x, y, &site.sin_lat, &site.cos_lat,
+             &site.lng_deg);
+
+  // ---- phase 0a: history ring
+  int count = hist.count[env];
+  if (reset_mask != nullptr && reset_mask[env] != 0) count = 0;
+  const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
+  float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
+  int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
+  float* h_err = hist.err_uv + env * (kGpCapacity * 2);
+  if (append) {
+    if (tid == 0) {
+      const int slot = count % kGpCapacity;
+      h_xyp[slot * 3] = xf; h_xyp[slot * 3 + 1] = yf; h_xyp[slot * 3 + 2] = pf;
+      h_t[slot] = elapsed;
+      h_err[slot * 2] = err_u; h_err[slot * 2 + 1] = err_v;
+    }
+    count += 1;
+  }
+  const int m = count < kGpCapacity ? count : kGpCapacity;
+  bool valid = false;
+  float ox = 0, oy = 0, op = 0, oeu = 0, oev = 0;
+  int32_t ot = 0;
+  if (tid < kGpCapacity && tid < m) {
+    if (append && tid == m - 1) {          // the entry lane 0 is writing right now
+      ox = xf; oy = yf; op = pf; ot = elapsed; oeu = err_u; oev = err_v;
+    } else {
+      const int slot = (count - m + tid) % kGpCapacity;
+      ox = h_xyp[slot * 3]; oy = h_xyp[slot * 3 + 1]; op = h_xyp[slot * 3 + 2];
+      ot = h_t[slot]; oeu = h_err[slot * 2]; oev = h_err[slot * 2 + 1];
+    }
+    const int32_t age = ot > elapsed ? ot - elapsed : elapsed - ot;
+    valid = age < kGpHorizonS;             // strict, wind_gp.py:183
+  }
+  int pos = 0;
+  if (wave < 2) {
+    const unsigned long long ballot = __ballot(valid);
+    pos = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) sh.wave_count[wave] = __popcll(ballot);
+  }
+
+  // ---- phase 0b: solar elevation table, search levels, pressure column
+  double* el_table = sh.V;
+  for (int k = tid; k < kElevTable; k += kObsBlock) {
+    double flux;
+    const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, now + 180 * (int64_t)(k - 240), &flux);
+    el_table[k] = el;
+    if (k == 240) { sh.el_now = el; sh.flux_now = flux; }
+  }
+  if (tid == kObsBlock - 1) sh.el_next = site_elevation(site, now + 1);
+  const double l0 = atm_lapse_f64(0, alpha);
+  const double p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
+  if (wave == 3 && lane < 20) {
+    // np.linspace(1000, p_floor, 20); p / T(p) at each level (pressure_range_builder.py:222-235)
+    const double level = lane == 19 ? p_floor : 1000.0 + (double)lane * ((p_floor - 1000.0) / 19.0);
+    const AtmWindow w = atm_window(alpha, level, &flags);
+    double h, t;
+    atm_at_pressure_f64(w, alpha, level, &h, &t);
+    sh.lev[lane] = level; sh.pot[lane] = level / t;
+  }
+  if (wave == 2 && lane < 20) {
+    // get_forecast_column: blend (x, y, t) first, pressure afterwards (grid_based_wind_field.py:96-132)
+    const WindQuery wq = wind_query(xf, yf, 5000.0f, elapsed);
+    const float* grid = wind_grid + env * grid_env_stride;
+    const int ip = lane >> 1, comp = lane & 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
+          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
+        }
+    sh.column[lane] = acc;
+  }
+  __syncthreads();   // B1
+
+  // ---- phase 0c: compact the window into LDS (chronological)
+  int n_obs = sh.wave_count[0] + sh.wave_count[1];
+  int drop = 0;
+  if (n_obs > kGpMax) { drop = n_obs - kGpMax; n_obs = kGpMax; flags |= kFlagGpWindow; }
+  if (wave < 2 && valid) {
+    const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
+    if (at >= 0) {
+      sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op; sh.loc[at][3] = (double)ot;
+      sh.rhs[at][0] = (double)oeu; sh.rhs[at][1] = (double)oev;
+      const double dx = ((double)ox - x) / 357000.0, dy = ((double)oy - y) / 357000.0,
+                   dt = ((double)ot - (double)elapsed) / 34560.0;
+      sh.a[at] = dx * dx + dy * dy + dt * dt;
+    }
+  }
+  const double el_now = sh.el_now, flux_now = sh.flux_now;
+  __syncthreads();   // B2
+
+  // ---- phase 1: three roles
+  if (tid == 0) {
+    // -- ambient features (features.py:400-470)
+    auto elev = [&](int64_t when) {
+      const int64_t k = (when - now) / 180 + 240;
+      return (k >= 0 && k < kElevTable && (when - now) % 180 == 0) ? el_table[k] : site_elevation(site, when);
+    };
+    int64_t sunrise, sunset;
+    next_sunrise_sunset_from(elev, sh.el_next < el_now, now, &sunrise, &sunset);
+    double cycle;
+    if (sunset < sunrise) {   // day
+      const int64_t prev = sunrise - 86400;
+      cycle = kPiD * (double)(now - prev) / (double)(sunset - prev);
+    } else {
+      const int64_t prev = sunset - 86400;
+      cycle = kPiD + kPiD * (double)(now - prev) / (double)(sunrise - prev);
+    }
+    double sc, cc;
+    sincos_f64(cycle, &sc, &cc);
+    const double batt = (double)st.battery_charge[env], soc = batt / 3058.56;
+    const double dist = sqrt(x * x + y * y);
+    const double sp_now = (double)st.superpressure[env];
+    const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) / p;
+    const int cmd = st.last_command[env];
+    const bool paused = st.power_paused[env] != 0 || st.env_fsm[env] != 0 || st.alt_fsm[env] != 0;
+    auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+    out[0] = (float)unit((p - 5000.0) / 9000.0);
+    out[1] = (float)soc;
+    out[2] = (float)unit((el_now + 90.0) / 180.0);
+    out[3] = (float)sc; out[4] = (float)cc;
+    out[5] = (float)(dist > 0.0 ? -x / dist : 0.0);        // sin(atan2(-x, -y))
+    out[6] = (float)(dist > 0.0 ? -y / dist : -1.0);       // cos(atan2(-x, -y)); atan2(-0, -0) = -pi
+    out[7] = (float)((dist / 1000.0) / (dist / 1000.0 + 250.0));
+    out[8] = cmd == kUp ? 1.0f : 0.0f; out[9] = cmd == kStay ? 1.0f : 0.0f; out[10] = cmd == kDown ? 1.0f : 0.0f;
+    out[11] = paused ? 1.0f : 0.0f; out[12] = paused ? 0.0f : 1.0f;
+    out[13] = (solar_power_f64(el_now, p) > 120.4 && soc > 0.99) ? 1.0f : 0.0f;     // balloon.py:231-238
+    out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) / 200.0);
+    out[15] = (float)ratio;
+  } else if (wave == 1) {
+    if (lane < 22) {
+      const double ceiling = pressure_ceiling(sh.lev, sh.pot);
+      const double level = lane < 20 ? sh.lev[lane] : (lane == 20 ? ceiling : p_floor);
+      uint32_t local = 0;
+      const StableParams s = stable_params(alpha, level, el_now, flux_now, (double)st.upwelling_infrared[env], &local);
+      sh.sp[lane] = s.sp;
+      flags |= local;
+    }
+  } else if (wave >= 2) {
+    // -- K + noise, packed lower triangle
+    const int total = tri(n_obs);
+    for (int e = tid - 128; e < total; e += 128) {
+      int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (tri(i) > e) --i;
+      while (tri(i + 1) <= e) ++i;
+      const int j = e - tri(i);
+      const double d0 = (sh.loc[i][0] - sh.loc[j][0]) / 357000.0, d1 = (sh.loc[i][1] - sh.loc[j][1]) / 357000.0,
+                   d2 = (sh.loc[i][2] - sh.loc[j][2]) / 326.0, d3 = (sh.loc[i][3] - sh.loc[j][3]) / 34560.0;
+      const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+      sh.L[e] = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
+    }
+  }
+  __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
+
+  // ---- reachable pressure range (pressure_range_builder.py:249-275)
+  if (tid == 0) {
+    int ok = 1;
+    const double ceiling = pressure_ceiling(sh.lev, sh.pot);
+    sh.p_lo = safe_pressure_search(sh.lev, sh.sp, ceiling, sh.sp[20], true, &ok);
+    sh.p_hi = safe_pressure_search(sh.lev, sh.sp, p_floor, sh.sp[21], false, &ok);
+    sh.range_ok = ok;
+  }
+
+  // ---- phase 2: Cholesky, right-looking, in place
+  for (int k = 0; k < n_obs; ++k) {
+    const int kk = tri(k) + k;
+    if (tid == 0) sh.L[kk] = sqrt(sh.L[kk]);
+    __syncthreads();
+    const double inv = 1.0 / sh.L[kk];
+    const int rows = n_obs - k - 1;
+    for (int r = tid; r < rows; r += kObsBlock) sh.L[tri(k + 1 + r) + k] *= inv;
+    __syncthreads();
+    const int total = tri(rows);
+    for (int e = tid; e < total; e += kObsBlock) {
+      int r = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (tri(r) > e) --r;
+      while (tri(r + 1) <= e) ++r;
+      const int c = e - tri(r);
+      const int i = k + 1 + r, j = k + 1 + c;
+      sh.L[tri(i) + j] = d_fma(-sh.L[tri(i) + k], sh.L[tri(j) + k], sh.L[tri(i) + j]);
+    }
+    // the next iteration's first barrier orders these updates before its reads
+    if (k + 1 < n_obs) __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- phase 3: alpha = K^-1 y, wave 0 (rows lane and lane + 64, both right-hand sides)
+  if (wave == 0) {
+    for (int j = 0; j < n_obs; ++j) {            // L z = y
+      const double inv = 1.0 / sh.L[tri(j) + j];
+      const double z0 = sh.rhs[j][0] * inv, z1 = sh.rhs[j][1] * inv;
+      wave_sync_lds();
+      if (lane == 0) { sh.rhs[j][0] = z0; sh.rhs[j][1] = z1; }
+      for (int i = j + 1 + lane; i < n_obs; i += 64) {
+        const double l = sh.L[tri(i) + j];
+        sh.rhs[i][0] = d_fma(-l, z0, sh.rhs[i][0]);
+        sh.rhs[i][1] = d_fma(-l, z1, sh.rhs[i][1]);
+      }
+      wave_sync_lds();
+    }
+    for (int j = n_obs - 1; j >= 0; --j) {       // L^T a = z
+      const double inv = 1.0 / sh.L[tri(j) + j];
+      const double a0 = sh.rhs[j][0] * inv, a1 = sh.rhs[j][1] * inv;
+      wave_sync_lds();
+      if (lane == 0) { sh.rhs[j][0] = a0; sh.rhs[j][1] = a1; }
+      for (int i = lane; i < j; i += 64) {
+        const double l = sh.L[tri(j) + i];
+        sh.rhs[i][0] = d_fma(-l, a0, sh.rhs[i][0]);
+        sh.rhs[i][1] = d_fma(-l, a1, sh.rhs[i][1]);
+      }
+      wave_sync_lds();
+    }
+  }
+  __syncthreads();
+
+  // ---- phases 4 + 5: the 181-level column, 3 chunks of 64 queries, 4 lanes per query
+  const double p_lo = sh.p_lo, p_hi = sh.p_hi;
+  if (sh.range_ok == 0) flags |= kFlagPressureSearch;
+  const double p_clamped = p < 5000.0 ? 5000.0 : (p > 14000.0 ? 14000.0 : p);
+  const int level_now = (int)d_rint((p_clamped - 5000.0) / 50.0);       // Python round(): half to even
+  const int pad_above = kObsLevels - level_now - 1;
+  const double dist = sqrt(x * x + y * y);
+  const double to_station_x = -x / (dist + 1e-5), to_station_y = -y / (dist + 1e-5);
+  const int qq = tid >> 2, part = tid & 3;
+  double* vrow = sh.V + qq * kVStride;
+  for (int chunk = 0; chunk < 3; ++chunk) {
+    const int q = chunk * kQueryChunk + qq;
+    const double level = 5000.0 + 50.0 * (double)q;
+    // k*(q, i) for the 16 queries of this wave
+    for (int i = part; i < n_obs; i += 4) {
+      const double dp = (level - sh.loc[i][2]) / 326.0;
+      vrow[i] = kGpSigma2 * d_exp_fast(-sqrt(sh.a[i] + dp * dp));
+    }
+    wave_sync_lds();
+    double mean_u = 0.0, mean_v = 0.0, ssq = 0.0;
+    for (int i = 0; i < n_obs; ++i) {
+      const double* lrow = sh.L + tri(i);
+      double partial = 0.0;
+      for (int j = part; j < i; j += 4) partial = d_fma(lrow[j], vrow[j], partial);
+      partial += __shfl_xor(partial, 1, 64);
+      partial += __shfl_xor(partial, 2, 64);
+      const double ks = vrow[i];
+      const double v = (ks - partial) / lrow[i];
+      mean_u = d_fma(ks, sh.rhs[i][0], mean_u);
+      mean_v = d_fma(ks, sh.rhs[i][1], mean_v);
+      ssq = d_fma(v, v, ssq);
+      wave_sync_lds();
+      if (part == 0) vrow[i] = v;
+      wave_sync_lds();
+    }
+    if (part == 0 && q < kObsLevels) {
+      float f0 = 0.0f, f1 = 1.0f, f2 = 1.0f;             // unreachable: certain, wrong way, infinitely fast
+      if (level >= p_lo && level <= p_hi) {
+        // forecast at this level from the blended column
+        int ip; float wp;
+        wind_axis((float)level, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
+        const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
+        const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
+        const double u = mean_u + (double)fu, v = mean_v + (double)fv;
+        double var = kGpSigma2 - ssq;
+        var = var < 0.0 ? 0.0 : var;
+        const double deviation = n_obs > 0 ? var / kGpSigma2 : 0.0;     // wind_gp.py:166-168
+        const double speed = sqrt(u * u + v * v);
+        double angle;
+        if (dist < 1e-5) {
+          angle = 0.0;
+        } else if (speed < 1e-5) {
+          angle = kPiD;
+        } else {
+          double c = (u * to_station_x + v * to_station_y) / (speed + 1e-5);
+          c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+          angle = kPiD / 2 - d_asin(c);
+        }
+        f0 = (float)deviation; f1 = (float)(angle / kPiD); f2 = (float)(speed / (speed + 30.0));
+      }
+      float* o = out + 16 + 3 * (pad_above + q);
+      o[0] = f0; o[1] = f1; o[2] = f2;
+    }
+    wave_sync_lds();
+  }
+  // padding above and below the 181 real levels
+  for (int c = tid; c < kObsColumn; c += kObsBlock) {
+    if (c < pad_above || c >= pad_above + kObsLevels) {
+      float* o = out + 16 + 3 * c;
+      o[0] = 0.0f; o[1] = 1.0f; o[2] = 1.0f;
+    }
+  }
+  // every lane has read the old count long before this point (barriers above)
+  if (tid == 0) hist.count[env] = count;
+  if (err_flags != nullptr && flags != 0) atomicOr(err_flags, flags);
+}
+
+}  // namespace ble

@@ -907,9 +907,8 @@ BLE_FN float acs_efficiency(const float* tab, float prm1, float power) {
 }
 
 // power_table.lookup (power_table.py:21-38)
-BLE_FN float power_table_lookup(float pr, float soc, uint32_t* flags) {
-  if (!(pr >= 0.99f && pr <= 5.0f)) *flags |= kFlagPowerTable;
-  const double prd = pr, s = soc;  // compare against the reference's double literals
+BLE_FN float power_table_lookup_f64(double prd, double s, uint32_t* flags) {
+  if (!(prd >= 0.99 && prd <= 5.0)) *flags |= kFlagPowerTable;
   int i = (prd >= 1.08) + (prd >= 1.11) + (prd >= 1.14) + (prd >= 1.17) + (prd >= 1.2) + (prd >= 1.23) + (prd >= 1.26);
   double e0, e1, e2; float w1, w2, w3;
   switch (i) {
@@ -924,6 +923,12 @@ BLE_FN float power_table_lookup(float pr, float soc, uint32_t* flags) {
   }
   int j = (s >= e0) + (s >= e1) + (s >= e2);
   return j == 0 ? 0.0f : (j == 1 ? w1 : (j == 2 ? w2 : w3));
+}
+BLE_FN float power_table_lookup(float pr, float soc, uint32_t* flags) {
+  // thresholds are compared in fp64 against the reference's double literals
+  if (!(pr >= 0.99f && pr <= 5.0f)) *flags |= kFlagPowerTable;
+  uint32_t ignored = 0;
+  return power_table_lookup_f64((double)pr, (double)soc, &ignored);
 }
 
 // ---------------------------------------------------------------- reward

@@ -126,12 +126,16 @@ struct SunSite { double sin_lat, cos_lat, lng_deg; };
 BLE_FN double site_elevation(const SunSite& g, int64_t t) {
   return solar_elevation_f64(g.sin_lat, g.cos_lat, g.lng_deg, t, nullptr);
 }
-// solar._find_solar_elevation_binary_search (solar.py:295-372); mode 0 min, 1 max, 2 |el - target|
-BLE_FN int64_t find_solar_elevation(const SunSite& g, int64_t min_t, int64_t max_t, int mode, double target) {
+// solar._find_solar_elevation_binary_search (solar.py:295-372); mode 0 min, 1 max, 2 |el - target|.
+// `elev(t)` returns the elevation [deg] at unix time t: evaluated directly (reset kernel) or
+// looked up in a table that a whole workgroup filled in parallel (observation kernel) -- every
+// time the search touches is start + 180 s * integer.
+template <class Elev>
+BLE_FN int64_t find_solar_elevation(const Elev& elev, int64_t min_t, int64_t max_t, int mode, double target) {
   const int64_t dt = 180;
   int64_t low = 0, high = (max_t - min_t) / dt;
   auto obj = [&](int64_t idx) {
-    const double el = site_elevation(g, min_t + dt * idx);
+    const double el = elev(min_t + dt * idx);
     return mode == 0 ? el : (mode == 1 ? -el : fabs(el - target));
   };
   double ol = obj(low), oh = obj(high);
@@ -143,19 +147,35 @@ BLE_FN int64_t find_solar_elevation(const SunSite& g, int64_t min_t, int64_t max
   }
   return min_t + dt * ((ol < oh) ? low : high);
 }
-// solar.get_next_sunrise_sunset (solar.py:432-483)
-BLE_FN void next_sunrise_sunset(const SunSite& g, int64_t t, int64_t* sunrise, int64_t* sunset) {
+// solar.get_next_sunrise_sunset (solar.py:432-483); `afternoon` = el(t + 1 s) < el(t) (:239-256)
+template <class Elev>
+BLE_FN void next_sunrise_sunset_from(const Elev& elev, bool afternoon, int64_t t, int64_t* sunrise, int64_t* sunset) {
   const int64_t h12 = 12 * 3600, h24 = 24 * 3600;
-  const bool afternoon = site_elevation(g, t + 1) < site_elevation(g, t);   // :239-256
-  const int64_t noon = afternoon ? find_solar_elevation(g, t + h12, t + h24, 1, 0.0)
-                                 : find_solar_elevation(g, t, t + h12, 1, 0.0);
-  const int64_t midnight = afternoon ? find_solar_elevation(g, t, t + h12, 0, 0.0)
-                                     : find_solar_elevation(g, t + h12, t + h24, 0, 0.0);
-  int64_t sr = find_solar_elevation(g, afternoon ? midnight : midnight - h24, noon, 2, -4.242);
-  int64_t ss = find_solar_elevation(g, afternoon ? noon - h24 : noon, midnight, 2, -4.242);
+  const int64_t noon = afternoon ? find_solar_elevation(elev, t + h12, t + h24, 1, 0.0)
+                                 : find_solar_elevation(elev, t, t + h12, 1, 0.0);
+  const int64_t midnight = afternoon ? find_solar_elevation(elev, t, t + h12, 0, 0.0)
+                                     : find_solar_elevation(elev, t + h12, t + h24, 0, 0.0);
+  int64_t sr = find_solar_elevation(elev, afternoon ? midnight : midnight - h24, noon, 2, -4.242);
+  int64_t ss = find_solar_elevation(elev, afternoon ? noon - h24 : noon, midnight, 2, -4.242);
   if (sr < t) sr += h24;
   if (ss < t) ss += h24;
   *sunrise = sr; *sunset = ss;
+}
+BLE_FN void next_sunrise_sunset(const SunSite& g, int64_t t, int64_t* sunrise, int64_t* sunset) {
+  auto elev = [&](int64_t when) { return site_elevation(g, when); };
+  next_sunrise_sunset_from(elev, site_elevation(g, t + 1) < site_elevation(g, t), t, sunrise, sunset);
+}
+
+// solar.solar_power (solar.py:515-536) in fp64; shadow thresholds are
+// degrees(atan2(sqrt(h (10.41603 + h)), 8.69275)) for the panels 3.3 m and 2.7 m below the envelope.
+BLE_FN double solar_attenuation_f64(double el_deg, double p);
+BLE_FN double solar_power_f64(double el_deg, double p) {
+  double s35, c35, s65, c65;
+  sincos_f64((el_deg - 35.0) * (kPiD / 180.0), &s35, &c35);
+  sincos_f64((el_deg - 65.0) * (kPiD / 180.0), &s65, &c65);
+  const double shadow_a = el_deg >= 37.738149050524044 ? 0.4392 : 1.0;
+  const double shadow_b = el_deg >= 34.39486500086289 ? 0.4392 : 1.0;
+  return 210.0 * solar_attenuation_f64(el_deg, p) * (4 * c35 * shadow_a + 2 * c65 * shadow_b);
 }
 
 // ---------------------------------------------------------------- cold start (stable_init.py:40-129)

@@ -36,6 +36,10 @@ def raise_for_flags(flags: int) -> None:
     raise AssertionError('power_table.lookup: pressure_ratio out of [0.99, 5]')
   if flags & _lib.FLAG_NONFINITE:
     raise FloatingPointError('non-finite balloon state')
+  if flags & _lib.FLAG_PRESSURE_SEARCH:
+    raise ValueError('Unable to find safe pressure for balloon.')       # pressure_range_builder.py:180-182
+  if flags & _lib.FLAG_GP_WINDOW:
+    raise OverflowError('WindGP window holds more than 120 observations (agent steps shorter than 180 s)')
 
 
 class VecSimulator:
@@ -58,6 +62,8 @@ class VecSimulator:
     self.grid: Optional[torch.Tensor] = None
     self.grid_env_stride = 0
     self._struct = dev.state_struct(self.state)
+    self._gp = None                 # WindGP history ring (allocated by the first observe())
+    self._obs_reset = None          # envs whose history must restart at the next observe()
 
   # ------------------------------------------------------------------ data in / out
   def set_state(self, arrays: Dict[str, np.ndarray]) -> None:
@@ -93,6 +99,50 @@ class VecSimulator:
                                   self.episode.data_ptr(), 1 if sample else 0, self.err_flags.data_ptr(), self.n,
                                   dev.stream_ptr(self.device))
     _lib.check(code, 'ble_reset_f32')
+    if self._gp is not None:        # a new episode gets a new feature constructor (balloon_arena.py:171-177)
+      if mask is None:
+        self._obs_reset.fill_(1)
+      else:
+        torch.maximum(self._obs_reset, mask, out=self._obs_reset)
+
+  # ------------------------------------------------------------------ observation
+  def observe(self, noise_uv: Optional[torch.Tensor] = None, append: bool = True,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PerciatelliFeatureConstructor.observe + get_features for every env: [n, 1099] float32
+    device tensor.  `noise_uv` [n, 2]: measured wind minus forecast at the balloons (None = 0)."""
+    assert self.grid is not None, 'Must call set_grid (reset) before observe.'
+    if self._gp is None:
+      with torch.cuda.device(self.device):
+        cap = _lib.GP_CAPACITY
+        self._gp = dict(xyp=torch.zeros(self.n, cap, 3, dtype=torch.float32, device=self.device),
+                        elapsed_s=torch.zeros(self.n, cap, dtype=torch.int32, device=self.device),
+                        err_uv=torch.zeros(self.n, cap, 2, dtype=torch.float32, device=self.device),
+                        count=torch.zeros(self.n, dtype=torch.int32, device=self.device))
+        self._obs_reset = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        self._gp_struct = _abi.BleGpHistoryF32()
+        for name, ct in (('xyp', ctypes.c_float), ('elapsed_s', ctypes.c_int32), ('err_uv', ctypes.c_float),
+                         ('count', ctypes.c_int32)):
+          setattr(self._gp_struct, name, ctypes.cast(ctypes.c_void_p(self._gp[name].data_ptr()), ctypes.POINTER(ct)))
+    if noise_uv is not None:
+      assert noise_uv.dtype == torch.float32 and noise_uv.is_contiguous() and tuple(noise_uv.shape) == (self.n, 2)
+    if out is None:
+      out = torch.empty(self.n, _lib.OBS_DIM, dtype=torch.float32, device=self.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (self.n, _lib.OBS_DIM)
+    code = self.lib.ble_observe_f32(ctypes.byref(self._struct), self.grid.data_ptr(), self.grid_env_stride,
+                                    dev.ptr(noise_uv), self._obs_reset.data_ptr(), ctypes.byref(self._gp_struct),
+                                    1 if append else 0, out.data_ptr(), self.err_flags.data_ptr(), self.n,
+                                    dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_observe_f32')
+    self._obs_reset.zero_()         # stream-ordered after the kernel
+    return out
+
+  def reset_observation_history(self, mask: Optional[torch.Tensor] = None) -> None:
+    """Forget the WindGP observations of the selected envs (all if None)."""
+    if self._gp is not None:
+      if mask is None:
+        self._obs_reset.fill_(1)
+      else:
+        torch.maximum(self._obs_reset, mask, out=self._obs_reset)
 
   # ------------------------------------------------------------------ stepping
   def step(self, action: torch.Tensor, noise_uv: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):

@@ -48,6 +48,8 @@ extern "C" {
 #define BLE_FLAG_SOLAR_RANGE 4u    /* solar.py:190-197 ValueError */
 #define BLE_FLAG_POWER_TABLE 16u   /* power_table.py:24 assert */
 #define BLE_FLAG_NONFINITE 32u     /* a state value became NaN/Inf (no reference analogue) */
+#define BLE_FLAG_GP_WINDOW 64u     /* > 120 observations inside the WindGP's 6 h window (steps < 180 s): oldest dropped */
+#define BLE_FLAG_PRESSURE_SEARCH 128u /* pressure_range_builder.py:104-108,180-182 ValueError */
 
 /* wind grid geometry: generative/vae.py:30-38,77-93 (FieldShape defaults) */
 #define BLE_GRID_NX 21 /* x (lat axis of the grid), -500..500 km step 50 */
@@ -187,6 +189,33 @@ int ble_forecast_f32(const float* wind_grid, int64_t grid_env_stride, const floa
 int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, const float* x_m,
                             const float* y_m, const int32_t* elapsed_s, const float* levels_pa,
                             int n_levels, float* out_uv, int64_t n, void* stream);
+
+/*
+ * Observation for n environments: PerciatelliFeatureConstructor.observe + get_features
+ * (env/features.py:301-330,400-581) with its WindGP (env/wind_gp.py:90-241: Matern nu = 0.5,
+ * refit on the observations of the last 6 h) and get_pressure_range
+ * (env/balloon/pressure_range_builder.py:203-275).  One workgroup per environment.
+ *
+ *   noise_uv     optional [n][2]: measured wind minus forecast at the balloon (the reference's
+ *                WindGP.observe error term, wind_gp.py:118-123); NULL = 0
+ *   reset_mask   optional [n]: != 0 starts a new episode's history (the reference builds a new
+ *                feature constructor in BalloonArena.reset, balloon_arena.py:171-177)
+ *   hist         per-env ring of the last BLE_GP_CAPACITY observations, caller-allocated device
+ *                memory, zero-initialised `count`
+ *   append       1: observe() then get_features(); 0: get_features() on the existing history
+ *   obs          [n][BLE_OBS_DIM] float32 out
+ */
+#define BLE_OBS_DIM 1099
+#define BLE_GP_CAPACITY 128
+typedef struct ble_gp_history_f32 {
+  float* xyp;         /* [n][BLE_GP_CAPACITY][3]  x m, y m, pressure Pa */
+  int32_t* elapsed_s; /* [n][BLE_GP_CAPACITY]     time_elapsed of the observation */
+  float* err_uv;      /* [n][BLE_GP_CAPACITY][2]  measured - forecast, m/s */
+  int32_t* count;     /* [n] observations appended this episode; ring slot = count % BLE_GP_CAPACITY */
+} ble_gp_history_f32;
+int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
+                    const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,
+                    int append, float* obs, uint32_t* err_flags, int64_t n, void* stream);
 
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,

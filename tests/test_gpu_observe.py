@@ -1,0 +1,158 @@
+"""Batched device observation (ble_observe_f32; SURVEY.md 8f #1, stage S2) through the C ABI.
+
+ * against the reference's own PerciatelliFeatureConstructor outputs (golden F11 / F12), the
+   states of the fixture being written into the device state step by step;
+ * against the CPU oracle (oracle/features_oracle.py, pinned to the same fixtures) on rollouts
+   produced by the step kernel itself, long enough for the 6 h window to slide;
+ * API behaviour: get_features without observe, episode reset, ragged batch sizes.
+
+Tolerances (features are float32, all O(1)): discrete pattern of unreachable levels identical;
+|diff| <= 2e-4 everywhere (the bearing feature is arccos(.)/pi whose conditioning near aligned
+winds turns the fp32 forecast's 1e-7 into ~1e-4), and <= 1e-5 for at least 99.9 % of entries.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+UNREACHABLE = lambda f: (f[..., 16::3] == 0) & (f[..., 17::3] == 1) & (f[..., 18::3] == 1)
+
+
+@pytest.fixture(scope='module')
+def vec_state():
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device; none visible')
+  from balloon_learning_environment_amd import vec_state
+  return vec_state
+
+
+def rows_to_arrays(rows):
+  return {k: np.array([r[k] for r in rows]) for k in rows[0]}
+
+
+def check(got, want, what):
+  np.testing.assert_array_equal(UNREACHABLE(got), UNREACHABLE(want), err_msg=what)
+  np.testing.assert_array_equal(got[..., 8:14], want[..., 8:14], err_msg=what)
+  err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+  assert err.max() <= 2e-4, (what, err.max(), np.unravel_index(err.argmax(), err.shape))
+  assert (err > 1e-5).mean() <= 1e-3, (what, (err > 1e-5).mean())
+  return err
+
+
+def drive_fixture(vec_state, name, envs):
+  g = helpers.golden(name)
+  field = helpers.fixture_field(g)
+  sim = vec_state.VecSimulator(len(envs))
+  sim.set_grid(torch.from_numpy(field).cuda())
+  n_steps = g['x'].shape[1]
+  out = np.zeros((len(envs), n_steps, 1099), np.float32)
+  for i in range(n_steps):
+    rows = [helpers.feature_row(g, j, i) for j in envs]
+    sim.set_state(rows_to_arrays(rows))
+    fu, fv = oracle.wind_forecast(field, [r['x'] for r in rows], [r['y'] for r in rows], [r['pressure'] for r in rows],
+                                  [r['time_elapsed_s'] for r in rows])
+    noise = np.stack([g['wind_measured'][envs, i, 0] - fu, g['wind_measured'][envs, i, 1] - fv], 1).astype(np.float32)
+    out[:, i] = sim.observe(torch.from_numpy(noise).cuda()).cpu().numpy()
+    sim.check_errors()
+  return out, g
+
+
+def test_observe_matches_reference_features(vec_state):
+  got, g = drive_fixture(vec_state, 'f11_features', [0, 1, 2])
+  err = check(got, g['features'], 'F11')
+  print('F11 device observation: max |diff| %.3g, median of non-zero %.3g' % (err.max(), np.median(err[err > 0])))
+
+
+def test_observe_long_horizon_matches_reference(vec_state):
+  got, g = drive_fixture(vec_state, 'f12_features_long', [0])
+  check(got[:, -16:], g['features'], 'F12')
+
+
+def test_observe_rollout_matches_oracle(vec_state):
+  """48 environments flown by the step kernel for 130 agent steps with random actions and a
+  random measured-minus-forecast term; every 10th step (and the last 12) is compared."""
+  import features_oracle
+  n, steps = 48, 130
+  rng = np.random.default_rng(5)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 6.0).astype(np.float32)
+  sim = vec_state.VecSimulator(n)
+  sim.set_grid(torch.from_numpy(field).cuda())
+  sim.reset_device(seed=77)
+  alpha = sim.state['alpha'].cpu().numpy().astype(np.float64)
+  oracles = [features_oracle.FeatureOracle(field, alpha[j]) for j in range(n)]
+  worst = 0.0
+  for i in range(steps + 1):
+    if i > 0:
+      actions = torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda()
+      sim.step(actions)
+    noise = (rng.standard_normal((n, 2)) * 1.5).astype(np.float32)
+    obs = sim.observe(torch.from_numpy(noise).cuda()).cpu().numpy()
+    sim.check_errors()
+    state = sim.get_state()
+    alive = state['status'] == 0
+    compare = (i % 10 == 0) or i > steps - 12
+    for j in range(n):
+      row = {k: float(state[k][j]) for k in helpers.STATE_FLOATS}
+      for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+        row[k] = float(state[k][j])
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
+        row[k] = int(state[k][j])
+      oracles[j].observe(row, noise[j].astype(np.float64))
+      if compare and alive[j] and j % 4 == i % 4:
+        want = oracles[j].features()
+        err = check(obs[j], want, f'env {j} step {i}')
+        worst = max(worst, err.max())
+  print('rollout vs oracle: worst |diff| %.3g' % worst)
+
+
+def test_observe_api_behaviour(vec_state):
+  for n in (1, 3, 65):
+    sim = vec_state.VecSimulator(n)
+    field = np.zeros((21, 21, 10, 9, 2), np.float32); field[..., 0] = 4.0
+    sim.set_grid(torch.from_numpy(field).cuda())
+    sim.reset_device(seed=3)
+    # get_features() before any observe(): forecast only, zero uncertainty (wind_gp.py:166-168)
+    f0 = sim.observe(append=False).cpu().numpy()
+    valid = ~UNREACHABLE(f0)
+    assert valid.any(axis=1).all()
+    assert (f0[:, 16::3][valid] == 0).all()
+    np.testing.assert_allclose(f0[:, 18::3][valid], 4.0 / 34.0, rtol=1e-6)
+    # first observation: uncertainty at the balloon's own level is noise / (sigma^2 + noise)
+    f1 = sim.observe().cpu().numpy()
+    # one observation at the balloon: deviation(level) = 1 - exp(-2 |dp| / 326) s^2 / (s^2 + noise)
+    pressure = sim.state['pressure'].cpu().numpy().astype(np.float64)
+    level = np.rint((np.clip(pressure, 5000, 14000) - 5000) / 50)
+    dp = np.abs(5000 + 50 * level - pressure)
+    want = 1 - np.exp(-2 * dp / 326.0) * 3.6 ** 2 / (3.6 ** 2 + 0.05)
+    own = ~UNREACHABLE(f1)[:, 180]                                       # the balloon's level is always entry 180
+    np.testing.assert_allclose(f1[own, 16 + 3 * 180], want[own], atol=1e-6)
+    assert (sim._gp['count'].cpu().numpy() == 1).all()
+    # same state, append=False: identical vector; a reset restarts the history
+    np.testing.assert_array_equal(sim.observe(append=False).cpu().numpy(), f1)
+    sim.reset_device(seed=4)
+    sim.observe()
+    assert (sim._gp['count'].cpu().numpy() == 1).all()
+    mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[0] = 1
+    sim.observe()
+    sim.reset_device(seed=5, mask=mask)
+    sim.observe()
+    counts = sim._gp['count'].cpu().numpy()
+    assert counts[0] == 1 and (counts[1:] == 3).all()
+    sim.check_errors()
+
+
+def test_observe_invalid_arguments(vec_state):
+  import ctypes
+  from balloon_learning_environment_amd import _abi, _lib
+  lib = _lib.lib()
+  sim = vec_state.VecSimulator(2)
+  sim.set_grid(torch.zeros(21, 21, 10, 9, 2, device='cuda'))
+  empty = _abi.BleGpHistoryF32()
+  obs = torch.zeros(2, 1099, device='cuda')
+  assert lib.ble_observe_f32(ctypes.byref(sim._struct), sim.grid.data_ptr(), 0, 0, 0, ctypes.byref(empty), 1,
+                             obs.data_ptr(), 0, 2, 0) == -1
+  assert lib.ble_observe_f32(ctypes.byref(sim._struct), sim.grid.data_ptr(), 0, 0, 0, None, 1, obs.data_ptr(), 0, 2, 0) == -1
