@@ -9,10 +9,12 @@
 //              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) for the
 //                      reachable pressure range (pressure_range_builder.py:203-275)
 //              waves 2-3: K = s^2 exp(-|d/ls|) + 0.05 I, packed lower triangle in LDS (fp64)
-//   phase 2    right-looking Cholesky of K in LDS (sklearn GaussianProcessRegressor.fit)
-//   phase 3    alpha = K^-1 y (two right-hand sides), one wave
-//   phase 4    181 query levels in 3 chunks of 64: V = L^-1 K*^T by forward substitution,
-//              4 lanes per query; mean = K* alpha + forecast, deviation = (s^2 - |v|^2) / s^2
+//   phase 2    left-looking Cholesky of K in LDS in panels of 8 columns (sklearn
+//              GaussianProcessRegressor.fit); the two error vectors ride along as extra rows,
+//              which turns them into z = L^-1 y for free
+//   phase 4    181 query levels in 3 chunks of 64: V = L^-1 K*^T by forward substitution in
+//              blocks of 8 rows, 4 lanes per query; mean = v . z + forecast  (= K* K^-1 y),
+//              deviation = (s^2 - |v|^2) / s^2
 //   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
 //
 // All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (L) + 62 KB (V)
@@ -29,7 +31,7 @@ constexpr int kGpCapacity = 128;                    // ring entries per env (BLE
 constexpr int kGpMax = 120;                         // 6 h / 180 s
 constexpr int kObsBlock = 256;
 constexpr int kQueryChunk = 64;
-constexpr int kVStride = kGpMax + 1;
+constexpr int kVStride = 124;                       // 248 dwords: 8 queries x 4 lanes of a ds_read_b64 group hit disjoint banks
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
 constexpr double kGpNoise2 = 0.05;                  // wind_gp.py:37
@@ -49,7 +51,8 @@ struct ObsShared {
   double V[kQueryChunk * kVStride];      // phases 0-1: elevation table [721]
   double loc[kGpMax][4];                 // x, y, p, t of the observations in the window
   double a[kGpMax];                      // scaled squared (x, y, t) distance to the query column
-  double rhs[kGpMax][2];                 // errors, then alpha
+  double z[2][kGpMax];                   // error components, then z = L^-1 y
+  double inv_diag[kGpMax];               // 1 / L[i][i]
   double lev[20], pot[20], sp[22];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
@@ -109,6 +112,13 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
                                                                 int append, float* __restrict__ obs,
                                                                 uint32_t* err_flags, int64_t n) {
   __shared__ ObsShared sh;
+#ifdef BLE_OBS_TIMING
+  long long tmark[8]; int nmark = 0;
+#define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BLE_MARK() do {} while (0)
+#endif
+  BLE_MARK();
   const int64_t env = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   uint32_t flags = 0;
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     sh.column[lane] = acc;
   }
   __syncthreads();   // B1
+  BLE_MARK();
 
   // ---- phase 0c: compact the window into LDS (chronological)
   int n_obs = sh.wave_count[0] + sh.wave_count[1];
@@ -209,13 +220,14 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
     if (at >= 0) {
       sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op; sh.loc[at][3] = (double)ot;
-      sh.rhs[at][0] = (double)oeu; sh.rhs[at][1] = (double)oev;
+      sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
       const double dx = ((double)ox - x) / 357000.0, dy = ((double)oy - y) / 357000.0,
                    dt = ((double)ot - (double)elapsed) / 34560.0;
       sh.a[at] = dx * dx + dy * dy + dt * dt;
     }
   }
   const double el_now = sh.el_now, flux_now = sh.flux_now;
+  const int n_pad = (n_obs + 7) & ~7;
   __syncthreads();   // B2
 
   // ---- phase 1: three roles
@@ -266,20 +278,29 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       flags |= local;
     }
   } else if (wave >= 2) {
-    // -- K + noise, packed lower triangle
-    const int total = tri(n_obs);
+    // -- K + noise, packed lower triangle; rows n_obs .. n_pad-1 are identity (padding to a
+    //    multiple of the panel width: they factor to themselves and contribute nothing)
+    const int total = tri(n_pad);
     for (int e = tid - 128; e < total; e += 128) {
       int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
       while (tri(i) > e) --i;
       while (tri(i + 1) <= e) ++i;
       const int j = e - tri(i);
-      const double d0 = (sh.loc[i][0] - sh.loc[j][0]) / 357000.0, d1 = (sh.loc[i][1] - sh.loc[j][1]) / 357000.0,
-                   d2 = (sh.loc[i][2] - sh.loc[j][2]) / 326.0, d3 = (sh.loc[i][3] - sh.loc[j][3]) / 34560.0;
-      const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-      sh.L[e] = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
+      double k_ij;
+      if (i < n_obs) {
+        const double d0 = (sh.loc[i][0] - sh.loc[j][0]) / 357000.0, d1 = (sh.loc[i][1] - sh.loc[j][1]) / 357000.0,
+                     d2 = (sh.loc[i][2] - sh.loc[j][2]) / 326.0, d3 = (sh.loc[i][3] - sh.loc[j][3]) / 34560.0;
+        const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        k_ij = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
+      } else {
+        k_ij = i == j ? 1.0 : 0.0;
+      }
+      sh.L[e] = k_ij;
     }
+    for (int i = n_obs + (tid - 128); i < n_pad; i += 128) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
   }
   __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
+  BLE_MARK();
 
   // ---- reachable pressure range (pressure_range_builder.py:249-275)
   if (tid == 0) {
@@ -290,57 +311,90 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     sh.range_ok = ok;
   }
 
-  // ---- phase 2: Cholesky, right-looking, in place
-  for (int k = 0; k < n_obs; ++k) {
-    const int kk = tri(k) + k;
-    if (tid == 0) sh.L[kk] = sqrt(sh.L[kk]);
-    __syncthreads();
-    const double inv = 1.0 / sh.L[kk];
-    const int rows = n_obs - k - 1;
-    for (int r = tid; r < rows; r += kObsBlock) sh.L[tri(k + 1 + r) + k] *= inv;
-    __syncthreads();
-    const int total = tri(rows);
-    for (int e = tid; e < total; e += kObsBlock) {
-      int r = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-      while (tri(r) > e) --r;
-      while (tri(r + 1) <= e) ++r;
-      const int c = e - tri(r);
-      const int i = k + 1 + r, j = k + 1 + c;
-      sh.L[tri(i) + j] = d_fma(-sh.L[tri(i) + k], sh.L[tri(j) + k], sh.L[tri(i) + j]);
-    }
-    // the next iteration's first barrier orders these updates before its reads
-    if (k + 1 < n_obs) __syncthreads();
-  }
-  __syncthreads();
-
-  // ---- phase 3: alpha = K^-1 y, wave 0 (rows lane and lane + 64, both right-hand sides)
-  if (wave == 0) {
-    for (int j = 0; j < n_obs; ++j) {            // L z = y
-      const double inv = 1.0 / sh.L[tri(j) + j];
-      const double z0 = sh.rhs[j][0] * inv, z1 = sh.rhs[j][1] * inv;
-      wave_sync_lds();
-      if (lane == 0) { sh.rhs[j][0] = z0; sh.rhs[j][1] = z1; }
-      for (int i = j + 1 + lane; i < n_obs; i += 64) {
-        const double l = sh.L[tri(i) + j];
-        sh.rhs[i][0] = d_fma(-l, z0, sh.rhs[i][0]);
-        sh.rhs[i][1] = d_fma(-l, z1, sh.rhs[i][1]);
+  // ---- phase 2: Cholesky, left-looking, panels of 8 columns.  Thread (slot, half): slot = row
+  // of the trailing matrix (or one of the two error rows), half = which half of the j range.
+  {
+    const int slot = tid >> 1, half = tid & 1;
+    for (int c0 = 0; c0 < n_pad; c0 += 8) {
+      const int rows = n_pad - c0;
+      const bool is_matrix = slot < rows, is_rhs = slot >= rows && slot < rows + 2;
+      const int i = c0 + slot;                                   // matrix row
+      double* rowbase = is_matrix ? sh.L + tri(i) : sh.z[is_rhs ? slot - rows : 0];
+      const int width = is_matrix ? (slot < 8 ? slot + 1 : 8) : 8;   // stored columns of this row inside the panel
+      double acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+      if (is_matrix || is_rhs) {
+        const double* col[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) col[c] = sh.L + tri(c0 + c);
+#pragma unroll 2
+        for (int j = half; j < c0; j += 2) {
+          const double lij = rowbase[j];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[c] = d_fma(lij, col[c][j], acc[c]);
+        }
       }
-      wave_sync_lds();
-    }
-    for (int j = n_obs - 1; j >= 0; --j) {       // L^T a = z
-      const double inv = 1.0 / sh.L[tri(j) + j];
-      const double a0 = sh.rhs[j][0] * inv, a1 = sh.rhs[j][1] * inv;
-      wave_sync_lds();
-      if (lane == 0) { sh.rhs[j][0] = a0; sh.rhs[j][1] = a1; }
-      for (int i = lane; i < j; i += 64) {
-        const double l = sh.L[tri(j) + i];
-        sh.rhs[i][0] = d_fma(-l, a0, sh.rhs[i][0]);
-        sh.rhs[i][1] = d_fma(-l, a1, sh.rhs[i][1]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += __shfl_xor(acc[c], 1, 64);
+      double av[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) av[c] = ((is_matrix || is_rhs) && c < width) ? rowbase[c0 + c] - acc[c] : 0.0;
+      // the panel's own rows publish their updated entries: the 8 x 8 diagonal block
+      if (is_matrix && slot < 8 && half == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < width) rowbase[c0 + c] = av[c];
       }
-      wave_sync_lds();
+      __syncthreads();
+      // barriers stay outside divergent code: a wave that executes both sides of a branch would
+      // arrive twice
+      double xr[8], invd[8], dd[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { xr[c] = 0.0; invd[c] = 0.0; dd[c] = 0.0; }
+      if (is_matrix || is_rhs) {
+        // every thread factors the diagonal block in registers (SIMT: free) ...
+        double d[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) d[r][c] = sh.L[tri(c0 + r) + c0 + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          d[k][k] = sqrt(d[k][k]);
+          invd[k] = 1.0 / d[k][k];
+          dd[k] = d[k][k];
+#pragma unroll
+          for (int r = k + 1; r < 8; ++r) d[r][k] *= invd[k];
+#pragma unroll
+          for (int r = k + 1; r < 8; ++r)
+#pragma unroll
+            for (int c = k + 1; c <= r; ++c) d[r][c] = d_fma(-d[r][k], d[c][k], d[r][c]);
+        }
+        // ... and solves its own row against it
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double t = av[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) t = d_fma(-xr[k], d[c][k], t);
+          xr[c] = t * invd[c];
+        }
+      }
+      __syncthreads();        // all reads of the un-factored diagonal block are done
+      if ((is_matrix || is_rhs) && half == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < width) rowbase[c0 + c] = (is_matrix && c == slot) ? dd[c] : xr[c];
+        if (slot == 0) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) sh.inv_diag[c0 + c] = invd[c];
+        }
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
+  BLE_MARK();
+  BLE_MARK();
 
   // ---- phases 4 + 5: the 181-level column, 3 chunks of 64 queries, 4 lanes per query
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
@@ -355,26 +409,45 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   for (int chunk = 0; chunk < 3; ++chunk) {
     const int q = chunk * kQueryChunk + qq;
     const double level = 5000.0 + 50.0 * (double)q;
-    // k*(q, i) for the 16 queries of this wave
-    for (int i = part; i < n_obs; i += 4) {
+    // k*(q, i) for the 16 queries of this wave (zero in the padding rows)
+    for (int i = part; i < n_pad; i += 4) {
       const double dp = (level - sh.loc[i][2]) / 326.0;
-      vrow[i] = kGpSigma2 * d_exp_fast(-sqrt(sh.a[i] + dp * dp));
+      vrow[i] = i < n_obs ? kGpSigma2 * d_exp_fast(-sqrt(sh.a[i] + dp * dp)) : 0.0;
     }
     wave_sync_lds();
     double mean_u = 0.0, mean_v = 0.0, ssq = 0.0;
-    for (int i = 0; i < n_obs; ++i) {
-      const double* lrow = sh.L + tri(i);
-      double partial = 0.0;
-      for (int j = part; j < i; j += 4) partial = d_fma(lrow[j], vrow[j], partial);
-      partial += __shfl_xor(partial, 1, 64);
-      partial += __shfl_xor(partial, 2, 64);
-      const double ks = vrow[i];
-      const double v = (ks - partial) / lrow[i];
-      mean_u = d_fma(ks, sh.rhs[i][0], mean_u);
-      mean_v = d_fma(ks, sh.rhs[i][1], mean_v);
-      ssq = d_fma(v, v, ssq);
+    for (int i0 = 0; i0 < n_pad; i0 += 8) {
+      const double* lrow[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lrow[r] = sh.L + tri(i0 + r);
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+#pragma unroll 2
+      for (int j = part; j < i0; j += 4) {
+        const double vj = vrow[j];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = d_fma(lrow[r][j], vj, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        acc[r] += __shfl_xor(acc[r], 1, 64);
+        acc[r] += __shfl_xor(acc[r], 2, 64);
+      }
+      double vv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        double t = vrow[i0 + r] - acc[r];
+#pragma unroll
+        for (int c = 0; c < r; ++c) t = d_fma(-lrow[r][i0 + c], vv[c], t);
+        vv[r] = t * sh.inv_diag[i0 + r];
+        ssq = d_fma(vv[r], vv[r], ssq);
+        mean_u = d_fma(vv[r], sh.z[0][i0 + r], mean_u);
+        mean_v = d_fma(vv[r], sh.z[1][i0 + r], mean_v);
+      }
       wave_sync_lds();
-      if (part == 0) vrow[i] = v;
+      vrow[i0 + 2 * part] = part == 0 ? vv[0] : (part == 1 ? vv[2] : (part == 2 ? vv[4] : vv[6]));
+      vrow[i0 + 2 * part + 1] = part == 0 ? vv[1] : (part == 1 ? vv[3] : (part == 2 ? vv[5] : vv[7]));
       wave_sync_lds();
     }
     if (part == 0 && q < kObsLevels) {
@@ -414,6 +487,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       o[0] = 0.0f; o[1] = 1.0f; o[2] = 1.0f;
     }
   }
+#ifdef BLE_OBS_TIMING
+  __syncthreads();
+  BLE_MARK();
+  if (tid == 0)
+    for (int k = 1; k < nmark; ++k) out[kObsDim - 8 + k] = (float)(tmark[k] - tmark[k - 1]);
+#endif
   // every lane has read the old count long before this point (barriers above)
   if (tid == 0) hist.count[env] = count;
   if (err_flags != nullptr && flags != 0) atomicOr(err_flags, flags);
