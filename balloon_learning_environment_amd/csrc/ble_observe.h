@@ -29,9 +29,8 @@ constexpr int kObsColumn = 2 * kObsLevels - 1;      // 361
 constexpr int kObsDim = 3 * kObsColumn + 16;        // 1099
 constexpr int kGpCapacity = 128;                    // ring entries per env (BLE_GP_CAPACITY)
 constexpr int kGpMax = 120;                         // 6 h / 180 s
+constexpr int kGpRows = 128;                        // kGpMax rounded up to the MFMA tile
 constexpr int kObsBlock = 256;
-constexpr int kQueryChunk = 64;
-constexpr int kVStride = 124;                       // 248 dwords: 8 queries x 4 lanes of a ds_read_b64 group hit disjoint banks
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
 constexpr double kGpNoise2 = 0.05;                  // wind_gp.py:37
@@ -47,21 +46,38 @@ struct GpHistory {
 };
 
 struct ObsShared {
-  double L[kGpMax * (kGpMax + 1) / 2];
-  double V[kQueryChunk * kVStride];      // phases 0-1: elevation table [721]
-  double loc[kGpMax][4];                 // x, y, p, t of the observations in the window
-  double a[kGpMax];                      // scaled squared (x, y, t) distance to the query column
-  double z[2][kGpMax];                   // error components, then z = L^-1 y
-  double inv_diag[kGpMax];               // 1 / L[i][i]
+  double L[kGpRows * (kGpRows + 1) / 2]; // packed lower triangle, rows padded with identity to a multiple of 16
+  double dinv[kGpRows / 16][256];        // inverses of the 16 x 16 diagonal blocks of L (row-major)
+  double el_table[kElevTable];           // solar elevation at now + 180 s * (k - 240)
+  double loc[kGpRows][4];                // x, y, p, t of the observations in the window
+  double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
+  double z[2][kGpRows];                  // error components, then z = L^-1 y
+  double inv_diag[kGpRows];              // 1 / L[i][i]
   double lev[20], pot[20], sp[22];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
   int wave_count[2];
   int n_obs;
   int range_ok;
+  float role_t[3];
 };
 
 BLE_FN int tri(int i) { return i * (i + 1) / 2; }
+
+// Sum over the 4 lanes of a quad (lanes 4k .. 4k+3) with DPP quad_perm moves: no LDS traffic,
+// unlike a ds_bpermute-based shuffle.
+__device__ __forceinline__ double quad_swap(double v, int xor1) {
+  union { double d; int w[2]; } a, b;
+  a.d = v;
+  if (xor1) {   // quad_perm [1,0,3,2]
+    b.w[0] = __builtin_amdgcn_update_dpp(0, a.w[0], 0xB1, 0xF, 0xF, true);
+    b.w[1] = __builtin_amdgcn_update_dpp(0, a.w[1], 0xB1, 0xF, 0xF, true);
+  } else {      // quad_perm [2,3,0,1]
+    b.w[0] = __builtin_amdgcn_update_dpp(0, a.w[0], 0x4E, 0xF, 0xF, true);
+    b.w[1] = __builtin_amdgcn_update_dpp(0, a.w[1], 0x4E, 0xF, 0xF, true);
+  }
+  return b.d;
+}
 
 __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   }
 
   // ---- phase 0b: solar elevation table, search levels, pressure column
-  double* el_table = sh.V;
+  double* el_table = sh.el_table;
   for (int k = tid; k < kElevTable; k += kObsBlock) {
     double flux;
     const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, now + 180 * (int64_t)(k - 240), &flux);
@@ -221,16 +237,19 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     if (at >= 0) {
       sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op; sh.loc[at][3] = (double)ot;
       sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
-      const double dx = ((double)ox - x) / 357000.0, dy = ((double)oy - y) / 357000.0,
-                   dt = ((double)ot - (double)elapsed) / 34560.0;
+      const double dx = ((double)ox - x) * (1.0 / 357000.0), dy = ((double)oy - y) * (1.0 / 357000.0),
+                   dt = ((double)ot - (double)elapsed) * (1.0 / 34560.0);
       sh.a[at] = dx * dx + dy * dy + dt * dt;
     }
   }
   const double el_now = sh.el_now, flux_now = sh.flux_now;
-  const int n_pad = (n_obs + 7) & ~7;
+  const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
   __syncthreads();   // B2
 
   // ---- phase 1: three roles
+#ifdef BLE_OBS_TIMING
+  const long long role_t0 = (long long)__builtin_readcyclecounter();
+#endif
   if (tid == 0) {
     // -- ambient features (features.py:400-470)
     auto elev = [&](int64_t when) {
@@ -288,9 +307,11 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       const int j = e - tri(i);
       double k_ij;
       if (i < n_obs) {
-        const double d0 = (sh.loc[i][0] - sh.loc[j][0]) / 357000.0, d1 = (sh.loc[i][1] - sh.loc[j][1]) / 357000.0,
-                     d2 = (sh.loc[i][2] - sh.loc[j][2]) / 326.0, d3 = (sh.loc[i][3] - sh.loc[j][3]) / 34560.0;
-        const double r = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        // (a - b) / length_scale as a multiplication by the rounded reciprocal: 1e-16 relative
+        const double d0 = (sh.loc[i][0] - sh.loc[j][0]) * (1.0 / 357000.0), d1 = (sh.loc[i][1] - sh.loc[j][1]) * (1.0 / 357000.0),
+                     d2 = (sh.loc[i][2] - sh.loc[j][2]) * (1.0 / 326.0), d3 = (sh.loc[i][3] - sh.loc[j][3]) * (1.0 / 34560.0);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        const double r = r2 > 0.0 ? r2 * d_rsqrt(r2) : 0.0;
         k_ij = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
       } else {
         k_ij = i == j ? 1.0 : 0.0;
@@ -299,6 +320,10 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     }
     for (int i = n_obs + (tid - 128); i < n_pad; i += 128) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
   }
+#ifdef BLE_OBS_TIMING
+  if (tid == 0 || tid == 64 || tid == 128)
+    sh.role_t[tid >> 6] = (float)((long long)__builtin_readcyclecounter() - role_t0);
+#endif
   __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
   BLE_MARK();
 
@@ -312,12 +337,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   }
 
   // ---- phase 2: Cholesky, left-looking, panels of 8 columns.  Thread (slot, half): slot = row
-  // of the trailing matrix (or one of the two error rows), half = which half of the j range.
+  // of the trailing matrix, half = which half of the j range.
   {
     const int slot = tid >> 1, half = tid & 1;
     for (int c0 = 0; c0 < n_pad; c0 += 8) {
       const int rows = n_pad - c0;
-      const bool is_matrix = slot < rows, is_rhs = slot >= rows && slot < rows + 2;
+      const bool is_matrix = slot < rows, is_rhs = false;
       const int i = c0 + slot;                                   // matrix row
       double* rowbase = is_matrix ? sh.L + tri(i) : sh.z[is_rhs ? slot - rows : 0];
       const int width = is_matrix ? (slot < 8 ? slot + 1 : 8) : 8;   // stored columns of this row inside the panel
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         }
       }
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] += __shfl_xor(acc[c], 1, 64);
+      for (int c = 0; c < 8; ++c) acc[c] += quad_swap(acc[c], 1);
       double av[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) av[c] = ((is_matrix || is_rhs) && c < width) ? rowbase[c0 + c] - acc[c] : 0.0;
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   BLE_MARK();
   BLE_MARK();
 
-  // ---- phases 4 + 5: the 181-level column, 3 chunks of 64 queries, 4 lanes per query
+  // ---- phases 4 + 5: the 181-level column
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0) flags |= kFlagPressureSearch;
   const double p_clamped = p < 5000.0 ? 5000.0 : (p > 14000.0 ? 14000.0 : p);
@@ -404,53 +429,123 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   const int pad_above = kObsLevels - level_now - 1;
   const double dist = sqrt(x * x + y * y);
   const double to_station_x = -x / (dist + 1e-5), to_station_y = -y / (dist + 1e-5);
-  const int qq = tid >> 2, part = tid & 3;
-  double* vrow = sh.V + qq * kVStride;
-  for (int chunk = 0; chunk < 3; ++chunk) {
-    const int q = chunk * kQueryChunk + qq;
-    const double level = 5000.0 + 50.0 * (double)q;
-    // k*(q, i) for the 16 queries of this wave (zero in the padding rows)
-    for (int i = part; i < n_pad; i += 4) {
-      const double dp = (level - sh.loc[i][2]) / 326.0;
-      vrow[i] = i < n_obs ? kGpSigma2 * d_exp_fast(-sqrt(sh.a[i] + dp * dp)) : 0.0;
+  // -- inverses of the 16 x 16 diagonal blocks (thread = (block, column): forward substitution)
+  if (tid < 128) {
+    const int blk = tid >> 4, c = tid & 15, base = blk * 16;
+    if (base < n_pad) {
+      double xcol[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double t = r == c ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) t = d_fma(-sh.L[tri(base + r) + base + k], xcol[k], t);
+        xcol[r] = (r < c) ? 0.0 : t * sh.inv_diag[base + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sh.dinv[blk][r * 16 + c] = xcol[r];
     }
-    wave_sync_lds();
-    double mean_u = 0.0, mean_v = 0.0, ssq = 0.0;
-    for (int i0 = 0; i0 < n_pad; i0 += 8) {
-      const double* lrow[8];
+  }
+  __syncthreads();
+
+  // -- V = L^-1 [K*^T | y] with v_mfma_f64_16x16x4: wave w owns query columns 48 w .. 48 w + 47
+  // (3 tiles of 16); columns 181 and 182 are the two error vectors, so z = L^-1 y falls out of
+  // the same sweep.  MFMA register layout (measured on gfx950): A lane l holds A[l % 16][l / 16],
+  // B lane l holds B[l / 16][l % 16], D lane l register v holds D[4 v + l / 16][l % 16] -- a D
+  // tile is therefore directly the four B operands of the next product, and V never leaves
+  // the registers.
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int g = lane >> 4, jq = lane & 15;
+  const int nb = n_pad >> 4;
+  d4 V[3][8];
+  double level_q[3];
+  int qcol[3];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) lrow[r] = sh.L + tri(i0 + r);
-      double acc[8];
+  for (int t = 0; t < 3; ++t) {
+    qcol[t] = wave * 48 + t * 16 + jq;
+    level_q[t] = 5000.0 + 50.0 * (double)qcol[t];
+  }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = 0.0;
-#pragma unroll 2
-      for (int j = part; j < i0; j += 4) {
-        const double vj = vrow[j];
+  for (int I = 0; I < 8; ++I) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = d_fma(lrow[r][j], vj, acc[r]);
+    for (int t = 0; t < 3; ++t) V[t][I] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (I < nb) {
+      d4 acc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double* arow = sh.L + tri(16 * I + jq) + g;
+#pragma unroll
+      for (int J = 0; J < I; ++J)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double a = arow[16 * J + 4 * c];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
+        }
+      d4 R[3];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + 4 * v + g;
+        const double a_row = sh.a[row], p_row = sh.loc[row][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          double rhs;
+          if (qcol[t] < kObsLevels) {
+            const double dp = (level_q[t] - p_row) * (1.0 / 326.0);
+            const double r2 = a_row + dp * dp;
+            rhs = row < n_obs ? kGpSigma2 * d_exp_fast(r2 > 0.0 ? -(r2 * d_rsqrt(r2)) : 0.0) : 0.0;
+          } else {
+            rhs = qcol[t] == kObsLevels ? sh.z[0][row] : (qcol[t] == kObsLevels + 1 ? sh.z[1][row] : 0.0);
+          }
+          R[t][v] = rhs - acc[t][v];
+        }
       }
+      const double* drow = sh.dinv[I] + jq * 16 + g;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        acc[r] += __shfl_xor(acc[r], 1, 64);
-        acc[r] += __shfl_xor(acc[r], 2, 64);
+      for (int c = 0; c < 4; ++c) {
+        const double a = drow[4 * c];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
       }
-      double vv[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        double t = vrow[i0 + r] - acc[r];
-#pragma unroll
-        for (int c = 0; c < r; ++c) t = d_fma(-lrow[r][i0 + c], vv[c], t);
-        vv[r] = t * sh.inv_diag[i0 + r];
-        ssq = d_fma(vv[r], vv[r], ssq);
-        mean_u = d_fma(vv[r], sh.z[0][i0 + r], mean_u);
-        mean_v = d_fma(vv[r], sh.z[1][i0 + r], mean_v);
-      }
-      wave_sync_lds();
-      vrow[i0 + 2 * part] = part == 0 ? vv[0] : (part == 1 ? vv[2] : (part == 2 ? vv[4] : vv[6]));
-      vrow[i0 + 2 * part + 1] = part == 0 ? vv[1] : (part == 1 ? vv[3] : (part == 2 ? vv[5] : vv[7]));
-      wave_sync_lds();
     }
-    if (part == 0 && q < kObsLevels) {
+  }
+  __syncthreads();                 // every lane has read the raw error vectors
+  if (wave == 3 && (jq == 5 || jq == 6)) {      // columns 181, 182 live in tile 2 of wave 3
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sh.z[jq - 5][16 * I + 4 * v + g] = V[2][I][v];
+  }
+  __syncthreads();
+  double ssq[3] = {0.0, 0.0, 0.0}, mean_u[3] = {0.0, 0.0, 0.0}, mean_v[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int I = 0; I < 8; ++I) {
+    if (I < nb) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + 4 * v + g;
+        const double zu = sh.z[0][row], zv = sh.z[1][row];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const double val = V[t][I][v];
+          ssq[t] = d_fma(val, val, ssq[t]);
+          mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y = (L^-1 k*) . (L^-1 y)
+          mean_v[t] = d_fma(val, zv, mean_v[t]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {     // the four lanes g = 0..3 of a column hold disjoint rows
+    ssq[t] += __shfl_xor(ssq[t], 16, 64); ssq[t] += __shfl_xor(ssq[t], 32, 64);
+    mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
+    mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int q = qcol[t];
+      if (q >= kObsLevels) continue;
+      const double level = level_q[t];
       float f0 = 0.0f, f1 = 1.0f, f2 = 1.0f;             // unreachable: certain, wrong way, infinitely fast
       if (level >= p_lo && level <= p_hi) {
         // forecast at this level from the blended column
@@ -458,8 +553,8 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         wind_axis((float)level, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
         const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
         const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
-        const double u = mean_u + (double)fu, v = mean_v + (double)fv;
-        double var = kGpSigma2 - ssq;
+        const double u = mean_u[t] + (double)fu, v = mean_v[t] + (double)fv;
+        double var = kGpSigma2 - ssq[t];
         var = var < 0.0 ? 0.0 : var;
         const double deviation = n_obs > 0 ? var / kGpSigma2 : 0.0;     // wind_gp.py:166-168
         const double speed = sqrt(u * u + v * v);
@@ -478,7 +573,6 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       float* o = out + 16 + 3 * (pad_above + q);
       o[0] = f0; o[1] = f1; o[2] = f2;
     }
-    wave_sync_lds();
   }
   // padding above and below the 181 real levels
   for (int c = tid; c < kObsColumn; c += kObsBlock) {
@@ -491,7 +585,10 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   __syncthreads();
   BLE_MARK();
   if (tid == 0)
+  {
     for (int k = 1; k < nmark; ++k) out[kObsDim - 8 + k] = (float)(tmark[k] - tmark[k - 1]);
+    for (int k = 0; k < 3; ++k) out[kObsDim - 12 + k] = sh.role_t[k];
+  }
 #endif
   // every lane has read the old count long before this point (barriers above)
   if (tid == 0) hist.count[env] = count;
