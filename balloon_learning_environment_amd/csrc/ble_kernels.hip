@@ -452,6 +452,8 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
   if (n == 0) return BLE_OK;
   GpHistory h;
   h.xyp = hist->xyp; h.elapsed_s = hist->elapsed_s; h.err_uv = hist->err_uv; h.count = hist->count;
+  h.chol = hist->chol; h.n_chol = hist->n_chol;
+  if (h.chol != nullptr && h.n_chol == nullptr) return BLE_E_INVALID_ARG;
   BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, *st, wind_grid,
              grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
   return launch_status();

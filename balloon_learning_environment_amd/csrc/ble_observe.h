@@ -9,9 +9,14 @@
 //              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) for the
 //                      reachable pressure range (pressure_range_builder.py:203-275)
 //              waves 2-3: K = s^2 exp(-|d/ls|) + 0.05 I, packed lower triangle in LDS (fp64)
-//   phase 2    left-looking Cholesky of K in LDS in panels of 8 columns (sklearn
-//              GaussianProcessRegressor.fit); the two error vectors ride along as extra rows,
-//              which turns them into z = L^-1 y for free
+//   phase 1/2  the Cholesky factor of K (sklearn GaussianProcessRegressor.fit refits every step):
+//              * incremental (hist.chol given): the factor of the previous window lives in HBM
+//                (58 KB per env); the window slides by dropping the oldest observation -- a
+//                stable rank-1 UPDATE of the trailing factor -- and appending the newest -- one
+//                forward substitution -- O(n^2) instead of O(n^3), done by one wave while the
+//                ambient / Newton lanes work
+//              * refit (no hist.chol, first call, or an inconsistent history): left-looking
+//                blocked Cholesky in LDS in panels of 8 columns
 //   phase 4    181 query levels in 3 chunks of 64: V = L^-1 K*^T by forward substitution in
 //              blocks of 8 rows, 4 lanes per query; mean = v . z + forecast  (= K* K^-1 y),
 //              deviation = (s^2 - |v|^2) / s^2
@@ -29,7 +34,8 @@ constexpr int kObsColumn = 2 * kObsLevels - 1;      // 361
 constexpr int kObsDim = 3 * kObsColumn + 16;        // 1099
 constexpr int kGpCapacity = 128;                    // ring entries per env (BLE_GP_CAPACITY)
 constexpr int kGpMax = 120;                         // 6 h / 180 s
-constexpr int kGpRows = 128;                        // kGpMax rounded up to the MFMA tile
+constexpr int kGpRows = 128;
+constexpr int kCholStride = kGpMax * (kGpMax + 1) / 2;   // 7260 doubles = 58 080 B per environment                        // kGpMax rounded up to the MFMA tile
 constexpr int kObsBlock = 256;
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
@@ -43,6 +49,8 @@ struct GpHistory {
   int32_t* elapsed_s;  // [n][128]
   float* err_uv;       // [n][128][2]
   int32_t* count;      // [n]
+  double* chol;        // [n][kCholStride] packed Cholesky factor of the current window, or nullptr
+  int32_t* n_chol;     // [n] rows of `chol` that are valid (the window it was computed for ends at `count`)
 };
 
 struct ObsShared {
@@ -57,6 +65,7 @@ struct ObsShared {
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
   int wave_count[2];
+  unsigned long long ballot[2];
   int n_obs;
   int range_ok;
   float role_t[3];
@@ -76,6 +85,14 @@ __device__ __forceinline__ double quad_swap(double v, int xor1) {
     b.w[0] = __builtin_amdgcn_update_dpp(0, a.w[0], 0x4E, 0xF, 0xF, true);
     b.w[1] = __builtin_amdgcn_update_dpp(0, a.w[1], 0x4E, 0xF, 0xF, true);
   }
+  return b.d;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane must be wave-uniform
+  union { double d; int w[2]; } a, b;
+  a.d = v;
+  b.w[0] = __builtin_amdgcn_readlane(a.w[0], src_lane);
+  b.w[1] = __builtin_amdgcn_readlane(a.w[1], src_lane);
   return b.d;
 }
 
@@ -153,7 +170,9 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
 
   // ---- phase 0a: history ring
   int count = hist.count[env];
-  if (reset_mask != nullptr && reset_mask[env] != 0) count = 0;
+  int n_chol0 = hist.chol != nullptr ? hist.n_chol[env] : 0;
+  if (reset_mask != nullptr && reset_mask[env] != 0) { count = 0; n_chol0 = 0; }
+  const int count0 = count;
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   if (wave < 2) {
     const unsigned long long ballot = __ballot(valid);
     pos = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) sh.wave_count[wave] = __popcll(ballot);
+    if (lane == 0) { sh.wave_count[wave] = __popcll(ballot); sh.ballot[wave] = ballot; }
   }
 
   // ---- phase 0b: solar elevation table, search levels, pressure column
@@ -244,6 +263,27 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   }
   const double el_now = sh.el_now, flux_now = sh.flux_now;
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
+  // Can the stored factor be slid to the new window?  The observations inside the 6 h window
+  // must be a suffix of the ring (time only moves forward inside an episode), the stored factor
+  // must cover a window that ends where this call started, and the new window must start inside it.
+  bool incremental = false;
+  int n_dropped = 0;
+  {
+    const unsigned long long b0 = sh.ballot[0], b1 = sh.ballot[1];
+    const int m0 = m < 64 ? m : 64, m1 = m - m0;
+    const unsigned long long inv0 = ~b0 & (m0 >= 64 ? ~0ull : ((1ull << m0) - 1ull));
+    const unsigned long long inv1 = ~b1 & (m1 >= 64 ? ~0ull : ((1ull << m1) - 1ull));
+    const int last_invalid = inv1 ? 127 - __clzll(inv1) : (inv0 ? 63 - __clzll(inv0) : -1);
+    const int first_valid = b0 ? __ffsll((long long)b0) - 1 : (b1 ? 63 + __ffsll((long long)b1) : m);
+    n_dropped = (count - n_obs) - (count0 - n_chol0);
+    incremental = hist.chol != nullptr && drop == 0 && last_invalid < first_valid && n_dropped >= 0 &&
+                  n_dropped <= n_chol0 && n_chol0 <= kGpMax;
+  }
+  double* chol_g = hist.chol != nullptr ? hist.chol + env * kCholStride : nullptr;
+  if (incremental) {
+    const int total = tri(n_chol0);
+    for (int e = tid; e < total; e += kObsBlock) sh.L[e] = chol_g[e];
+  }
   __syncthreads();   // B2
 
   // ---- phase 1: three roles
@@ -296,8 +336,110 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       sh.sp[lane] = s.sp;
       flags |= local;
     }
+  } else if (wave >= 2 && incremental) {
+    if (wave == 2) {
+      // ---- slide the factor: lane owns rows `lane` and `lane + 64`
+      const bool appended = count != count0;
+      const int nn = n_obs - (appended ? 1 : 0);    // rows after the drops; the new observation is window entry nn
+      auto kern = [&](int i) {
+        const double d0 = (sh.loc[nn][0] - sh.loc[i][0]) * (1.0 / 357000.0), d1 = (sh.loc[nn][1] - sh.loc[i][1]) * (1.0 / 357000.0),
+                     d2 = (sh.loc[nn][2] - sh.loc[i][2]) * (1.0 / 326.0), d3 = (sh.loc[nn][3] - sh.loc[i][3]) * (1.0 / 34560.0);
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        return kGpSigma2 * d_exp_fast(r2 > 0.0 ? -(r2 * d_rsqrt(r2)) : 0.0);
+      };
+      // append: new row = (L^-1 k_new)^T, new diagonal = sqrt(k_nn - |row|^2); b = k_new, reduced in place
+      double b0 = (appended && lane < nn) ? kern(lane) : 0.0, b1 = (appended && lane + 64 < nn) ? kern(lane + 64) : 0.0;
+      double ssum = 0.0;
+      double* new_row = sh.L + tri(nn);
+      int n_cur = n_chol0;
+      for (int rep = 0; rep < n_dropped; ++rep) {
+        // K = [k11 k21^T; k21 K22], L = [l11 0; l21 L22]  =>  chol(K22) = cholupdate(L22, l21).
+        // The result is written one row up and one column left of where L22 was read, which no
+        // later read of this sweep touches.  The last sweep also carries the append's forward
+        // substitution: column k of the new factor is used the moment it exists (no LDS read).
+        const bool fuse = appended && rep == n_dropped - 1;
+        const int rows = n_cur - 1;
+        double x0 = lane < rows ? sh.L[tri(lane + 1)] : 0.0;
+        double x1 = lane + 64 < rows ? sh.L[tri(lane + 65)] : 0.0;
+        const bool own0 = lane < rows, own1 = lane + 64 < rows;
+        const double* row0 = sh.L + tri(lane + 1) + 1;       // old row lane + 1, shifted one column
+        const double* row1 = sh.L + tri(lane + 65) + 1;
+        // the loads of step k + 1 are issued during step k: none of this sweep's stores aliases them
+        double lkk = sh.L[tri(1) + 1];
+        double lik0 = own0 && lane > 0 ? row0[0] : 0.0, lik1 = own1 ? row1[0] : 0.0;
+        for (int k = 0; k < rows; ++k) {
+          const int kn = k + 1 < rows ? k + 1 : k;
+          const double lkk_next = sh.L[tri(kn + 1) + kn + 1];
+          const double lik0_next = own0 && lane > kn ? row0[kn] : 0.0;
+          const double lik1_next = own1 && lane + 64 > kn ? row1[kn] : 0.0;
+          const double xk = readlane_f64(k < 64 ? x0 : x1, k & 63);
+          const double r2 = d_fma(lkk, lkk, xk * xk);
+          const double ir = d_rsqrt(r2), il = d_rcp(lkk);
+          const double r = r2 * ir, c = r * il, sn = xk * il, ic = lkk * ir;
+          double ln0 = 0.0, ln1 = 0.0;
+          if (own0 && lane > k) {
+            ln0 = d_fma(sn, x0, lik0) * ic;
+            x0 = d_fma(c, x0, -sn * ln0);
+            sh.L[tri(lane) + k] = ln0;
+          }
+          if (own1 && lane + 64 > k) {
+            ln1 = d_fma(sn, x1, lik1) * ic;
+            x1 = d_fma(c, x1, -sn * ln1);
+            sh.L[tri(lane + 64) + k] = ln1;
+          }
+          if (fuse) {
+            const double xj = readlane_f64(k < 64 ? b0 : b1, k & 63) * ir;      // 1 / L'[k][k] == ir
+            ssum = d_fma(xj, xj, ssum);
+            b0 = d_fma(-ln0, xj, b0);
+            b1 = d_fma(-ln1, xj, b1);
+            if (lane == 0) { sh.L[tri(k) + k] = r; new_row[k] = xj; sh.inv_diag[k] = ir; }
+          } else if (lane == 0) {
+            sh.L[tri(k) + k] = r;
+          }
+          lkk = lkk_next; lik0 = lik0_next; lik1 = lik1_next;
+        }
+        n_cur = rows;
+        wave_sync_lds();
+      }
+      if (!(appended && n_dropped > 0)) {
+        if (lane < n_cur) sh.inv_diag[lane] = d_rcp(sh.L[tri(lane) + lane]);
+        if (lane + 64 < n_cur) sh.inv_diag[lane + 64] = d_rcp(sh.L[tri(lane + 64) + lane + 64]);
+        wave_sync_lds();
+      }
+      if (appended && n_dropped == 0) {
+        const bool in0 = lane < nn, in1 = lane + 64 < nn;
+        const double* row0 = sh.L + tri(lane);
+        const double* row1 = sh.L + tri(lane + 64);
+        double inv_j = nn > 0 ? sh.inv_diag[0] : 0.0;
+        double l0 = in0 && lane > 0 ? row0[0] : 0.0, l1 = in1 ? row1[0] : 0.0;
+        for (int j = 0; j < nn; ++j) {
+          const int jn = j + 1 < nn ? j + 1 : j;
+          const double inv_next = sh.inv_diag[jn];
+          const double l0_next = in0 && lane > jn ? row0[jn] : 0.0, l1_next = in1 && lane + 64 > jn ? row1[jn] : 0.0;
+          const double xj = readlane_f64(j < 64 ? b0 : b1, j & 63) * inv_j;
+          ssum = d_fma(xj, xj, ssum);
+          if (lane == 0) new_row[j] = xj;
+          if (in0 && lane > j) b0 = d_fma(-l0, xj, b0);
+          if (in1 && lane + 64 > j) b1 = d_fma(-l1, xj, b1);
+          inv_j = inv_next; l0 = l0_next; l1 = l1_next;
+        }
+      }
+      if (appended && lane == 0) {
+        const double dd = sqrt(kGpSigma2 + kGpNoise2 - ssum);
+        new_row[nn] = dd;
+        sh.inv_diag[nn] = 1.0 / dd;
+      }
+      // identity padding up to the MFMA tile
+      for (int i = n_obs + lane; i < n_pad; i += 64) {
+        double* row = sh.L + tri(i);
+        for (int j = 0; j < i; ++j) row[j] = 0.0;
+        row[i] = 1.0;
+        sh.inv_diag[i] = 1.0;
+        sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0;
+      }
+    }
   } else if (wave >= 2) {
-    // -- K + noise, packed lower triangle; rows n_obs .. n_pad-1 are identity (padding to a
+    // -- refit path: K + noise, packed lower triangle; rows n_obs .. n_pad-1 are identity (padding to a
     //    multiple of the panel width: they factor to themselves and contribute nothing)
     const int total = tri(n_pad);
     for (int e = tid - 128; e < total; e += 128) {
@@ -340,16 +482,16 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   // of the trailing matrix, half = which half of the j range.
   {
     const int slot = tid >> 1, half = tid & 1;
-    for (int c0 = 0; c0 < n_pad; c0 += 8) {
+    for (int c0 = 0; c0 < (incremental ? 0 : n_pad); c0 += 8) {
       const int rows = n_pad - c0;
-      const bool is_matrix = slot < rows, is_rhs = false;
+      const bool is_matrix = slot < rows;
       const int i = c0 + slot;                                   // matrix row
-      double* rowbase = is_matrix ? sh.L + tri(i) : sh.z[is_rhs ? slot - rows : 0];
-      const int width = is_matrix ? (slot < 8 ? slot + 1 : 8) : 8;   // stored columns of this row inside the panel
+      double* rowbase = sh.L + tri(is_matrix ? i : 0);
+      const int width = slot < 8 ? slot + 1 : 8;   // stored columns of this row inside the panel
       double acc[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-      if (is_matrix || is_rhs) {
+      if (is_matrix) {
         const double* col[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) col[c] = sh.L + tri(c0 + c);
@@ -364,7 +506,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       for (int c = 0; c < 8; ++c) acc[c] += quad_swap(acc[c], 1);
       double av[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) av[c] = ((is_matrix || is_rhs) && c < width) ? rowbase[c0 + c] - acc[c] : 0.0;
+      for (int c = 0; c < 8; ++c) av[c] = (is_matrix && c < width) ? rowbase[c0 + c] - acc[c] : 0.0;
       // the panel's own rows publish their updated entries: the 8 x 8 diagonal block
       if (is_matrix && slot < 8 && half == 0) {
 #pragma unroll
@@ -377,7 +519,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       double xr[8], invd[8], dd[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) { xr[c] = 0.0; invd[c] = 0.0; dd[c] = 0.0; }
-      if (is_matrix || is_rhs) {
+      if (is_matrix) {
         // every thread factors the diagonal block in registers (SIMT: free) ...
         double d[8][8];
 #pragma unroll
@@ -406,10 +548,10 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         }
       }
       __syncthreads();        // all reads of the un-factored diagonal block are done
-      if ((is_matrix || is_rhs) && half == 0) {
+      if (is_matrix && half == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-          if (c < width) rowbase[c0 + c] = (is_matrix && c == slot) ? dd[c] : xr[c];
+          if (c < width) rowbase[c0 + c] = c == slot ? dd[c] : xr[c];
         if (slot == 0) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) sh.inv_diag[c0 + c] = invd[c];
@@ -422,8 +564,6 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   BLE_MARK();
 
   // ---- phases 4 + 5: the 181-level column
-  const double p_lo = sh.p_lo, p_hi = sh.p_hi;
-  if (sh.range_ok == 0) flags |= kFlagPressureSearch;
   const double p_clamped = p < 5000.0 ? 5000.0 : (p > 14000.0 ? 14000.0 : p);
   const int level_now = (int)d_rint((p_clamped - 5000.0) / 50.0);       // Python round(): half to even
   const int pad_above = kObsLevels - level_now - 1;
@@ -446,6 +586,9 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     }
   }
   __syncthreads();
+  // (lane 0's pressure-range search above is ordered before these reads by the barrier)
+  const double p_lo = sh.p_lo, p_hi = sh.p_hi;
+  if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
   // -- V = L^-1 [K*^T | y] with v_mfma_f64_16x16x4: wave w owns query columns 48 w .. 48 w + 47
   // (3 tiles of 16); columns 181 and 182 are the two error vectors, so z = L^-1 y falls out of
@@ -590,6 +733,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     for (int k = 0; k < 3; ++k) out[kObsDim - 12 + k] = sh.role_t[k];
   }
 #endif
+  // the factor of this window goes back to HBM for the next call
+  if (chol_g != nullptr) {
+    const int total = tri(n_obs);
+    for (int e = tid; e < total; e += kObsBlock) chol_g[e] = sh.L[e];
+    if (tid == 0) hist.n_chol[env] = n_obs;
+  }
   // every lane has read the old count long before this point (barriers above)
   if (tid == 0) hist.count[env] = count;
   if (err_flags != nullptr && flags != 0) atomicOr(err_flags, flags);

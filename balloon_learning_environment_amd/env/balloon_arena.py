@@ -62,6 +62,12 @@ class VecBalloonArena:
     """actions: uint8 device tensor [N] -> (reward [N] f32, terminal [N] u8) device tensors."""
     return self.sim.step(actions, noise_uv)
 
+  def observe(self, noise_uv: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Perciatelli observation of every env: [N, 1099] float32 device tensor (features.py:301-330 on
+    the device, WindGP history kept per env).  `noise_uv`: measured minus forecast wind at the
+    balloons' current positions."""
+    return self.sim.observe(noise_uv, out=out)
+
   # ---- per-env views -----------------------------------------------------------------
   def row(self, i: int) -> dict:
     return {name: t[i].item() for name, t in self.sim.state.items()}

@@ -107,9 +107,11 @@ class VecSimulator:
 
   # ------------------------------------------------------------------ observation
   def observe(self, noise_uv: Optional[torch.Tensor] = None, append: bool = True,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, carry_factor: bool = True) -> torch.Tensor:
     """PerciatelliFeatureConstructor.observe + get_features for every env: [n, 1099] float32
-    device tensor.  `noise_uv` [n, 2]: measured wind minus forecast at the balloons (None = 0)."""
+    device tensor.  `noise_uv` [n, 2]: measured wind minus forecast at the balloons (None = 0).
+    carry_factor (fixed by the first call): keep each env's WindGP Cholesky factor in HBM (58 KB per
+    env) and slide it from step to step instead of refactoring the whole window every call."""
     assert self.grid is not None, 'Must call set_grid (reset) before observe.'
     if self._gp is None:
       with torch.cuda.device(self.device):
@@ -118,10 +120,15 @@ class VecSimulator:
                         elapsed_s=torch.zeros(self.n, cap, dtype=torch.int32, device=self.device),
                         err_uv=torch.zeros(self.n, cap, 2, dtype=torch.float32, device=self.device),
                         count=torch.zeros(self.n, dtype=torch.int32, device=self.device))
+        if carry_factor:
+          self._gp['chol'] = torch.zeros(self.n, _lib.GP_CHOL_STRIDE, dtype=torch.float64, device=self.device)
+          self._gp['n_chol'] = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         self._obs_reset = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
         self._gp_struct = _abi.BleGpHistoryF32()
         for name, ct in (('xyp', ctypes.c_float), ('elapsed_s', ctypes.c_int32), ('err_uv', ctypes.c_float),
-                         ('count', ctypes.c_int32)):
+                         ('count', ctypes.c_int32), ('chol', ctypes.c_double), ('n_chol', ctypes.c_int32)):
+          if name not in self._gp:
+            continue
           setattr(self._gp_struct, name, ctypes.cast(ctypes.c_void_p(self._gp[name].data_ptr()), ctypes.POINTER(ct)))
     if noise_uv is not None:
       assert noise_uv.dtype == torch.float32 and noise_uv.is_contiguous() and tuple(noise_uv.shape) == (self.n, 2)

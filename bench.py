@@ -69,6 +69,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--active-count', action='store_true', help='analysis only: use the in-kernel live-env counter')
   ap.add_argument('--substeps', type=int, default=18, help='analysis only: physics substeps per agent step (18 = the metric)')
+  ap.add_argument('--observe', type=int, default=0, metavar='N',
+                  help='extra leg (not part of `value`): N timed step+observation pairs with the full 1099-feature '
+                       'Perciatelli observation (ble_observe_f32) after the WindGP window (120 observations) has filled')
   args = ap.parse_args()
 
   import numpy as np
@@ -165,6 +168,34 @@ def main():
     except Exception:
       traffic = None
 
+  # ---- optional leg: observation-inclusive stepping, reported beside `value`
+  observe_leg = None
+  if args.observe > 0:
+    sim.set_state(state)                                  # fresh episodes
+    obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
+    one = torch.zeros(n, dtype=torch.uint8, device=device)
+    sim.reset_observation_history()
+    fill = 121                                            # 6 h window = 120 observations; 121st call slides it
+    for i in range(fill):
+      sim.step(actions[i % k_total])
+      sim.observe(out=obs)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+    t_obs = 0.0; t_pair = 0.0
+    for i in range(args.observe):
+      e0.record(); sim.step(actions[(fill + i) % k_total]); e1.record(); sim.observe(out=obs); e2.record()
+      torch.cuda.synchronize()
+      t_obs += e1.elapsed_time(e2); t_pair += e0.elapsed_time(e2)
+    sim.check_errors()
+    live = float((sim.state['status'] == 0).sum().item())
+    observe_leg = {'pairs': args.observe, 'ms_per_observation_launch': t_obs / args.observe,
+                   'ms_per_step_plus_observation': t_pair / args.observe,
+                   'env_observations_per_s': n * args.observe / (t_obs * 1e-3),
+                   'env_steps_per_s_with_observation': n * args.observe / (t_pair * 1e-3),
+                   'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
+                   'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)'}
+    del one
+
   if rank == 0:
     out = {
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
@@ -183,6 +214,8 @@ def main():
                      'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
                      'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)'},
     }
+    if observe_leg is not None:
+      out['observe'] = observe_leg
     if world == 1 and not args.no_cpu_baseline:
       acts = actions[:64].cpu().numpy()
       out['cpu_baseline'] = cpu_baseline(state, list(acts), field)

@@ -207,11 +207,16 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
  */
 #define BLE_OBS_DIM 1099
 #define BLE_GP_CAPACITY 128
+#define BLE_GP_CHOL_STRIDE 7260 /* 120 * 121 / 2 doubles */
 typedef struct ble_gp_history_f32 {
   float* xyp;         /* [n][BLE_GP_CAPACITY][3]  x m, y m, pressure Pa */
   int32_t* elapsed_s; /* [n][BLE_GP_CAPACITY]     time_elapsed of the observation */
   float* err_uv;      /* [n][BLE_GP_CAPACITY][2]  measured - forecast, m/s */
   int32_t* count;     /* [n] observations appended this episode; ring slot = count % BLE_GP_CAPACITY */
+  double* chol;       /* optional [n][BLE_GP_CHOL_STRIDE]: packed lower Cholesky factor of the current window's
+                         K + noise, carried from call to call so that the per-step refit of the reference
+                         (wind_gp.py:186-188) becomes an O(n^2) slide; NULL = refit in LDS every call */
+  int32_t* n_chol;    /* [n] rows of `chol` in use (required when chol != NULL), zero-initialised */
 } ble_gp_history_f32;
 int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
                     const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,

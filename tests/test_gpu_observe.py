@@ -43,7 +43,7 @@ def check(got, want, what):
   return err
 
 
-def drive_fixture(vec_state, name, envs):
+def drive_fixture(vec_state, name, envs, carry=True):
   g = helpers.golden(name)
   field = helpers.fixture_field(g)
   sim = vec_state.VecSimulator(len(envs))
@@ -56,23 +56,27 @@ def drive_fixture(vec_state, name, envs):
     fu, fv = oracle.wind_forecast(field, [r['x'] for r in rows], [r['y'] for r in rows], [r['pressure'] for r in rows],
                                   [r['time_elapsed_s'] for r in rows])
     noise = np.stack([g['wind_measured'][envs, i, 0] - fu, g['wind_measured'][envs, i, 1] - fv], 1).astype(np.float32)
-    out[:, i] = sim.observe(torch.from_numpy(noise).cuda()).cpu().numpy()
+    out[:, i] = sim.observe(torch.from_numpy(noise).cuda(), carry_factor=carry).cpu().numpy()
     sim.check_errors()
   return out, g
 
 
-def test_observe_matches_reference_features(vec_state):
-  got, g = drive_fixture(vec_state, 'f11_features', [0, 1, 2])
+@pytest.mark.parametrize('carry', [True, False])
+def test_observe_matches_reference_features(vec_state, carry):
+  """carry=True: the WindGP factor is slid from call to call (HBM-resident); False: refit in LDS."""
+  got, g = drive_fixture(vec_state, 'f11_features', [0, 1, 2], carry)
   err = check(got, g['features'], 'F11')
   print('F11 device observation: max |diff| %.3g, median of non-zero %.3g' % (err.max(), np.median(err[err > 0])))
 
 
-def test_observe_long_horizon_matches_reference(vec_state):
-  got, g = drive_fixture(vec_state, 'f12_features_long', [0])
+@pytest.mark.parametrize('carry', [True, False])
+def test_observe_long_horizon_matches_reference(vec_state, carry):
+  got, g = drive_fixture(vec_state, 'f12_features_long', [0], carry)
   check(got[:, -16:], g['features'], 'F12')
 
 
-def test_observe_rollout_matches_oracle(vec_state):
+@pytest.mark.parametrize('carry', [True, False])
+def test_observe_rollout_matches_oracle(vec_state, carry):
   """48 environments flown by the step kernel for 130 agent steps with random actions and a
   random measured-minus-forecast term; every 10th step (and the last 12) is compared."""
   import features_oracle
@@ -90,7 +94,7 @@ def test_observe_rollout_matches_oracle(vec_state):
       actions = torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda()
       sim.step(actions)
     noise = (rng.standard_normal((n, 2)) * 1.5).astype(np.float32)
-    obs = sim.observe(torch.from_numpy(noise).cuda()).cpu().numpy()
+    obs = sim.observe(torch.from_numpy(noise).cuda(), carry_factor=carry).cpu().numpy()
     sim.check_errors()
     state = sim.get_state()
     alive = state['status'] == 0
@@ -106,7 +110,7 @@ def test_observe_rollout_matches_oracle(vec_state):
         want = oracles[j].features()
         err = check(obs[j], want, f'env {j} step {i}')
         worst = max(worst, err.max())
-  print('rollout vs oracle: worst |diff| %.3g' % worst)
+  print('rollout vs oracle (carry=%s): worst |diff| %.3g' % (carry, worst))
 
 
 def test_observe_api_behaviour(vec_state):
