@@ -35,7 +35,7 @@ def main(tag):
   meta = {}
   for name in sorted(os.listdir(base)):
     p = os.path.join(base, name, f'{name}_counter_collection.csv')
-    if not os.path.exists(p):
+    if not os.path.exists(p) or name.startswith('pmc_obs'):     # pmc_obs*: the --observe leg, summarised below
       continue
     with open(p) as f:
       for r in csv.DictReader(f):
@@ -74,6 +74,32 @@ def main(tag):
                   'tcc_hit': avg.get('TCC_HIT_sum'), 'tcc_miss': avg.get('TCC_MISS_sum')}
     json.dump({'hbm_bytes_per_launch': fetch + write, 'source': f'profiles/{tag}_summary.json'},
               open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
+  # ---- observation kernel (bench.py --observe leg)
+  obs_md = []
+  obs_stats = os.path.join(base, 'trace_obs', 'trace_obs_kernel_stats.csv')
+  if os.path.exists(obs_stats):
+    with open(obs_stats) as f:
+      rows = list(csv.DictReader(f))
+    obs_md = ['| kernel | calls | avg us | min us | max us | % |', '|---|---|---|---|---|---|']
+    for r in rows[:6]:
+      obs_md.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
+                    f"{float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
+      if 'ble_observe_kernel' in r['Name']:
+        out['observe_kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
+                                       'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3}
+    oc = collections.defaultdict(list)
+    for name in ('pmc_obs1', 'pmc_obs2'):
+      p = os.path.join(base, name, f'{name}_counter_collection.csv')
+      if os.path.exists(p):
+        with open(p) as f:
+          for r in csv.DictReader(f):
+            if 'ble_observe_kernel' in r['Kernel_Name']:
+              oc[r['Counter_Name']].append(float(r['Counter_Value']))
+              out['observe_dispatch'] = {'grid': int(r['Grid_Size']), 'wg': int(r['Workgroup_Size']), 'vgpr': int(r['VGPR_Count']),
+                                         'agpr': int(r['Accum_VGPR_Count']), 'sgpr': int(r['SGPR_Count']),
+                                         'scratch': int(r['Scratch_Size']), 'lds': int(r['LDS_Block_Size'])}
+    # the last launches are the steady state (window full); average the final 8
+    out['observe_pmc_per_launch_steady'] = {k: sum(v[-8:]) / len(v[-8:]) for k, v in oc.items()}
   json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'), 'w'), indent=1)
   with open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.md'), 'w') as f:
     f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 192 --warmup 32` (one launch = 32 agent steps) ({tag})\n\n')
@@ -81,6 +107,11 @@ def main(tag):
     f.write('## ble_step_kernel PMC (per launch averages; separate --pmc passes)\n\n```json\n')
     f.write(json.dumps({k: out[k] for k in ('dispatch', 'derived', 'hbm') if k in out}, indent=1))
     f.write('\n```\n')
+    if obs_md:
+      f.write('\n# `python bench.py --steps 32 --warmup 32 --observe 8`: 121 window-filling + 8 timed step/observation pairs\n\n')
+      f.write('\n'.join(obs_md) + '\n\n## ble_observe_kernel PMC (steady state: last 8 launches)\n\n```json\n')
+      f.write(json.dumps({k: out[k] for k in ('observe_dispatch', 'observe_pmc_per_launch_steady') if k in out}, indent=1))
+      f.write('\n```\n')
   print(json.dumps(out, indent=1))
 
 
