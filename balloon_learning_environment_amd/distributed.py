@@ -73,6 +73,41 @@ class OutputGatherer:
       torch.cuda.current_stream(self.reward.device).wait_stream(self.stream)
 
 
+class ObservationGatherer:
+  """Collects the [n_local, 1099] observation blocks of every rank on rank `dst` (the learner):
+  one point-to-point `gather` per observation launch (4 396 B per env; 288 MB per exchange
+  for 65 536 envs per GPU), on a side stream like OutputGatherer.  Double-buffered on the
+  producer side: the kernel of step t+1 may overwrite its output while step t is in flight."""
+
+  def __init__(self, n_local: int, obs_dim: int, device, world: Optional[int] = None, dst: int = 0):
+    initialized = dist.is_available() and dist.is_initialized()
+    self.world = world if world is not None else (dist.get_world_size() if initialized else 1)
+    self.rank = dist.get_rank() if initialized else 0
+    self.dst, self.is_dst = dst, self.rank == dst
+    rows = self.world if self.is_dst else 0
+    self.obs = torch.zeros((rows, n_local, obs_dim), dtype=torch.float32, device=device)
+    self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+
+  def gather(self, block: torch.Tensor) -> None:
+    if self.world == 1:
+      self.obs[0].copy_(block)
+      return
+
+    def go():
+      dist.gather(block, [self.obs[r] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
+    if self.stream is not None:
+      self.stream.wait_stream(torch.cuda.current_stream(block.device))
+      with torch.cuda.stream(self.stream):
+        go()
+        block.record_stream(self.stream)
+    else:
+      go()
+
+  def wait(self) -> None:
+    if self.stream is not None:
+      torch.cuda.current_stream(self.obs.device).wait_stream(self.stream)
+
+
 def max_over_ranks(value: float, device) -> float:
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
     return value

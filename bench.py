@@ -175,6 +175,7 @@ def main():
     obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
     one = torch.zeros(n, dtype=torch.uint8, device=device)
     sim.reset_observation_history()
+    obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world) if world > 1 else None
     fill = 121                                            # 6 h window = 120 observations; 121st call slides it
     for i in range(fill):
       sim.step(actions[i % k_total])
@@ -183,7 +184,10 @@ def main():
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
     t_obs = 0.0; t_pair = 0.0
     for i in range(args.observe):
-      e0.record(); sim.step(actions[(fill + i) % k_total]); e1.record(); sim.observe(out=obs); e2.record()
+      e0.record(); sim.step(actions[(fill + i) % k_total]); e1.record(); sim.observe(out=obs)
+      if obs_gatherer is not None:                         # "observations gathered back" (north star), 4 396 B/env
+        obs_gatherer.gather(obs); obs_gatherer.wait()
+      e2.record()
       torch.cuda.synchronize()
       t_obs += e1.elapsed_time(e2); t_pair += e0.elapsed_time(e2)
     sim.check_errors()

@@ -48,7 +48,11 @@ def _worker(rank, world, port, out_dir):
     g.gather(reward.contiguous(), terminal.contiguous())
     g.wait()
     mx = bdist.max_over_ranks(float(rank + 1), 'cpu'); sm = bdist.sum_over_ranks(float(rank + 1), 'cpu')
-    torch.save(dict(grid=grid, reward=g.reward, terminal=g.terminal, mx=mx, sm=sm), os.path.join(out_dir, f'r{rank}.pt'))
+    # observation blocks [n_local, 1099] to rank 0
+    og = bdist.ObservationGatherer(hi - lo, 1099, 'cpu', world)
+    og.gather((env_ids[:, None] + torch.arange(1099, dtype=torch.float32)[None, :] / 2048).contiguous())
+    og.wait()
+    torch.save(dict(grid=grid, reward=g.reward, terminal=g.terminal, mx=mx, sm=sm, obs=og.obs), os.path.join(out_dir, f'r{rank}.pt'))
   finally:
     dist.destroy_process_group()
 
@@ -69,3 +73,7 @@ def test_broadcast_and_gather_world2(tmp_path):
   tglob = torch.cat([o['terminal'][r] for r in range(world)], dim=1)
   assert torch.equal(tglob, (expect.to(torch.int64) % 3 == 0).to(torch.uint8))
   assert outs[1]['reward'].numel() == 0                   # senders keep nothing
+  obs = torch.cat([o['obs'][r] for r in range(world)], dim=0)
+  assert obs.shape == (12, 1099)
+  assert torch.equal(obs, torch.arange(12, dtype=torch.float32)[:, None] + torch.arange(1099, dtype=torch.float32)[None, :] / 2048)
+  assert outs[1]['obs'].numel() == 0                      # only the destination rank holds the gathered blocks
