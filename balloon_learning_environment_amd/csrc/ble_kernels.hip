@@ -259,6 +259,44 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
 }
 
+// Decoder tail of the wind-field VAE (generative/vae.py:149-186): flow fields psi [n][7][7][90]
+// (the last Dense layer's output, flow-field index fastest) -> half-pixel linear resize to
+// 23 x 23 (jax.image.resize 'linear': triangle kernel, edge weights renormalised == clamped
+// taps) -> central differences u = d psi / dy, v = -d psi / dx on the interior 21 x 21 ->
+// the wind grid [n][21][21][10][9][2] the step kernel reads (grid_env_stride = 79 380).
+// One thread per (i, j, field): 16 cached reads, one 8-byte store; the 90 x 2 floats of an
+// (i, j) cell are contiguous, so both sides are coalesced.  HBM-bound: 317.5 KB written per env.
+__global__ __launch_bounds__(256) void ble_decode_flow_kernel(const float* __restrict__ flow, float* __restrict__ grid,
+                                                              int64_t n) {
+  __shared__ int tap0[23];
+  __shared__ float w1[23];
+  if (threadIdx.x < 23) {
+    const float x = ((float)threadIdx.x + 0.5f) * (7.0f / 23.0f) - 0.5f;
+    const float fl = floorf(x);
+    tap0[threadIdx.x] = (int)fl;
+    w1[threadIdx.x] = x - fl;
+  }
+  __syncthreads();
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int64_t env = blockIdx.y;
+  if (idx >= 21 * 21 * 90 || env >= n) return;
+  const int f = idx % 90, ij = idx / 90, i = ij / 21, j = ij % 21;
+  const float* psi = flow + env * (7 * 7 * 90) + f;
+  auto resized = [&](int a, int b) {       // psi resized at (a, b) of the 23 x 23 lattice
+    const int a0 = tap0[a], b0 = tap0[b];
+    const int a_lo = a0 < 0 ? 0 : a0, a_hi = a0 + 1 > 6 ? 6 : a0 + 1;
+    const int b_lo = b0 < 0 ? 0 : b0, b_hi = b0 + 1 > 6 ? 6 : b0 + 1;
+    const float wa = w1[a], wb = w1[b];
+    const float lo = f_fma(wb, psi[(a_lo * 7 + b_hi) * 90] - psi[(a_lo * 7 + b_lo) * 90], psi[(a_lo * 7 + b_lo) * 90]);
+    const float hi = f_fma(wb, psi[(a_hi * 7 + b_hi) * 90] - psi[(a_hi * 7 + b_lo) * 90], psi[(a_hi * 7 + b_lo) * 90]);
+    return f_fma(wa, hi - lo, lo);
+  };
+  const float u = 0.5f * (resized(i + 2, j + 1) - resized(i, j + 1));
+  const float v = -0.5f * (resized(i + 1, j + 2) - resized(i + 1, j));
+  float2* out = reinterpret_cast<float2*>(grid + env * (int64_t)(21 * 21 * 90 * 2)) + idx;
+  *out = make_float2(u, v);
+}
+
 // Episode reset for the lanes selected by `mask` (all lanes if mask == nullptr).
 // sample != 0: draw the initial conditions (utils/sampling.py, balloon_arena.py:228-268) from
 // Philox(seed, env, episode[i]); sample == 0: keep x, y, pressure, centre lat/lng, IR, alpha,
@@ -456,6 +494,14 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
   if (h.chol != nullptr && h.n_chol == nullptr) return BLE_E_INVALID_ARG;
   BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, *st, wind_grid,
              grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
+  return launch_status();
+}
+
+int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream) {
+  if (!flow || !wind_grid || n < 0 || n > 65535) return BLE_E_INVALID_ARG;     // gridDim.y limit; call in slices
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(ble_decode_flow_kernel, dim3((21 * 21 * 90 + 255) / 256, (unsigned)n), dim3(256), 0, (hipStream_t)stream, flow,
+             wind_grid, n);
   return launch_status();
 }
 

@@ -222,6 +222,15 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
                     const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,
                     int append, float* obs, uint32_t* err_flags, int64_t n, void* stream);
 
+/*
+ * Tail of the wind-field VAE decoder (generative/vae.py:149-186, Decoder.__call__ after the
+ * last Dense layer): n sets of 7 x 7 x 90 flow fields -> half-pixel linear resize to 23 x 23
+ * -> central differences -> n wind grids [21][21][10][9][2] (grid_env_stride = 79 380 floats).
+ * The four Dense layers before it are plain GEMMs (rocBLAS/hipBLASLt through torch.matmul).
+ * n <= 65535 per call.
+ */
+int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream);
+
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,
                         uint32_t* err_flags, int64_t n, void* stream);
