@@ -69,6 +69,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--active-count', action='store_true', help='analysis only: use the in-kernel live-env counter')
   ap.add_argument('--substeps', type=int, default=18, help='analysis only: physics substeps per agent step (18 = the metric)')
+  ap.add_argument('--per-env-grids', action='store_true',
+                  help='BASELINE config 5 shape: every env flies in its own forecast, decoded on the device by the '
+                       'VAE-decoder restatement (synthetic weights); use with --envs-per-gpu 32768 (10.4 GB of grids)')
   ap.add_argument('--observe', type=int, default=0, metavar='N',
                   help='extra leg (not part of `value`): N timed step+observation pairs with the full 1099-feature '
                        'Perciatelli observation (ble_observe_f32) after the WindGP window (120 observations) has filled')
@@ -108,7 +111,20 @@ def main():
     field = (np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).astype(np.float32)
     grid.copy_(torch.from_numpy(field))
   bdist.broadcast_grid(grid, src=0)                     # once per field, over xGMI when world > 1
-  sim.set_grid(grid)
+  decode_ms = None
+  if args.per_env_grids:
+    # config 5: no broadcast at all -- every rank decodes its own latents into per-env grids
+    from balloon_learning_environment_amd.env import generative_wind_field
+    sampler = generative_wind_field.GenerativeWindFieldSampler(device=device, seed=0)
+    latents = sampler.sample_latents(n, seed=100 + rank)
+    grids = torch.empty((n, 21, 21, 10, 9, 2), dtype=torch.float32, device=device)
+    sampler.decode(latents[:256], grids[:256]); torch.cuda.synchronize()
+    d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
+    d0.record(); sampler.decode(latents, grids); d1.record(); torch.cuda.synchronize()
+    decode_ms = d0.elapsed_time(d1)
+    sim.set_grid(grids, per_env=True)
+  else:
+    sim.set_grid(grid)
   gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
   actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
   rewards = torch.zeros((k_total, n), dtype=torch.float32, device=device)
@@ -206,10 +222,13 @@ def main():
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{n} vectorised envs per GPU, random policy, one decoded wind grid '
-                               '(BASELINE.json configs[2]: 65 536 envs, 1xMI355X headline)',
+        'config': {'workload': (f'{n} vectorised envs per GPU, random policy, per-env forecasts decoded on the device '
+                                '(BASELINE.json configs[4] shape: VAE path, synthetic weights)' if args.per_env_grids else
+                                f'{n} vectorised envs per GPU, random policy, one decoded wind grid '
+                                '(BASELINE.json configs[2]: 65 536 envs, 1xMI355X headline)'),
                    'envs_per_gpu': n, 'global_envs': n * world, 'substeps_per_step': args.substeps,
                    'live_env_fraction_end': float(live_per_step[-1].item()) / n,
+                   'per_env_grids': bool(args.per_env_grids), 'decode_ms': decode_ms,
                    'parallelism': f'env-sharded x{world}, grid broadcast once, reward/terminal gather to rank 0 every {GATHER_EVERY} steps'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
