@@ -148,3 +148,19 @@ def test_feature_driven_controller_beats_random(mods):
   rng = random.Random(3)
   seeds = (11, 12, 13)
   assert sum(run(greedy, s) for s in seeds) > sum(run(lambda o: rng.randrange(3), s) for s in seeds)
+
+
+def test_device_feature_constructor_matches_host(mods):
+  """BalloonEnv with the device observation (ble_observe_f32, n = 1) against the host constructor
+  on the same seed, actions and (Gaussian) grid wind field: identical discrete pattern, <= 2e-4."""
+  _, balloon_env, features, _ = mods
+  host = balloon_env.BalloonEnv(seed=21)
+  dev = balloon_env.BalloonEnv(seed=21, feature_constructor_factory=features.DevicePerciatelliFeatureConstructor)
+  for i in range(25):
+    a = (i * 7) % 3
+    oh, rh, th, _ = host.step(a)
+    od, rd, td, _ = dev.step(a)
+    assert rh == rd and th == td
+    unreach = lambda f: (f[16::3] == 0) & (f[17::3] == 1) & (f[18::3] == 1)
+    np.testing.assert_array_equal(unreach(oh), unreach(od))
+    assert np.abs(oh.astype(np.float64) - od).max() <= 2e-4
