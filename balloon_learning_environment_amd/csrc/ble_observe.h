@@ -35,7 +35,8 @@ constexpr int kObsDim = 3 * kObsColumn + 16;        // 1099
 constexpr int kGpCapacity = 128;                    // ring entries per env (BLE_GP_CAPACITY)
 constexpr int kGpMax = 120;                         // 6 h / 180 s
 constexpr int kGpRows = 128;
-constexpr int kCholStride = kGpMax * (kGpMax + 1) / 2;   // 7260 doubles = 58 080 B per environment                        // kGpMax rounded up to the MFMA tile
+constexpr int kCholStride = kGpMax * (kGpMax + 1) / 2;   // 7260 doubles = 58 080 B per environment
+constexpr int kCholPrefetch = (kCholStride / 2 + 255) / 256;   // double2 loads per lane (15)                        // kGpMax rounded up to the MFMA tile
 constexpr int kObsBlock = 256;
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
@@ -173,6 +174,16 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   int n_chol0 = hist.chol != nullptr ? hist.n_chol[env] : 0;
   if (reset_mask != nullptr && reset_mask[env] != 0) { count = 0; n_chol0 = 0; }
   const int count0 = count;
+  // The stored factor (58 KB) is requested now, 16 B per lane and 15 loads in flight, and lands in
+  // LDS after the solar table has been computed: its HBM latency hides behind phase 0b.
+  double* chol_g = hist.chol != nullptr ? hist.chol + env * kCholStride : nullptr;
+  const int chol_pairs = (tri(n_chol0 <= kGpMax ? n_chol0 : 0) + 1) >> 1;
+  double2 chol_pre[kCholPrefetch];
+#pragma unroll
+  for (int i = 0; i < kCholPrefetch; ++i) {
+    const int e2 = tid + kObsBlock * i;
+    chol_pre[i] = (chol_g != nullptr && e2 < chol_pairs) ? reinterpret_cast<const double2*>(chol_g)[e2] : make_double2(0.0, 0.0);
+  }
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -279,10 +290,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     incremental = hist.chol != nullptr && drop == 0 && last_invalid < first_valid && n_dropped >= 0 &&
                   n_dropped <= n_chol0 && n_chol0 <= kGpMax;
   }
-  double* chol_g = hist.chol != nullptr ? hist.chol + env * kCholStride : nullptr;
   if (incremental) {
-    const int total = tri(n_chol0);
-    for (int e = tid; e < total; e += kObsBlock) sh.L[e] = chol_g[e];
+#pragma unroll
+    for (int i = 0; i < kCholPrefetch; ++i) {
+      const int e2 = tid + kObsBlock * i;
+      if (e2 < chol_pairs) reinterpret_cast<double2*>(sh.L)[e2] = chol_pre[i];
+    }
   }
   __syncthreads();   // B2
 
@@ -359,45 +372,65 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         // substitution: column k of the new factor is used the moment it exists (no LDS read).
         const bool fuse = appended && rep == n_dropped - 1;
         const int rows = n_cur - 1;
-        double x0 = lane < rows ? sh.L[tri(lane + 1)] : 0.0;
-        double x1 = lane + 64 < rows ? sh.L[tri(lane + 65)] : 0.0;
         const bool own0 = lane < rows, own1 = lane + 64 < rows;
-        const double* row0 = sh.L + tri(lane + 1) + 1;       // old row lane + 1, shifted one column
-        const double* row1 = sh.L + tri(lane + 65) + 1;
-        // the loads of step k + 1 are issued during step k: none of this sweep's stores aliases them
-        double lkk = sh.L[tri(1) + 1];
-        double lik0 = own0 && lane > 0 ? row0[0] : 0.0, lik1 = own1 ? row1[0] : 0.0;
-        for (int k = 0; k < rows; ++k) {
+        double x0 = own0 ? sh.L[tri(lane + 1)] : 0.0;
+        double x1 = own1 ? sh.L[tri(lane + 65)] : 0.0;
+        // Old row i + 1 shifted one column; lanes that own no row read in-bounds garbage that only
+        // ever reaches their private x / b, which nobody reads (readlane targets owner lanes only).
+        const double* old0 = sh.L + tri(own0 ? lane + 1 : 1) + 1;
+        const double* old1 = sh.L + tri(own1 ? lane + 65 : 1) + 1;
+        double* new0 = sh.L + tri(lane);
+        double* new1 = sh.L + tri(lane + 64);
+        // what lane k (rows k and k + 64) will write when the sweep is over
+        double diag0 = 0.0, diag1 = 0.0, row0 = 0.0, row1 = 0.0, inv0 = 1.0, inv1 = 1.0;
+        // loads and the reciprocal of step k + 1 are issued during step k (none of this sweep's
+        // stores aliases them; see the index argument above)
+        double lkk = sh.L[tri(1) + 1], il = d_rcp(lkk);
+        double lik0 = old0[0], lik1 = old1[0];
+        const int first = rows < 64 ? rows : 64;
+        for (int k = 0; k < first; ++k) {                 // rows k .. rows-1 live in both halves
           const int kn = k + 1 < rows ? k + 1 : k;
           const double lkk_next = sh.L[tri(kn + 1) + kn + 1];
-          const double lik0_next = own0 && lane > kn ? row0[kn] : 0.0;
-          const double lik1_next = own1 && lane + 64 > kn ? row1[kn] : 0.0;
-          const double xk = readlane_f64(k < 64 ? x0 : x1, k & 63);
+          const double lik0_next = old0[kn], lik1_next = old1[kn];
+          const double xk = readlane_f64(x0, k);
           const double r2 = d_fma(lkk, lkk, xk * xk);
-          const double ir = d_rsqrt(r2), il = d_rcp(lkk);
-          const double r = r2 * ir, c = r * il, sn = xk * il, ic = lkk * ir;
-          double ln0 = 0.0, ln1 = 0.0;
-          if (own0 && lane > k) {
-            ln0 = d_fma(sn, x0, lik0) * ic;
-            x0 = d_fma(c, x0, -sn * ln0);
-            sh.L[tri(lane) + k] = ln0;
-          }
-          if (own1 && lane + 64 > k) {
-            ln1 = d_fma(sn, x1, lik1) * ic;
-            x1 = d_fma(c, x1, -sn * ln1);
-            sh.L[tri(lane + 64) + k] = ln1;
-          }
-          if (fuse) {
-            const double xj = readlane_f64(k < 64 ? b0 : b1, k & 63) * ir;      // 1 / L'[k][k] == ir
-            ssum = d_fma(xj, xj, ssum);
-            b0 = d_fma(-ln0, xj, b0);
-            b1 = d_fma(-ln1, xj, b1);
-            if (lane == 0) { sh.L[tri(k) + k] = r; new_row[k] = xj; sh.inv_diag[k] = ir; }
-          } else if (lane == 0) {
-            sh.L[tri(k) + k] = r;
-          }
-          lkk = lkk_next; lik0 = lik0_next; lik1 = lik1_next;
+          const double ir = d_rsqrt(r2);
+          const double sn = xk * il, ic = lkk * ir;
+          const double n0 = d_fma(sn, x0, lik0) * ic, n1 = d_fma(sn, x1, lik1) * ic;
+          x0 = d_fma(-sn, lik0, x0) * ic;                // c x - s l_new == (x - s l_old) / c
+          x1 = d_fma(-sn, lik1, x1) * ic;
+          if (own0 && lane > k) new0[k] = n0;
+          if (own1) new1[k] = n1;
+          const double xj = fuse ? readlane_f64(b0, k) * ir : 0.0;      // 1 / L'[k][k] == ir
+          ssum = d_fma(xj, xj, ssum);
+          b0 = d_fma(-n0, xj, b0);
+          b1 = d_fma(-n1, xj, b1);
+          const bool mine = lane == k;
+          diag0 = mine ? r2 * ir : diag0; row0 = mine ? xj : row0; inv0 = mine ? ir : inv0;
+          const double il_next = d_rcp(lkk_next);
+          lkk = lkk_next; il = il_next; lik0 = lik0_next; lik1 = lik1_next;
         }
+        for (int k = 64; k < rows; ++k) {                 // only the upper halves are still live
+          const int kn = k + 1 < rows ? k + 1 : k;
+          const double lkk_next = sh.L[tri(kn + 1) + kn + 1];
+          const double lik1_next = old1[kn];
+          const double xk = readlane_f64(x1, k - 64);
+          const double r2 = d_fma(lkk, lkk, xk * xk);
+          const double ir = d_rsqrt(r2);
+          const double sn = xk * il, ic = lkk * ir;
+          const double n1 = d_fma(sn, x1, lik1) * ic;
+          x1 = d_fma(-sn, lik1, x1) * ic;
+          if (own1 && lane + 64 > k) new1[k] = n1;
+          const double xj = fuse ? readlane_f64(b1, k - 64) * ir : 0.0;
+          ssum = d_fma(xj, xj, ssum);
+          b1 = d_fma(-n1, xj, b1);
+          const bool mine = lane + 64 == k;
+          diag1 = mine ? r2 * ir : diag1; row1 = mine ? xj : row1; inv1 = mine ? ir : inv1;
+          const double il_next = d_rcp(lkk_next);
+          lkk = lkk_next; il = il_next; lik1 = lik1_next;
+        }
+        if (own0) { new0[lane] = diag0; if (fuse) { new_row[lane] = row0; sh.inv_diag[lane] = inv0; } }
+        if (own1) { new1[lane + 64] = diag1; if (fuse) { new_row[lane + 64] = row1; sh.inv_diag[lane + 64] = inv1; } }
         n_cur = rows;
         wave_sync_lds();
       }
@@ -735,8 +768,8 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
 #endif
   // the factor of this window goes back to HBM for the next call
   if (chol_g != nullptr) {
-    const int total = tri(n_obs);
-    for (int e = tid; e < total; e += kObsBlock) chol_g[e] = sh.L[e];
+    const int pairs = (tri(n_obs) + 1) >> 1;       // (an odd tail stores one unused double inside the slab)
+    for (int e2 = tid; e2 < pairs; e2 += kObsBlock) reinterpret_cast<double2*>(chol_g)[e2] = reinterpret_cast<const double2*>(sh.L)[e2];
     if (tid == 0) hist.n_chol[env] = n_obs;
   }
   // every lane has read the old count long before this point (barriers above)
