@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
                                                                 uint32_t* err_flags, int64_t n) {
   __shared__ ObsShared sh;
 #ifdef BLE_OBS_TIMING
-  long long tmark[8]; int nmark = 0;
+  long long tmark[12]; int nmark = 0;
 #define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define BLE_MARK() do {} while (0)
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     }
   }
   __syncthreads();
+  BLE_MARK();
   // (lane 0's pressure-range search above is ordered before these reads by the barrier)
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
@@ -662,18 +663,20 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       for (int v = 0; v < 4; ++v) {
         const int row = 16 * I + 4 * v + g;
         const double a_row = sh.a[row], p_row = sh.loc[row][2];
+        const double live = row < n_obs ? kGpSigma2 : 0.0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          double rhs;
-          if (qcol[t] < kObsLevels) {
-            const double dp = (level_q[t] - p_row) * (1.0 / 326.0);
-            const double r2 = a_row + dp * dp;
-            rhs = row < n_obs ? kGpSigma2 * d_exp_fast(r2 > 0.0 ? -(r2 * d_rsqrt(r2)) : 0.0) : 0.0;
-          } else {
-            rhs = qcol[t] == kObsLevels ? sh.z[0][row] : (qcol[t] == kObsLevels + 1 ? sh.z[1][row] : 0.0);
-          }
-          R[t][v] = rhs - acc[t][v];
+          // branch-free: every lane evaluates the kernel (columns past level 180 are simply unused)
+          const double dp = (level_q[t] - p_row) * (1.0 / 326.0);
+          const double r2 = a_row + dp * dp;
+          R[t][v] = live * d_exp_fast(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)));
         }
+        if (wave == 3) {        // uniform: tile 2 of wave 3 holds the error vectors in columns 181 / 182
+          const double zu = sh.z[0][row], zv = sh.z[1][row];
+          R[2][v] = jq < 5 ? R[2][v] : (jq == 5 ? zu : (jq == 6 ? zv : 0.0));
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) R[t][v] -= acc[t][v];
       }
       const double* drow = sh.dinv[I] + jq * 16 + g;
 #pragma unroll
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       }
     }
   }
+  BLE_MARK();
   __syncthreads();                 // every lane has read the raw error vectors
   if (wave == 3 && (jq == 5 || jq == 6)) {      // columns 181, 182 live in tile 2 of wave 3
 #pragma unroll
@@ -716,6 +720,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
     mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
   }
+  BLE_MARK();
   if (g == 0) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -762,8 +767,8 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   BLE_MARK();
   if (tid == 0)
   {
-    for (int k = 1; k < nmark; ++k) out[kObsDim - 8 + k] = (float)(tmark[k] - tmark[k - 1]);
-    for (int k = 0; k < 3; ++k) out[kObsDim - 12 + k] = sh.role_t[k];
+    for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
+    for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
   }
 #endif
   // the factor of this window goes back to HBM for the next call
