@@ -33,7 +33,14 @@ def perciatelli_reward_function(simulator_state: simulator_data.SimulatorState, 
 
 
 def generative_wind_field_factory(device='cuda:0'):
-  """The reference's default is the VAE sampler (weights absent); this is the synthetic stand-in."""
+  """GridBasedWindField over the VAE sampler, as in the reference (env/generative_wind_field.py:35-37).
+  The decoder runs on the device with synthetic weights (the trained blob is not in the checkout)."""
+  from balloon_learning_environment_amd.env import generative_wind_field
+  return grid_based_wind_field.GridBasedWindField(generative_wind_field.GenerativeWindFieldSampler(device=device), device)
+
+
+def gaussian_wind_field_factory(device='cuda:0'):
+  """White-noise grid (tests, worst case for the interpolation)."""
   return grid_based_wind_field.GridBasedWindField(grid_wind_field_sampler.GaussianFieldSampler(), device)
 
 
