@@ -160,3 +160,59 @@ def test_observe_invalid_arguments(vec_state):
   assert lib.ble_observe_f32(ctypes.byref(sim._struct), sim.grid.data_ptr(), 0, 0, 0, ctypes.byref(empty), 1,
                              obs.data_ptr(), 0, 2, 0) == -1
   assert lib.ble_observe_f32(ctypes.byref(sim._struct), sim.grid.data_ptr(), 0, 0, 0, None, 1, obs.data_ptr(), 0, 2, 0) == -1
+
+
+def test_observe_edge_cases_match_oracle(vec_state):
+  """Edge cases of the feature constructor (features.py:330-350,470-560): balloon on the station
+  (distance < 1e-5 m: bearing 0), still air (speed < 1e-5: bearing pi -> feature 1), pressures
+  outside the 5-14 kPa feature range (clamped level, saturated feature 0), paused navigation,
+  each last command, night / day, full and empty battery."""
+  import features_oracle
+  from balloon_learning_environment_amd import reset_host
+  n = 12
+  base = reset_host.sample_initial_state(n, seed=9)
+  st = {k: np.array(v, copy=True) for k, v in base.items()}
+  st['x'][0] = 0.0; st['y'][0] = 0.0                          # on the station
+  st['x'][1] = 3.0e-6; st['y'][1] = -2.0e-6                   # inside the tolerance
+  st['pressure'][2] = 4900.0; st['pressure'][3] = 14100.0     # outside the feature range
+  st['pressure'][4] = 5025.0; st['pressure'][5] = 5075.0      # Python round(): half to even (0.5 -> 0, 1.5 -> 2)
+  st['last_command'][6] = 0; st['last_command'][7] = 2
+  st['power_paused'][8] = 1; st['env_fsm'][9] = 2; st['alt_fsm'][10] = 1
+  st['battery_charge'][11] = 3058.56; st['battery_charge'][6] = 0.0
+  # consistent internal state for the edited pressures
+  atm = reset_host.AtmosphereTables(st['alpha'].astype(np.float64))
+  for j in (2, 3, 4, 5):
+    lat, lng = reset_host.latlng_from_offset(np.radians(st['center_lat_deg'][j:j + 1].astype(np.float64)),
+                                             np.radians(st['center_lng_deg'][j:j + 1].astype(np.float64)),
+                                             st['x'][j:j + 1].astype(np.float64), st['y'][j:j + 1].astype(np.float64))
+    sp = reset_host.stable_params(st['pressure'][j:j + 1].astype(np.float64), lat, lng, st['start_unix'][j:j + 1],
+                                  st['upwelling_infrared'][j:j + 1].astype(np.float64),
+                                  reset_host.AtmosphereTables(st['alpha'][j:j + 1].astype(np.float64)))
+    for k in ('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume', 'superpressure'):
+      st[k][j] = sp[k][0]
+  del atm
+  for field_scale in (0.0, 4.0):                               # still air, then a real field
+    field = (np.random.default_rng(2).standard_normal((21, 21, 10, 9, 2)) * field_scale).astype(np.float32)
+    sim = vec_state.VecSimulator(n)
+    sim.set_state(st)
+    sim.set_grid(torch.from_numpy(field).cuda())
+    obs = sim.observe().cpu().numpy()
+    sim.check_errors()
+    state = sim.get_state()
+    for j in range(n):
+      fo = features_oracle.FeatureOracle(field, float(state['alpha'][j]))
+      row = {k: float(state[k][j]) for k in helpers.STATE_FLOATS}
+      for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+        row[k] = float(state[k][j])
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
+        row[k] = int(state[k][j])
+      fo.observe(row, (0.0, 0.0))
+      check(obs[j], fo.features(), f'edge env {j} scale {field_scale}')
+    if field_scale == 0.0:
+      valid = ~UNREACHABLE(obs)
+      for j in range(2, n):                                    # still air: bearing pi (envs off the station)
+        assert (obs[j, 17::3][valid[j]] == 1.0).all()
+      assert (obs[0, 17::3][valid[0]] == 0.0).all() and (obs[1, 17::3][valid[1]] == 0.0).all()   # on the station: 0
+    assert obs[2, 0] == 0.0 and obs[3, 0] == 1.0
+    assert tuple(obs[6, 8:11]) == (0.0, 0.0, 1.0) and tuple(obs[7, 8:11]) == (1.0, 0.0, 0.0)
+    assert obs[8, 11] == 1.0 and obs[9, 11] == 1.0 and obs[10, 11] == 1.0 and obs[11, 11] == 0.0
