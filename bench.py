@@ -213,6 +213,7 @@ def main():
                    'env_observations_per_s': n * args.observe / (t_obs * 1e-3),
                    'env_steps_per_s_with_observation': n * args.observe / (t_pair * 1e-3),
                    'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
+                   'includes_gather_to_rank0': world > 1,
                    'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)'}
     del one
 
