@@ -452,7 +452,8 @@ BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, 
   const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;   // |y| ~ 2e-5: expm1 to y^3
   const double em1 = y * d_fma(y, d_fma(y, 1.0 / 6.0, 0.5), 1.0);
   // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
-  double inv = iso ? d_rcp((-kAirSpecificGasD / 9.80665) * t_p * lg) : lapse * d_rcp(t_p * em1);
+  // one reciprocal, selected operands (same values as the two-branch form, no divergence)
+  double inv = (iso ? 1.0 : lapse) * d_rcp(t_p * (iso ? (-kAirSpecificGasD / 9.80665) * lg : em1));
   const double q = p + d;
   // cur_hi / cur_lo: the transition pressures that bound the layer of p (+-inf if unknown/far)
   const bool below = q > cur_hi;            // q in the layer with higher pressure

@@ -216,3 +216,63 @@ def test_observe_edge_cases_match_oracle(vec_state):
     assert obs[2, 0] == 0.0 and obs[3, 0] == 1.0
     assert tuple(obs[6, 8:11]) == (0.0, 0.0, 1.0) and tuple(obs[7, 8:11]) == (1.0, 0.0, 0.0)
     assert obs[8, 11] == 1.0 and obs[9, 11] == 1.0 and obs[10, 11] == 1.0 and obs[11, 11] == 0.0
+
+
+@pytest.mark.parametrize('carry', [True, False])
+def test_observe_irregular_history_matches_oracle(vec_state, carry):
+  """Irregular use of the history: observations skipped for random stretches (several old
+  observations leave the 6 h window at once), get_features without observe after time has
+  advanced (drops only), and episode resets of a subset of the environments in mid-flight."""
+  import features_oracle
+  n, steps = 24, 200
+  rng = np.random.default_rng(17)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  sim = vec_state.VecSimulator(n)
+  sim.set_grid(torch.from_numpy(field).cuda())
+  sim.reset_device(seed=123)
+
+  def rows_of(state):
+    out = []
+    for j in range(n):
+      row = {k: float(state[k][j]) for k in helpers.STATE_FLOATS}
+      for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+        row[k] = float(state[k][j])
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
+        row[k] = int(state[k][j])
+      out.append(row)
+    return out
+
+  state = sim.get_state()
+  oracles = [features_oracle.FeatureOracle(field, float(state['alpha'][j])) for j in range(n)]
+  worst, compared, skipping = 0.0, 0, 0
+  for i in range(steps):
+    sim.step(torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda())
+    if i in (60, 131):                         # new episodes for a third of the envs
+      mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[::3] = 1
+      sim.reset_device(seed=1000 + i, mask=mask)
+      state = sim.get_state()
+      for j in range(0, n, 3):
+        oracles[j] = features_oracle.FeatureOracle(field, float(state['alpha'][j]))
+    if skipping > 0:
+      skipping -= 1
+      continue
+    if rng.random() < 0.12:
+      skipping = int(rng.integers(1, 25))      # up to 72 min without an observation
+    noise = (rng.standard_normal((n, 2)) * 1.2).astype(np.float32)
+    append = rng.random() > 0.1
+    obs = sim.observe(torch.from_numpy(noise).cuda(), append=bool(append), carry_factor=carry).cpu().numpy()
+    sim.check_errors()
+    state = sim.get_state()
+    rows = rows_of(state)
+    for j in range(n):
+      if append:
+        oracles[j].observe(rows[j], noise[j].astype(np.float64))
+      else:
+        oracles[j].row = rows[j]               # get_features() on the current state, history unchanged
+    if i % 7 == 0 or i > steps - 6 or not append:
+      for j in range(i % 3, n, 3):
+        if state['status'][j] == 0 and len(oracles[j].locs) > 0:
+          err = check(obs[j], oracles[j].features(), f'irregular env {j} step {i} append {append}')
+          worst = max(worst, err.max()); compared += 1
+  assert compared > 50
+  print('irregular history (carry=%s): %d comparisons, worst |diff| %.3g' % (carry, compared, worst))
