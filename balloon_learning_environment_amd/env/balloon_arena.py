@@ -105,7 +105,7 @@ class BalloonArenaInterface(abc.ABC):
 class BalloonArena(BalloonArenaInterface):
   """One balloon in one wind field (reference constructor signature)."""
 
-  def __init__(self, feature_constructor_factory: Callable = features.PerciatelliFeatureConstructor,
+  def __init__(self, feature_constructor_factory: Callable = features.perciatelli_feature_constructor,
                wind_field_instance: Optional[grid_based_wind_field.GridBasedWindField] = None,
                seed: Optional[int] = None, device='cuda:0'):
     self._feature_constructor_factory = feature_constructor_factory

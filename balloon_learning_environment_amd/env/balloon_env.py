@@ -51,7 +51,7 @@ class BalloonEnv:
   def __init__(self, *, station_keeping_radius_km: float = 50.0,
                arena: Optional[balloon_arena.BalloonArenaInterface] = None,
                reward_function: Callable[[simulator_data.SimulatorState], float] = perciatelli_reward_function,
-               feature_constructor_factory: Callable = features.PerciatelliFeatureConstructor,
+               feature_constructor_factory: Callable = features.perciatelli_feature_constructor,
                wind_field_factory: Callable = generative_wind_field_factory, seed: Optional[int] = None,
                renderer=None):
     self.radius = units.Distance(km=station_keeping_radius_km)

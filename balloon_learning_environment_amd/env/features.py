@@ -308,3 +308,12 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     low[[3, 4, 5, 6]] = -1.0
     low[15], high[15] = 1.0, np.inf
     return Box(low, high)
+
+
+def perciatelli_feature_constructor(forecast, atmosphere) -> FeatureConstructor:
+  """Default factory of BalloonEnv / BalloonArena: the device observation (`ble_observe_f32`)
+  whenever the forecast is a device grid; the host constructor only for forecast objects that
+  exist on the host alone (e.g. the unit-test SimpleStaticWindField)."""
+  if getattr(forecast, 'grid', None) is not None:
+    return DevicePerciatelliFeatureConstructor(forecast, atmosphere)
+  return PerciatelliFeatureConstructor(forecast, atmosphere)

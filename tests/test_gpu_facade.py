@@ -154,8 +154,9 @@ def test_device_feature_constructor_matches_host(mods):
   """BalloonEnv with the device observation (ble_observe_f32, n = 1) against the host constructor
   on the same seed, actions and (Gaussian) grid wind field: identical discrete pattern, <= 2e-4."""
   _, balloon_env, features, _ = mods
-  host = balloon_env.BalloonEnv(seed=21)
-  dev = balloon_env.BalloonEnv(seed=21, feature_constructor_factory=features.DevicePerciatelliFeatureConstructor)
+  host = balloon_env.BalloonEnv(seed=21, feature_constructor_factory=features.PerciatelliFeatureConstructor)
+  dev = balloon_env.BalloonEnv(seed=21)      # default: the device observation for grid forecasts
+  assert isinstance(dev.arena.feature_constructor, features.DevicePerciatelliFeatureConstructor)
   for i in range(25):
     a = (i * 7) % 3
     oh, rh, th, _ = host.step(a)
