@@ -11,6 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 192 --warmup 32 --no-cpu-baseline"
+if [ "${BLE_PROFILE_ONLY_OBS:-0}" != "1" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 run_pmc () {  # name, counters...
   local name=$1; shift
@@ -22,9 +23,12 @@ run_pmc pmc_f64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F6
 run_pmc pmc_misc SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VSKIPPED
 run_pmc pmc_fetch FETCH_SIZE TCC_MISS_sum
 run_pmc pmc_write WRITE_SIZE TCC_HIT_sum
+fi
 # observation kernel: trace of the --observe leg and two PMC passes
 OBS="python $ROOT/bench.py --steps 32 --warmup 32 --observe 8 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_obs -o trace_obs -- $OBS > $OUT/trace_obs.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_obs1 -o pmc_obs1 -- $OBS > $OUT/pmc_obs1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/pmc_obs2 -o pmc_obs2 -- $OBS > $OUT/pmc_obs2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_obs1 -o pmc_obs1 -- $OBS > $OUT/pmc_obs1.log 2>&1
+if [ "${BLE_PROFILE_OBS_PMC:-0}" = "1" ]; then   # this counter set aborted rocprofv3 on the first try (r01); opt-in, bounded
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/pmc_obs2 -o pmc_obs2 -- $OBS > $OUT/pmc_obs2.log 2>&1
+fi
 find $OUT -name "*.csv" | head -60
