@@ -364,6 +364,52 @@ def _sampled_batch_parity(ble, n, steps, seed, threads):
   return total, outliers, worst
 
 
+def test_long_rollout_checkpoints_match_oracle(ble):
+  """Two-day rollouts (1 000 agent steps = 50 h: past the 48 h wind-field horizon where the time
+  axis boomerangs, through two sunsets and every safety-layer state), with auto-reset of
+  terminated environments; every 125th step is checked against the oracle from the GPU's own
+  pre-step state."""
+  from balloon_learning_environment_amd import reset_host
+  n = 2048
+  sim = ble.VecSimulator(n)
+  sim.set_state(reset_host.sample_initial_state(n, seed=77))
+  field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  sim.set_grid(field)
+  rng = np.random.default_rng(78)
+  total = outliers = 0; worst = 0.0; max_elapsed = 0
+  for s in range(1000):
+    act = rng.integers(0, 3, n).astype(np.uint8)
+    # a sticky policy, so that balloons really climb and sink instead of dithering
+    if s % 40 < 25:
+      act = np.where(np.arange(n) % 3 == 0, 2, np.where(np.arange(n) % 3 == 1, 0, act)).astype(np.uint8)
+    check = s % 125 == 124 or s >= 995
+    if check:
+      before = sim.get_state()
+      live = before['status'] == 0
+      o2 = oracle_state_from_abi(before)
+    reward, terminal = sim.step(_dev(act, np.uint8))
+    if check:
+      torch.cuda.synchronize(); sim.check_errors()
+      ro, to, eo, err = oracle.step(o2, act, field=field, threads=8)
+      got = sim.get_state()
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+        np.testing.assert_array_equal(got[k][live], o2[k][live], err_msg=f'step {s} {k}')
+      np.testing.assert_array_equal(sim.effective_action.cpu().numpy()[live], eo[live])
+      bad = np.zeros(n, bool)
+      for k in STATE_FLOATS:
+        e = rel_err(got[k], o2[k], FLOORS[k]); e[~live] = 0.0
+        bad |= e > RTOL; worst = max(worst, float(e.max()))
+      total += int(live.sum()); outliers += int(bad.sum())
+      max_elapsed = max(max_elapsed, int(got['time_elapsed_s'].max()))
+    if s % 50 == 49:                      # new episodes for the terminated ones (same seed stream)
+      mask = (sim.state['status'] != 0).to(torch.uint8)
+      sim.reset_device(seed=5, mask=mask)
+  sim.check_errors()
+  print(f'long rollout: {total} checked env-steps, {outliers} beyond 1e-5, worst {worst:.2g}, max elapsed {max_elapsed / 3600:.1f} h')
+  assert max_elapsed > 48 * 3600
+  assert outliers <= max(2, total // 5000) and worst < 5e-4
+
+
 def test_config_4096_envs_random_policy(ble):
   """BASELINE.json configs[1]: 4 096 vectorised envs, random policy, one decoded wind field."""
   total, outliers, worst = _sampled_batch_parity(ble, 4096, steps=12, seed=41, threads=8)
