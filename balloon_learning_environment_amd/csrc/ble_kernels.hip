@@ -14,6 +14,7 @@
 #include "ble_reset.h"
 #include "ble_step_core.h"
 #include "ble_observe.h"
+#include "ble_noise.h"
 
 using namespace ble;
 
@@ -297,6 +298,25 @@ __global__ __launch_bounds__(256) void ble_decode_flow_kernel(const float* __res
   *out = make_float2(u, v);
 }
 
+// mode 0: the wind noise (u, v) of every environment at its (x, y, pressure, elapsed);
+// mode 1 (test probe): noise_uv[2 i] = simplex4(x, y, pressure, elapsed as float, seed) -- raw primitive.
+__global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ pressure,
+                                                             const int32_t* __restrict__ elapsed, unsigned long long seed,
+                                                             const uint32_t* __restrict__ episode, int mode,
+                                                             float* __restrict__ noise_uv, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float u, v;
+  if (mode == 0) {
+    wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, episode ? episode[i] : 0u, &u, &v);
+  } else {
+    u = simplex4(x[i], y[i], pressure[i], (float)elapsed[i] * (1.0f / 3600.0f), (uint32_t)seed);
+    v = 0.0f;
+  }
+  noise_uv[2 * i] = u; noise_uv[2 * i + 1] = v;
+}
+
 // Episode reset for the lanes selected by `mask` (all lanes if mask == nullptr).
 // sample != 0: draw the initial conditions (utils/sampling.py, balloon_arena.py:228-268) from
 // Philox(seed, env, episode[i]); sample == 0: keep x, y, pressure, centre lat/lng, IR, alpha,
@@ -502,6 +522,16 @@ int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, v
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(ble_decode_flow_kernel, dim3((21 * 21 * 90 + 255) / 256, (unsigned)n), dim3(256), 0, (hipStream_t)stream, flow,
              wind_grid, n);
+  return launch_status();
+}
+
+int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
+                       unsigned long long seed, const uint32_t* episode, int mode, float* noise_uv, int64_t n,
+                       void* stream) {
+  if (!x_m || !y_m || !pressure || !elapsed_s || !noise_uv || n < 0 || mode < 0 || mode > 1) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(ble_wind_noise_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x_m, y_m, pressure,
+             elapsed_s, seed, episode, mode, noise_uv, n);
   return launch_status();
 }
 

@@ -1,0 +1,40 @@
+"""SimplexWindNoise (env/simplex_wind_noise.py:214-259): the truth-minus-forecast wind.
+
+Evaluated by `ble_wind_noise_f32` (csrc/ble_noise.h): the reference's harmonic structure over a
+4-D simplex-noise primitive.  opensimplex==0.3 is not available, so the values are not the
+reference's (parity unpinned); statistics and structure are (tests/test_gpu_noise.py).
+"""
+import datetime as dt
+
+import numpy as np
+import torch
+
+from balloon_learning_environment_amd import _lib
+from balloon_learning_environment_amd import device as dev
+from balloon_learning_environment_amd.env import wind_field
+from balloon_learning_environment_amd.utils import units
+
+
+class SimplexWindNoise:
+  def __init__(self, device='cuda:0'):
+    self.device = dev.require_gpu(device)
+    self._lib = _lib.lib()
+    self._seed = None
+    self._buf = torch.zeros(8, dtype=torch.float32, device=self.device)      # x, y, p | u, v
+    self._t = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+  def reset(self, key) -> None:
+    self._seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
+
+  def get_wind_noise(self, x: units.Distance, y: units.Distance, pressure: float,
+                     elapsed_time: dt.timedelta) -> wind_field.WindVector:
+    if self._seed is None:
+      raise ValueError('Must call reset before get_noise.')            # simplex_wind_noise.py:133-134
+    self._buf[:3] = torch.tensor([x.m, y.m, pressure], dtype=torch.float32)
+    self._t[0] = int(elapsed_time.total_seconds())
+    b = self._buf
+    _lib.check(self._lib.ble_wind_noise_f32(b[0:1].data_ptr(), b[1:2].data_ptr(), b[2:3].data_ptr(), self._t.data_ptr(),
+                                            self._seed, 0, 0, b[4:6].data_ptr(), 1, dev.stream_ptr(self.device)),
+               'ble_wind_noise_f32')
+    u, v = b[4:6].cpu().numpy()
+    return wind_field.WindVector(units.Velocity(mps=float(u)), units.Velocity(mps=float(v)))

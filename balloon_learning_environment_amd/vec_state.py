@@ -143,6 +143,18 @@ class VecSimulator:
     self._obs_reset.zero_()         # stream-ordered after the kernel
     return out
 
+  def wind_noise(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SimplexWindNoise at every env's current position and time: [n, 2] float32 (m/s), the
+    `noise_uv` input of step() / observe().  One noise field per (seed, env, episode)."""
+    if out is None:
+      out = torch.empty(self.n, 2, dtype=torch.float32, device=self.device)
+    s = self.state
+    code = self.lib.ble_wind_noise_f32(s['x'].data_ptr(), s['y'].data_ptr(), s['pressure'].data_ptr(),
+                                       s['time_elapsed_s'].data_ptr(), int(seed) & (2 ** 64 - 1), self.episode.data_ptr(),
+                                       0, out.data_ptr(), self.n, dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_wind_noise_f32')
+    return out
+
   def reset_observation_history(self, mask: Optional[torch.Tensor] = None) -> None:
     """Forget the WindGP observations of the selected envs (all if None)."""
     if self._gp is not None:

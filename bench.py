@@ -193,14 +193,19 @@ def main():
     sim.reset_observation_history()
     obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world) if world > 1 else None
     fill = 121                                            # 6 h window = 120 observations; 121st call slides it
+    # forecast != truth: the additive wind noise (ble_wind_noise_f32) is evaluated at the balloons once
+    # per step -- it is both the next step's ground-truth term and this observation's error term
+    noise = sim.wind_noise(seed=1234)
     for i in range(fill):
-      sim.step(actions[i % k_total])
-      sim.observe(out=obs)
+      sim.step(actions[i % k_total], noise)
+      sim.wind_noise(seed=1234, out=noise)
+      sim.observe(noise, out=obs)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
     t_obs = 0.0; t_pair = 0.0
     for i in range(args.observe):
-      e0.record(); sim.step(actions[(fill + i) % k_total]); e1.record(); sim.observe(out=obs)
+      e0.record(); sim.step(actions[(fill + i) % k_total], noise); sim.wind_noise(seed=1234, out=noise)
+      e1.record(); sim.observe(noise, out=obs)
       if obs_gatherer is not None:                         # "observations gathered back" (north star), 4 396 B/env
         obs_gatherer.gather(obs); obs_gatherer.wait()
       e2.record()

@@ -231,6 +231,17 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
  */
 int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream);
 
+/*
+ * SimplexWindNoise.get_wind_noise (env/simplex_wind_noise.py:214-259) for n environments at their
+ * positions: noise_uv [n][2] in m/s, to be passed as `noise_uv` to ble_step_f32 / ble_observe_f32.
+ * Five harmonics per component with the reference's weights and spacings; generator seeds and
+ * offsets per (seed, env, episode[i]).  The 4-D noise primitive is NOT opensimplex 0.3's (absent,
+ * unpinned): see csrc/ble_noise.h.  mode 1 is a test probe of the raw primitive.
+ */
+int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
+                       unsigned long long seed, const uint32_t* episode, int mode, float* noise_uv, int64_t n,
+                       void* stream);
+
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,
                         uint32_t* err_flags, int64_t n, void* stream);

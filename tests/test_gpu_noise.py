@@ -1,0 +1,102 @@
+"""Wind-noise generator (env/simplex_wind_noise.py).  The reference's primitive
+(opensimplex 0.3 noise4d) is absent and unpinned, so these are property tests of the structure the
+reference prescribes: zero-mean smooth noise, variance 1.02 (m/s)^2 per component
+(simplex_wind_noise.py:66-79,190-211), one field per (seed, env, episode), and that it plugs into
+the step and observation kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SIMPLEX4_VARIANCE = 0.088392    # kSimplex4Variance in csrc/ble_noise.h == SIMPLEX_VARIANCE of simplex_wind_noise.py:70
+
+
+@pytest.fixture(scope='module')
+def lib():
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device; none visible')
+  from balloon_learning_environment_amd import _lib
+  return _lib.lib()
+
+
+def raw(lib, pts, seed):
+  n = pts.shape[0]
+  d = [torch.from_numpy(np.ascontiguousarray(pts[:, k], np.float32)).cuda() for k in range(3)]
+  t = torch.from_numpy(np.ascontiguousarray(pts[:, 3] * 3600.0).astype(np.int32)).cuda()
+  out = torch.empty(n, 2, device='cuda')
+  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), t.data_ptr(), seed, 0, 1, out.data_ptr(), n, 0) == 0
+  torch.cuda.synchronize()
+  return out[:, 0].cpu().numpy().astype(np.float64)
+
+
+def test_simplex4_primitive(lib):
+  rng = np.random.default_rng(0)
+  pts = rng.uniform(-40, 40, (400000, 4))
+  pts[:, 3] = np.round(pts[:, 3] * 3600) / 3600          # the probe takes whole seconds
+  v = raw(lib, pts, 12345)
+  assert np.abs(v).max() <= 1.05 and abs(v.mean()) < 5e-3
+  print('simplex4 variance %.5f' % v.var())
+  assert abs(v.var() - SIMPLEX4_VARIANCE) < 0.03 * SIMPLEX4_VARIANCE
+  # continuous: a 1e-3 displacement moves the value by O(1e-2) at most; different seeds decorrelate
+  moved = pts.copy(); moved[:, 0] += 1e-3
+  assert np.abs(raw(lib, moved, 12345) - v).max() < 2e-2
+  other = raw(lib, pts, 54321)
+  assert abs(np.corrcoef(v, other)[0, 1]) < 0.02
+  # zero on... nothing special at the origin of the lattice for a hashed gradient field, but finite
+  assert np.isfinite(raw(lib, np.zeros((4, 4)), 1)).all()
+
+
+def test_wind_noise_statistics_and_plumbing(lib):
+  from balloon_learning_environment_amd import vec_state
+  n = 65536
+  sim = vec_state.VecSimulator(n)
+  sim.set_grid(torch.zeros(21, 21, 10, 9, 2, device='cuda'))
+  sim.reset_device(seed=2)
+  noise = sim.wind_noise(seed=99)
+  u, v = noise[:, 0].cpu().numpy().astype(np.float64), noise[:, 1].cpu().numpy().astype(np.float64)
+  print('wind noise: var u %.3f, var v %.3f, mean %.3f %.3f' % (u.var(), v.var(), u.mean(), v.mean()))
+  for c in (u, v):
+    assert abs(c.mean()) < 0.05 and 0.8 < c.var() < 1.3          # target 1.02 (m/s)^2
+  assert abs(np.corrcoef(u, v)[0, 1]) < 0.05
+  # deterministic, and a different seed gives a different field
+  assert torch.equal(noise, sim.wind_noise(seed=99))
+  assert not torch.equal(noise, sim.wind_noise(seed=100))
+  # flying in it: zero forecast + noise moves the balloons by noise * 180 s; the field is smooth in time
+  x0 = sim.state['x'].clone()
+  acts = torch.ones(n, dtype=torch.uint8, device='cuda')
+  sim.step(acts, noise)
+  moved = (sim.state['x'] - x0).cpu().numpy()
+  np.testing.assert_allclose(moved, u * 180.0, atol=0.3)         # fp32 positions ~1e5 m: 18 roundings of 0.008 m
+  after = sim.wind_noise(seed=99)
+  # 3 minutes, < 1 km and a few tens of Pa later the wind is still strongly correlated with itself
+  # (the harmonics' pressure spacings go down to 66 Pa, so it is not identical)
+  assert np.corrcoef(after[:, 0].cpu().numpy(), u)[0, 1] > 0.6
+  obs = sim.observe(after)
+  sim.check_errors()
+  assert torch.isfinite(obs).all()
+  # a new episode draws new generators
+  mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[:1000] = 1
+  before = sim.wind_noise(seed=99)[1000:2000].clone()
+  sim.reset_device(seed=7, mask=mask)
+  assert torch.equal(sim.wind_noise(seed=99)[1000:2000], before)
+
+
+def test_facade_with_noise(lib):
+  """GridBasedWindField(noise=True): forecast != ground truth (grid_based_wind_field_test.py:76-84),
+  the truth is self-consistent (:67-74), and BalloonEnv flies and observes in it (the WindGP gets
+  non-zero errors to model)."""
+  import datetime as dt
+  from balloon_learning_environment_amd.env import balloon_env, grid_based_wind_field, grid_wind_field_sampler
+  from balloon_learning_environment_amd.utils import units
+  wf = grid_based_wind_field.GridBasedWindField(grid_wind_field_sampler.GaussianFieldSampler(), noise=True)
+  with pytest.raises(ValueError):
+    wf.noise_model.get_wind_noise(units.Distance(km=1), units.Distance(km=2), 9000.0, dt.timedelta(hours=1))
+  wf.reset(np.array([0, 5], np.uint32), None)
+  args = (units.Distance(km=12.0), units.Distance(km=-30.0), 9000.0, dt.timedelta(hours=3))
+  f, t1, t2 = wf.get_forecast(*args), wf.get_ground_truth(*args), wf.get_ground_truth(*args)
+  assert t1 == t2 and (f.u.mps != t1.u.mps or f.v.mps != t1.v.mps)
+  env = balloon_env.BalloonEnv(wind_field_factory=lambda: grid_based_wind_field.GridBasedWindField(
+      grid_wind_field_sampler.GaussianFieldSampler(), noise=True), seed=4)
+  for a in (1, 2, 0, 1):
+    obs, r, term, info = env.step(a)
+    assert obs.shape == (1099,) and np.isfinite(obs).all() and 0.0 <= r <= 1.0
