@@ -48,16 +48,46 @@ def cpu_baseline(state, actions, field, seconds_target=10.0):
   ost['sunrise_h'][:] = state['start_unix'][:n] + state['sunrise_h_rel'][:n]
   ost['sunset'][:] = state['start_unix'][:n] + state['sunset_rel'][:n]
   oracle.step(ost, actions[0][:n], field=field, threads=cores)   # warm-up (page in, spin up threads)
+  # The container may expose more hardware threads than its CFS quota lets it run (the GPU boxes show
+  # 256 threads under a 16-CPU quota; a 256-thread OpenMP team then spends its time throttled).  The
+  # team size is the quota; `cores` reports the threads actually used.
+  cores_seen, quota = cores, None
+  try:
+    q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+    quota = None if q == 'max' else float(q) / float(per)
+  except Exception:
+    try:
+      q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+      quota = q / per if q > 0 else None
+    except Exception:
+      quota = None
+  if quota is not None:
+    cores = max(1, min(cores, int(round(quota))))
+  oracle.step(ost, actions[1][:n], field=field, threads=cores)
   steps = 0; live = 0; t0 = time.perf_counter()
   while True:
     live += int((ost['status'] == 0).sum())
     oracle.step(ost, actions[(steps + 1) % len(actions)][:n], field=field, threads=cores)
     steps += 1
-    if time.perf_counter() - t0 > seconds_target or steps >= 64:
+    if time.perf_counter() - t0 > seconds_target or steps >= 512:
       break
   dt = time.perf_counter() - t0
+  # single-thread figure on a slice of the same batch (about 3 s)
+  m = 2048
+  one = oracle.new_state(m)
+  for k in one:
+    one[k][:] = ost[k][:m]
+  oracle.step(one, actions[0][:m], field=field, threads=1)
+  t1 = time.perf_counter(); s1 = 0; live1 = 0
+  while time.perf_counter() - t1 < 3.0 and s1 < 16:
+    live1 += int((one['status'] == 0).sum())
+    oracle.step(one, actions[(s1 + 1) % len(actions)][:m], field=field, threads=1)
+    s1 += 1
+  dt1 = time.perf_counter() - t1
   return {'value': live / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-          'sample': f'{n} envs x {steps} agent steps of the same workload, fp64 C oracle with OpenMP over envs, {dt:.1f} s'}
+          'sample': f'{n} envs x {steps} agent steps of the same workload, fp64 C oracle with OpenMP over envs, {dt:.1f} s',
+          'value_single_thread': live1 / dt1, 'sample_single_thread': f'{m} envs x {s1} agent steps, 1 thread, {dt1:.1f} s',
+          'host_cpu_count': os.cpu_count(), 'affinity_threads': cores_seen, 'cgroup_cpu_quota': quota}
 
 
 def main():
