@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume,
     double s, c;
     sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
     const float att = solar_attenuation((float)s, pressure[i]);
-    const float rho = pressure[i] * kAirMolarOverR * f_rcp(t_amb[i]);
-    const float v23 = f_exp2((2.0f / 3.0f) * f_log2(volume[i]));
-    dtdt[i] = thermal_dtdt(v23, t_int[i], t_amb[i], rho, flux[i] * att, earth_heat_per_area(ir[i], &flags), &flags);
+    const float lv = f_log2(volume[i]);
+    const float v23 = f_exp2((2.0f / 3.0f) * lv), v_m13 = f_exp2((-1.0f / 3.0f) * lv);
+    dtdt[i] = thermal_dtdt(v23, v_m13, t_int[i], t_amb[i], pressure[i], flux[i] * att, earth_heat_per_area(ir[i], &flags), &flags);
   }
   report_flags(flags, err_flags);
 }

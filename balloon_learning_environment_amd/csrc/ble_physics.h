@@ -822,27 +822,30 @@ BLE_FN float earth_heat_per_area(float upwelling_ir, uint32_t* flags) {
   float t_bb = f_sqrt(f_sqrt(upwelling_ir * (1.0f / kStefanBoltzmann)));
   return upwelling_ir * 0.4605f * total_absorptivity(absorptivity_ir(t_bb), flags);
 }
-// d_balloon_temperature_dt (thermal.py:175-230).  v23 = V^(2/3); rho = air density at (p, T_amb).
-BLE_FN float thermal_dtdt(float v23, float t_int, float t_amb, float rho, float solar_flux_att,
+// d_balloon_temperature_dt (thermal.py:175-230).  v23 = V^(2/3), v_m13 = V^(-1/3), p = ambient pressure.
+// One transcendental (rt = T_amb^-1/2) serves air density, viscosity and the 1/T of the Grashof
+// number: rho / mu = p (M/R) (T + 110.4) rt^5 / 1.458e-6; radius = c V^(1/3) = c v23 v_m13.
+BLE_FN float thermal_dtdt(float v23, float v_m13, float t_int, float t_amb, float p, float solar_flux_att,
                           float q_earth_per_area, uint32_t* flags) {
   const float kR2 = 0.38483473659f;         // (3 / (4 pi))^(2/3)
-  float r2 = kR2 * v23;                   // radius^2
-  float radius = f_sqrt(r2);
+  const float kR1 = 0.62035049090f;         // (3 / (4 pi))^(1/3)
+  float r2 = kR2 * v23;                     // radius^2
+  float dia = (2.0f * kR1) * (v23 * v_m13);
+  float inv_dia = (0.5f / kR1) * v_m13;
   float area = 4.0f * kPi * r2;
   float q_solar = solar_flux_att * 0.25f * kSolarAbsorptivityTotal;           // per area
   float t2 = t_int * t_int;
   float q_emit = kStefanBoltzmann * t2 * t2 * total_absorptivity(absorptivity_ir(t_int), flags);
   // convective_heat_air_factor (thermal.py:150-172)
-  float viscosity = 1.458e-6f * t_amb * f_sqrt(t_amb) * f_rcp(t_amb + 110.4f);
+  float rt = f_rsqrt(t_amb), rt2 = rt * rt;
+  float rv = (kAirMolarOverR / 1.458e-6f) * p * (t_amb + 110.4f) * (rt2 * rt2 * rt);      // rho / viscosity
   float conductivity = 0.0241f * f_pow(t_amb * (1.0f / 273.15f), 0.9f);
   float prandtl = f_fma(-3.25e-4f, t_amb, 0.804f);
-  float dia = 2.0f * radius;
   float dt = t_amb - t_int;
-  float rv = rho * f_rcp(viscosity);
-  float grashof = 9.80665f * rv * rv * (dia * dia * dia) * f_rcp(t_amb) * fabsf(dt);
+  float grashof = 9.80665f * rv * rv * (dia * dia * dia) * rt2 * fabsf(dt);
   float rayleigh = prandtl * grashof;
   float nusselt = 2.0f + 0.457f * f_sqrt(f_sqrt(rayleigh)) + f_pow(f_fma(2.69e-8f, rayleigh, 1.0f), 1.0f / 12.0f);
-  float q_conv = nusselt * conductivity * f_rcp(dia) * dt;                    // per area
+  float q_conv = nusselt * conductivity * inv_dia * dt;                       // per area
   return area * (q_solar + q_earth_per_area + q_conv - q_emit) * (1.0f / (1500.0f * kEnvelopeMass));
 }
 

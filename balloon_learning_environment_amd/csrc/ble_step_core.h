@@ -130,7 +130,6 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
     // equilibrium d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error
     // in the increment itself is amplified past the parity bar within a few substeps.
-    const float rho = pf * kAirMolarOverR * f_rcp(t_ambf);                 // fp32 copy for the thermal model
     const float lv = f_log2(volf);
     const float v23 = f_exp2((2.0f / 3.0f) * lv);                           // V^(2/3), fp32 (thermal model)
     // rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
@@ -138,7 +137,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
     const double dir = num >= 0.0 ? 1.0 : -1.0;
     // 1/drag = 4 V^(-2/3): V^(-1/3) by one Newton step  y <- y (4 - V y^3) / 3  from an fp32 seed
-    double yc = (double)f_exp2((-1.0f / 3.0f) * lv);
+    const float v_m13 = f_exp2((-1.0f / 3.0f) * lv);                        // V^(-1/3), fp32 (thermal model; seed below)
+    double yc = (double)v_m13;
     yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
     // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
     const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * (dir * num) * rp * (yc * yc);
@@ -148,7 +148,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf);
-    const float dtdt = thermal_dtdt(v23, t_intf, t_ambf, rho, flux * att, q_earth, flags);
+    const float dtdt = thermal_dtdt(v23, v_m13, t_intf, t_ambf, pf, flux * att, q_earth, flags);
     const double t_int_new = t_int + (double)(dtdt * kStride);
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
