@@ -8,22 +8,23 @@
 //   phase 1    lane 0: sunrise/sunset searches on the table -> 16 ambient features
 //              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) for the
 //                      reachable pressure range (pressure_range_builder.py:203-275)
-//              waves 2-3: K = s^2 exp(-|d/ls|) + 0.05 I, packed lower triangle in LDS (fp64)
-//   phase 1/2  the Cholesky factor of K (sklearn GaussianProcessRegressor.fit refits every step):
+//              wave 2 (or waves 2-3 when refitting): the Cholesky factor of K = s^2 exp(-|d/ls|) + 0.05 I
+//                      (sklearn GaussianProcessRegressor.fit refits it every step):
 //              * incremental (hist.chol given): the factor of the previous window lives in HBM
-//                (58 KB per env); the window slides by dropping the oldest observation -- a
-//                stable rank-1 UPDATE of the trailing factor -- and appending the newest -- one
-//                forward substitution -- O(n^2) instead of O(n^3), done by one wave while the
-//                ambient / Newton lanes work
-//              * refit (no hist.chol, first call, or an inconsistent history): left-looking
-//                blocked Cholesky in LDS in panels of 8 columns
-//   phase 4    181 query levels in 3 chunks of 64: V = L^-1 K*^T by forward substitution in
-//              blocks of 8 rows, 4 lanes per query; mean = v . z + forecast  (= K* K^-1 y),
+//                (58 KB per env, prefetched with 16-byte loads at kernel entry); the window slides
+//                by dropping the oldest observation -- a stable rank-1 UPDATE of the trailing
+//                factor -- and appending the newest -- one forward substitution -- O(n^2) instead
+//                of O(n^3), one fused wave-synchronous sweep
+//              * refit (no hist.chol, first call, or an inconsistent history): K built in LDS, then
+//                (phase 2) a left-looking blocked Cholesky in panels of 8 columns
+//   phase 4    V = L^-1 [K*^T | y] for the 181 query levels and the two error vectors: blocked forward
+//              substitution on v_mfma_f64_16x16x4_f64, 48 columns per wave, V resident in registers,
+//              inverted 16 x 16 diagonal blocks; mean = v . z + forecast (= K* K^-1 y),
 //              deviation = (s^2 - |v|^2) / s^2
 //   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
 //
-// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (L) + 62 KB (V)
-// + 7 KB -- one workgroup per CU.
+// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 66 KB (L, rows padded to 128)
+// + 16 KB (diagonal-block inverses) + 15 KB -- one workgroup per CU.  DESIGN.md 3b has the cycle budget.
 #pragma once
 #include "ble_reset.h"
 
