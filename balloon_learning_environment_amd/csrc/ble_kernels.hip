@@ -15,6 +15,7 @@
 #include "ble_step_core.h"
 #include "ble_observe.h"
 #include "ble_noise.h"
+#include "ble_decode.h"
 
 using namespace ble;
 
@@ -271,29 +272,14 @@ __global__ __launch_bounds__(256) void ble_decode_flow_kernel(const float* __res
                                                               int64_t n) {
   __shared__ int tap0[23];
   __shared__ float w1[23];
-  if (threadIdx.x < 23) {
-    const float x = ((float)threadIdx.x + 0.5f) * (7.0f / 23.0f) - 0.5f;
-    const float fl = floorf(x);
-    tap0[threadIdx.x] = (int)fl;
-    w1[threadIdx.x] = x - fl;
-  }
+  if (threadIdx.x < 23) resize_tap((int)threadIdx.x, &tap0[threadIdx.x], &w1[threadIdx.x]);
   __syncthreads();
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int64_t env = blockIdx.y;
   if (idx >= 21 * 21 * 90 || env >= n) return;
   const int f = idx % 90, ij = idx / 90, i = ij / 21, j = ij % 21;
-  const float* psi = flow + env * (7 * 7 * 90) + f;
-  auto resized = [&](int a, int b) {       // psi resized at (a, b) of the 23 x 23 lattice
-    const int a0 = tap0[a], b0 = tap0[b];
-    const int a_lo = a0 < 0 ? 0 : a0, a_hi = a0 + 1 > 6 ? 6 : a0 + 1;
-    const int b_lo = b0 < 0 ? 0 : b0, b_hi = b0 + 1 > 6 ? 6 : b0 + 1;
-    const float wa = w1[a], wb = w1[b];
-    const float lo = f_fma(wb, psi[(a_lo * 7 + b_hi) * 90] - psi[(a_lo * 7 + b_lo) * 90], psi[(a_lo * 7 + b_lo) * 90]);
-    const float hi = f_fma(wb, psi[(a_hi * 7 + b_hi) * 90] - psi[(a_hi * 7 + b_lo) * 90], psi[(a_hi * 7 + b_lo) * 90]);
-    return f_fma(wa, hi - lo, lo);
-  };
-  const float u = 0.5f * (resized(i + 2, j + 1) - resized(i, j + 1));
-  const float v = -0.5f * (resized(i + 1, j + 2) - resized(i + 1, j));
+  float u, v;
+  decode_flow_point(flow + env * (7 * 7 * 90) + f, i, j, tap0, w1, &u, &v);
   float2* out = reinterpret_cast<float2*>(grid + env * (int64_t)(21 * 21 * 90 * 2)) + idx;
   *out = make_float2(u, v);
 }

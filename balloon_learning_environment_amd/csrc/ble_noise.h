@@ -11,26 +11,31 @@
 // 10 generators x 256 B per environment would not fit LDS at one lane per environment), its
 // empirical variance measured on the device (tests/test_gpu_noise.py).
 #pragma once
+#include <math.h>
+
 #include "ble_reset.h"
 
 namespace ble {
 
 struct Harmonic { float weight, x_spacing, y_spacing, p_spacing, t_spacing; };
-// simplex_wind_noise.py:50-64 (weight, x km, y km, pressure Pa, time h)
-__device__ const Harmonic kHarmonicsU[5] = {{0.1445f, 702.269f, 2116.987f, 2587.802f, 245.0f},
-                                            {0.2766f, 1483.570f, 752.124f, 646.208f, 16.39f},
-                                            {0.2627f, 276.810f, 147.040f, 587.702f, 3.836f},
-                                            {0.2137f, 10214.525f, 1512.216f, 965.629f, 41.780f},
-                                            {0.1025f, 181.286f, 420.942f, 8500.0f, 245.0f}};
-__device__ const Harmonic kHarmonicsV[5] = {{0.2716f, 1974.228f, 2028.814f, 713.697f, 26.435f},
-                                            {0.2684f, 699.738f, 541.845f, 632.116f, 9.530f},
-                                            {0.2348f, 217.750f, 196.522f, 686.825f, 3.546f},
-                                            {0.1186f, 47.500f, 43.048f, 66.553f, 8.424f},
-                                            {0.1066f, 3663.291f, 232.023f, 7499.741f, 225.0f}};
+// simplex_wind_noise.py:50-64 (weight, x km, y km, pressure Pa, time h); comp 0 = u, 1 = v
+BLE_FN Harmonic harmonic_params(int comp, int h) {
+  constexpr Harmonic kU[5] = {{0.1445f, 702.269f, 2116.987f, 2587.802f, 245.0f},
+                              {0.2766f, 1483.570f, 752.124f, 646.208f, 16.39f},
+                              {0.2627f, 276.810f, 147.040f, 587.702f, 3.836f},
+                              {0.2137f, 10214.525f, 1512.216f, 965.629f, 41.780f},
+                              {0.1025f, 181.286f, 420.942f, 8500.0f, 245.0f}};
+  constexpr Harmonic kV[5] = {{0.2716f, 1974.228f, 2028.814f, 713.697f, 26.435f},
+                              {0.2684f, 699.738f, 541.845f, 632.116f, 9.530f},
+                              {0.2348f, 217.750f, 196.522f, 686.825f, 3.546f},
+                              {0.1186f, 47.500f, 43.048f, 66.553f, 8.424f},
+                              {0.1066f, 3663.291f, 232.023f, 7499.741f, 225.0f}};
+  return comp == 0 ? kU[h] : kV[h];
+}
 constexpr float kSimplex4Variance = 0.088392f;   // of simplex4() below: measured 0.0889 (tests/test_gpu_noise.py) == the reference's SIMPLEX_VARIANCE (:70)
 constexpr float kNoiseVariance = 1.02f;          // simplex_wind_noise.py:73
 
-__device__ __forceinline__ uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
+BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
   uint32_t h = seed;
   h = (h ^ (uint32_t)i) * 0x9E3779B1u; h ^= h >> 15;
   h = (h ^ (uint32_t)j) * 0x85EBCA77u; h ^= h >> 13;
@@ -40,7 +45,7 @@ __device__ __forceinline__ uint32_t lattice_hash(int i, int j, int k, int l, uin
 }
 // One corner: (0.6 - |d|^2)^4 * (gradient . d), gradient = one of the 32 midpoints of the edges of
 // the 4-cube (one zero component, the other three +-1).
-__device__ __forceinline__ float simplex_corner(float x, float y, float z, float w, uint32_t h) {
+BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h) {
   float t = 0.6f - x * x - y * y - z * z - w * w;
   if (t < 0.0f) return 0.0f;
   const uint32_t g = h >> 27;                      // 5 bits
@@ -50,7 +55,7 @@ __device__ __forceinline__ float simplex_corner(float x, float y, float z, float
   t *= t;
   return t * t * (a + b + c);
 }
-__device__ inline float simplex4(float x, float y, float z, float w, uint32_t seed) {
+BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed) {
   const float F4 = 0.30901699437494745f, G4 = 0.1381966011250105f;
   const float s = (x + y + z + w) * F4;
   const int i = (int)floorf(x + s), j = (int)floorf(y + s), k = (int)floorf(z + s), l = (int)floorf(w + s);
@@ -79,7 +84,7 @@ __device__ inline float simplex4(float x, float y, float z, float w, uint32_t se
 
 // NoisyWindComponent.get_noise (:190-211) for both components; the per-harmonic generator seeds and
 // offsets (NoisyWindHarmonic.reset :97-114) come from the environment's Philox stream.
-__device__ inline void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env,
+BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env,
                                   uint32_t episode, float* u, float* v) {
   Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
   const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
@@ -87,14 +92,13 @@ __device__ inline void wind_noise(float x_m, float y_m, float pressure, int32_t 
   float out[2];
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
-    const Harmonic* hs = comp == 0 ? kHarmonicsU : kHarmonicsV;
     float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f;
 #pragma unroll 1
     for (int h = 0; h < 5; ++h) {
       const uint32_t hseed = philox_u32(g);
       const float ox = (float)(2.0 * philox_uniform(g) - 1.0), oy = (float)(2.0 * philox_uniform(g) - 1.0),
                   op = (float)(2.0 * philox_uniform(g) - 1.0), ot = (float)(2.0 * philox_uniform(g) - 1.0);
-      const Harmonic hp = hs[h];
+      const Harmonic hp = harmonic_params(comp, h);
       const float nz = magnitude * simplex4(x_km / hp.x_spacing + ox, y_km / hp.y_spacing + oy,
                                             pressure / hp.p_spacing + op, t_h / hp.t_spacing + ot, hseed);
       acc = f_fma(nz, hp.weight, acc); wsum += hp.weight; w2sum = f_fma(hp.weight, hp.weight, w2sum);

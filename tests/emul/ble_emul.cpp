@@ -4,6 +4,8 @@
 // v_sqrt hardware approximations, so this shows the algorithmic fp32 error, not the
 // last-ulp behaviour of the device.
 #include "../../balloon_learning_environment_amd/csrc/ble_step_core.h"
+#include "../../balloon_learning_environment_amd/csrc/ble_noise.h"
+#include "../../balloon_learning_environment_amd/csrc/ble_decode.h"
 #include "../../include/ble_abi.h"
 
 using namespace ble;
@@ -104,3 +106,27 @@ extern "C" void emul_philox(uint64_t seed, uint64_t env, uint32_t episode, int64
   for (int64_t i = 0; i < n; ++i) gamma12[i] = philox_gamma(g, 1.2);
 }
 extern "C" double emul_asin(double x) { return d_asin(x); }
+
+
+// ---- wind noise (csrc/ble_noise.h) and the decoder tail (csrc/ble_decode.h), host build
+extern "C" void emul_simplex4(int64_t n, const float* x, const float* y, const float* z, const float* w, uint32_t seed,
+                              float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = simplex4(x[i], y[i], z[i], w[i], seed);
+}
+extern "C" void emul_wind_noise(int64_t n, const float* x_m, const float* y_m, const float* pressure,
+                                const int32_t* elapsed_s, uint64_t seed, const uint32_t* episode, float* noise_uv) {
+  for (int64_t i = 0; i < n; ++i)
+    wind_noise(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, &noise_uv[2 * i],
+               &noise_uv[2 * i + 1]);
+}
+extern "C" void emul_decode_flow(int64_t n, const float* flow, float* grid) {
+  int tap0[23]; float w1[23];
+  for (int a = 0; a < 23; ++a) resize_tap(a, &tap0[a], &w1[a]);
+  for (int64_t e = 0; e < n; ++e)
+    for (int idx = 0; idx < 21 * 21 * 90; ++idx) {
+      const int f = idx % 90, ij = idx / 90;
+      float u, v;
+      decode_flow_point(flow + e * 4410 + f, ij / 21, ij % 21, tap0, w1, &u, &v);
+      grid[(e * 39690 + idx) * 2] = u; grid[(e * 39690 + idx) * 2 + 1] = v;
+    }
+}

@@ -100,3 +100,22 @@ def test_facade_with_noise(lib):
   for a in (1, 2, 0, 1):
     obs, r, term, info = env.step(a)
     assert obs.shape == (1099,) and np.isfinite(obs).all() and 0.0 <= r <= 1.0
+
+
+def test_device_noise_equals_host_build(lib):
+  """The device kernel and the g++ build of the same header agree (fp32 arithmetic, libm vs
+  hardware floor/sqrt: identical lattice decisions; values within 2e-5)."""
+  import test_noise_decode_host as host
+  rng = np.random.default_rng(5)
+  n = 20000
+  x, y = rng.uniform(-2e5, 2e5, n).astype(np.float32), rng.uniform(-2e5, 2e5, n).astype(np.float32)
+  p, t = rng.uniform(5000, 14000, n).astype(np.float32), rng.integers(0, 48 * 3600, n).astype(np.int32)
+  ep = rng.integers(0, 5, n).astype(np.uint32)
+  d = [torch.from_numpy(a).cuda() for a in (x, y, p)]
+  td, epd = torch.from_numpy(t).cuda(), torch.from_numpy(ep.astype(np.int32)).cuda()
+  out = torch.empty(n, 2, device='cuda')
+  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), td.data_ptr(), 77, epd.data_ptr(), 0,
+                                out.data_ptr(), n, 0) == 0
+  torch.cuda.synchronize()
+  want = host.wind_noise(x, y, p, t, seed=77, episode=ep)
+  np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5)
