@@ -252,6 +252,16 @@ def main():
                    'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)'}
     del one
 
+  # what actually bounds the kernel (from the committed PMC summary of the same command, if present)
+  issue = None
+  try:
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_summary.json')))['derived']
+    issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
+             'valu_insts_per_env_step': d['valu_insts_per_wave'] / 32.0, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / 32.0,
+             'source': 'profiles/r01_summary.json (rocprofv3 --pmc, per 32-step launch)'}
+  except Exception:
+    issue = None
+
   if rank == 0:
     out = {
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
@@ -271,7 +281,8 @@ def main():
                      'kernel': 'ble_step_kernel', 'kernel_ms': kernel_ms, 'agent_steps_per_launch': args.steps / n_launches,
                      'kernel_us_per_agent_step': 1e3 * kernel_ms * n_launches / args.steps,
                      'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
-                     'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)'},
+                     'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)',
+                     'instruction_issue': issue},
     }
     if observe_leg is not None:
       out['observe'] = observe_leg
