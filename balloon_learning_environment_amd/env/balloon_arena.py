@@ -70,7 +70,15 @@ class VecBalloonArena:
 
   # ---- per-env views -----------------------------------------------------------------
   def row(self, i: int) -> dict:
-    return {name: t[i].item() for name, t in self.sim.state.items()}
+    """State of env i as Python scalars: one device->host copy per dtype instead of one per field."""
+    by_dtype = {}
+    for name, t in self.sim.state.items():
+      by_dtype.setdefault(t.dtype, []).append(name)
+    out = {}
+    for dtype, names in by_dtype.items():
+      vals = torch.stack([self.sim.state[n][i] for n in names]).cpu().tolist()
+      out.update(zip(names, vals))
+    return {name: out[name] for name in self.sim.state}
 
   def get_balloon_state(self, i: int = 0) -> balloon.BalloonState:
     return balloon.state_from_row(self.row(i))
