@@ -121,3 +121,51 @@ class BalloonEnv:
   def __exit__(self, *args):
     self.close()
     return False
+
+
+class VecBalloonEnv:
+  """N BalloonEnvs advanced together on one GPU (no reference counterpart: the reference steps one
+  environment per Python call).  Same semantics per environment as BalloonEnv -- Perciatelli
+  observation, perciatelli_reward_function, terminal on out-of-power / burst / zero-pressure --
+  with device tensors in and out and optional auto-reset of terminated environments.
+
+    env = VecBalloonEnv(65536, seed=0)
+    obs = env.reset()                                  # [N, 1099] float32 (device)
+    obs, reward, terminal = env.step(actions_u8)       # device tensors
+  """
+
+  def __init__(self, num_envs: int, *, seed: int = 0, wind_field=None, wind_noise: bool = False,
+               auto_reset: bool = True, device='cuda:0'):
+    self.arena = balloon_arena.VecBalloonArena(num_envs, wind_field, seed=seed, device=device)
+    self.num_envs, self.device = self.arena.num_envs, self.arena.device
+    self._seed, self._wind_noise, self._auto_reset = int(seed), bool(wind_noise), bool(auto_reset)
+    self._noise = None
+
+  def _noise_now(self):
+    if not self._wind_noise:
+      return None
+    self._noise = self.arena.sim.wind_noise(self._seed, out=self._noise)
+    return self._noise
+
+  def reset(self):
+    self.arena.reset(self._seed)
+    return self.arena.observe(self._noise_now())
+
+  def step(self, actions):
+    """actions: uint8 device tensor [N] in {0, 1, 2}.  Returns (obs [N, 1099], reward [N], terminal [N] u8);
+    `terminal` refers to the transition just made; with auto_reset the returned observation of a
+    terminated environment is the first one of its next episode."""
+    reward, terminal = self.arena.step(actions, self._noise if self._wind_noise else None)
+    reward, terminal = reward.clone(), terminal.clone()
+    if self._auto_reset:
+      self.arena.sim.reset_device(self._seed, mask=terminal)
+    return self.arena.observe(self._noise_now()), reward, terminal
+
+  @property
+  def observation_space(self):
+    return features.Box(np.concatenate([[0, 0, 0, -1, -1, -1, -1], np.zeros(8), [1.0], np.zeros(1083)]).astype(np.float32),
+                        np.concatenate([np.ones(15), [np.inf], np.ones(1083)]).astype(np.float32))
+
+  @property
+  def action_space(self):
+    return features.Discrete(3)

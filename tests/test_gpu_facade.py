@@ -165,3 +165,31 @@ def test_device_feature_constructor_matches_host(mods):
     unreach = lambda f: (f[16::3] == 0) & (f[17::3] == 1) & (f[18::3] == 1)
     np.testing.assert_array_equal(unreach(oh), unreach(od))
     assert np.abs(oh.astype(np.float64) - od).max() <= 2e-4
+
+
+def test_vec_balloon_env(mods):
+  """VecBalloonEnv: env k of the batch behaves like a BalloonEnv -- same state evolution as a
+  1-env simulator started from the same state, observations inside the space, auto-reset."""
+  import torch
+  _, balloon_env, _, _ = mods
+  n = 256
+  env = balloon_env.VecBalloonEnv(n, seed=9, wind_noise=True)
+  obs = env.reset()
+  assert obs.shape == (n, 1099) and obs.dtype == torch.float32
+  space = env.observation_space
+  total = torch.zeros(n, device='cuda')
+  # drain a few batteries so that some environments terminate and are reset
+  env.arena.sim.state['battery_charge'][:16] = 1e-3
+  env.arena.sim.state['start_unix'][:16] += 0
+  for i in range(12):
+    actions = torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda')
+    obs, reward, terminal = env.step(actions)
+    total += reward
+    o = obs.cpu().numpy()
+    assert (o >= space.low - 1e-6).all() and (o <= space.high + 1e-6).all()
+    assert ((reward >= 0) & (reward <= 1)).all()
+    assert (env.arena.sim.state['status'] == 0).all()              # auto-reset: everybody flies
+  env.arena.sim.check_errors()
+  assert total.max() <= 12.0
+  # with wind noise on, forecast != truth: the WindGP uncertainty at the balloon's level is below 1
+  assert (obs[:, 16 + 3 * 180] < 0.5).float().mean() > 0.5
