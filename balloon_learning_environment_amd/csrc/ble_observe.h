@@ -26,6 +26,8 @@
 // All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 66 KB (L, rows padded to 128)
 // + 16 KB (diagonal-block inverses) + 15 KB -- one workgroup per CU.  DESIGN.md 3b has the cycle budget.
 #pragma once
+#include <type_traits>
+
 #include "ble_reset.h"
 
 namespace ble {
@@ -625,114 +627,122 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
-  // -- V = L^-1 [K*^T | y] with v_mfma_f64_16x16x4: wave w owns query columns 48 w .. 48 w + 47
-  // (3 tiles of 16); columns 181 and 182 are the two error vectors, so z = L^-1 y falls out of
-  // the same sweep.  MFMA register layout (measured on gfx950): A lane l holds A[l % 16][l / 16],
-  // B lane l holds B[l / 16][l % 16], D lane l register v holds D[4 v + l / 16][l % 16] -- a D
-  // tile is therefore directly the four B operands of the next product, and V never leaves
-  // the registers.
+  // -- V = L^-1 [y | K*^T] with v_mfma_f64_16x16x4.  Columns: 0, 1 = the two error vectors (so
+  // z = L^-1 y falls out of the same sweep), then ONLY the reachable levels lo_idx .. hi_idx -- the
+  // others are (0, 1, 1) whatever the GP says (features.py:530-536).  Typically 117-126 of the 181
+  // levels are reachable: 8 tiles of 16 columns = two per wave instead of three.  Tile T = 4 round +
+  // wave.  MFMA register layout (measured on gfx950): A lane l holds A[l % 16][l / 16], B lane l
+  // holds B[l / 16][l % 16], D lane l register v holds D[4 v + l / 16][l % 16] -- a D tile is
+  // therefore directly the four B operands of the next product, and V never leaves the registers.
   typedef double d4 __attribute__((ext_vector_type(4)));
   const int g = lane >> 4, jq = lane & 15;
   const int nb = n_pad >> 4;
-  d4 V[3][8];
-  double level_q[3];
-  int qcol[3];
+  int lo_idx = (int)((p_lo - 5000.0) * (1.0 / 50.0)), hi_idx = (int)((p_hi - 5000.0) * (1.0 / 50.0));
+  lo_idx = lo_idx < 0 ? 0 : (lo_idx > 181 ? 181 : lo_idx);
+  hi_idx = hi_idx < -1 ? -1 : (hi_idx > 180 ? 180 : hi_idx);
+  while (lo_idx > 0 && 5000.0 + 50.0 * (double)(lo_idx - 1) >= p_lo) --lo_idx;     // exactly the reference's
+  while (lo_idx <= 180 && 5000.0 + 50.0 * (double)lo_idx < p_lo) ++lo_idx;          // level >= p_lo && level <= p_hi
+  while (hi_idx < 180 && 5000.0 + 50.0 * (double)(hi_idx + 1) <= p_hi) ++hi_idx;
+  while (hi_idx >= 0 && 5000.0 + 50.0 * (double)hi_idx > p_hi) --hi_idx;
+  const int n_reach = hi_idx >= lo_idx ? hi_idx - lo_idx + 1 : 0;
+  const int n_tiles = (2 + n_reach + 15) >> 4;                                       // 1 .. 12
+  // Each wave sweeps its tiles {wave, wave + 4, wave + 8} TOGETHER (independent accumulators keep the
+  // matrix pipe busy); NT = 2 of them when <= 8 tiles are active (the usual case), else 3.
+  auto sweep = [&](auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    d4 V[NT][8];
+    int col[NT];
+    double level[NT];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    qcol[t] = wave * 48 + t * 16 + jq;
-    level_q[t] = 5000.0 + 50.0 * (double)qcol[t];
-  }
+    for (int t = 0; t < NT; ++t) {
+      col[t] = 16 * (4 * t + wave) + jq;
+      level[t] = 5000.0 + 50.0 * (double)(lo_idx + col[t] - 2);
+    }
 #pragma unroll
-  for (int I = 0; I < 8; ++I) {
+    for (int I = 0; I < 8; ++I) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) V[t][I] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (I < nb) {
-      d4 acc[3];
+      for (int t = 0; t < NT; ++t) V[t][I] = (d4){0.0, 0.0, 0.0, 0.0};
+      if (I < nb) {
+        d4 acc[NT];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-      const double* arow = sh.L + tri(16 * I + jq) + g;
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double* arow = sh.L + tri(16 * I + jq) + g;
 #pragma unroll
-      for (int J = 0; J < I; ++J)
+        for (int J = 0; J < I; ++J)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double a = arow[16 * J + 4 * c];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
+          }
+        d4 R[NT];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + 4 * v + g;
+          const double a_row = sh.a[row], p_row = sh.loc[row][2];
+          const double live = row < n_obs ? kGpSigma2 : 0.0;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused)
+            const double dp = (level[t] - p_row) * (1.0 / 326.0);
+            const double r2 = a_row + dp * dp;
+            R[t][v] = live * d_exp_fast(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)));
+          }
+          if (wave == 0) R[0][v] = jq == 0 ? sh.z[0][row] : (jq == 1 ? sh.z[1][row] : R[0][v]);   // uniform branch: tile 0
+#pragma unroll
+          for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
+        }
+        const double* drow = sh.dinv[I] + jq * 16 + g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double a = arow[16 * J + 4 * c];
+          const double a = drow[4 * c];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
         }
-      d4 R[3];
+      }
+    }
+    __syncthreads();                 // wave 0 has read the raw error vectors
+    if (wave == 0 && jq < 2) {       // columns 0, 1 of tile 0
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * I + 4 * v + g;
-        const double a_row = sh.a[row], p_row = sh.loc[row][2];
-        const double live = row < n_obs ? kGpSigma2 : 0.0;
+      for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          // branch-free: every lane evaluates the kernel (columns past level 180 are simply unused)
-          const double dp = (level_q[t] - p_row) * (1.0 / 326.0);
-          const double r2 = a_row + dp * dp;
-          R[t][v] = live * d_exp_fast(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)));
-        }
-        if (wave == 3) {        // uniform: tile 2 of wave 3 holds the error vectors in columns 181 / 182
+        for (int v = 0; v < 4; ++v) sh.z[jq][16 * I + 4 * v + g] = V[0][I][v];
+    }
+    __syncthreads();
+    double ssq[NT], mean_u[NT], mean_v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { ssq[t] = 0.0; mean_u[t] = 0.0; mean_v[t] = 0.0; }
+#pragma unroll
+    for (int I = 0; I < 8; ++I) {
+      if (I < nb) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + 4 * v + g;
           const double zu = sh.z[0][row], zv = sh.z[1][row];
-          R[2][v] = jq < 5 ? R[2][v] : (jq == 5 ? zu : (jq == 6 ? zv : 0.0));
-        }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) R[t][v] -= acc[t][v];
-      }
-      const double* drow = sh.dinv[I] + jq * 16 + g;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double a = drow[4 * c];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
-      }
-    }
-  }
-  BLE_MARK();
-  __syncthreads();                 // every lane has read the raw error vectors
-  if (wave == 3 && (jq == 5 || jq == 6)) {      // columns 181, 182 live in tile 2 of wave 3
-#pragma unroll
-    for (int I = 0; I < 8; ++I)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) sh.z[jq - 5][16 * I + 4 * v + g] = V[2][I][v];
-  }
-  __syncthreads();
-  double ssq[3] = {0.0, 0.0, 0.0}, mean_u[3] = {0.0, 0.0, 0.0}, mean_v[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-  for (int I = 0; I < 8; ++I) {
-    if (I < nb) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * I + 4 * v + g;
-        const double zu = sh.z[0][row], zv = sh.z[1][row];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const double val = V[t][I][v];
-          ssq[t] = d_fma(val, val, ssq[t]);
-          mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y = (L^-1 k*) . (L^-1 y)
-          mean_v[t] = d_fma(val, zv, mean_v[t]);
+          for (int t = 0; t < NT; ++t) {
+            const double val = V[t][I][v];
+            ssq[t] = d_fma(val, val, ssq[t]);
+            mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y = (L^-1 k*) . (L^-1 y)
+            mean_v[t] = d_fma(val, zv, mean_v[t]);
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {     // the four lanes g = 0..3 of a column hold disjoint rows
-    ssq[t] += __shfl_xor(ssq[t], 16, 64); ssq[t] += __shfl_xor(ssq[t], 32, 64);
-    mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
-    mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
-  }
-  BLE_MARK();
-  if (g == 0) {
+    for (int t = 0; t < NT; ++t) {     // the four lanes g = 0..3 of a column hold disjoint rows
+      ssq[t] += __shfl_xor(ssq[t], 16, 64); ssq[t] += __shfl_xor(ssq[t], 32, 64);
+      mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
+      mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
+    }
+    if (g == 0) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int q = qcol[t];
-      if (q >= kObsLevels) continue;
-      const double level = level_q[t];
-      float f0 = 0.0f, f1 = 1.0f, f2 = 1.0f;             // unreachable: certain, wrong way, infinitely fast
-      if (level >= p_lo && level <= p_hi) {
+      for (int t = 0; t < NT; ++t) {
+        const int level_idx = lo_idx + col[t] - 2;
+        if (col[t] < 2 || level_idx > hi_idx) continue;
         // forecast at this level from the blended column
         int ip; float wp;
-        wind_axis((float)level, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
+        wind_axis((float)level[t], 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
         const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
         const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
         const double u = mean_u[t] + (double)fu, v = mean_v[t] + (double)fv;
@@ -750,15 +760,16 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
           c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
           angle = kPiD / 2 - d_asin(c);
         }
-        f0 = (float)deviation; f1 = (float)(angle / kPiD); f2 = (float)(speed / (speed + 30.0));
+        float* o = out + 16 + 3 * (pad_above + level_idx);
+        o[0] = (float)deviation; o[1] = (float)(angle / kPiD); o[2] = (float)(speed / (speed + 30.0));
       }
-      float* o = out + 16 + 3 * (pad_above + q);
-      o[0] = f0; o[1] = f1; o[2] = f2;
     }
-  }
-  // padding above and below the 181 real levels
+  };
+  if (n_tiles <= 8) sweep(std::integral_constant<int, 2>{});
+  else sweep(std::integral_constant<int, 3>{});
+  // padding above and below the 181 real levels, and the unreachable levels: certain, wrong way, infinitely fast
   for (int c = tid; c < kObsColumn; c += kObsBlock) {
-    if (c < pad_above || c >= pad_above + kObsLevels) {
+    if (c < pad_above + lo_idx || c > pad_above + hi_idx) {
       float* o = out + 16 + 3 * c;
       o[0] = 0.0f; o[1] = 1.0f; o[2] = 1.0f;
     }
