@@ -8,7 +8,6 @@
 // 8 x (4 contiguous floats).  Nothing here is a dense contraction: no MFMA.
 // Target: gfx950 only (hipcc --offload-arch=gfx950); no other backend, no shims.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 
 #include "../../include/ble_abi.h"
 #include "ble_reset.h"
@@ -391,13 +390,7 @@ __global__ __launch_bounds__(256) void probe_f64_kernel(const double* x, double*
   y[i] = r;
 }
 namespace {
-inline int env_lanes() {
-  static const int lanes = [] {
-    const char* e = getenv("BLE_LANES_PER_WAVE");
-    return (e && atoi(e) == 32) ? 32 : 64;
-  }();
-  return lanes;
-}
+inline int env_lanes() { return kBlock; }   // one environment per lane, all 64 lanes (32 was measured: slower)
 // hipGetLastError is per-thread and sticky: an error left behind by an unrelated runtime call
 // of the host application (torch probes pointers / peers at start-up) must not be reported as
 // ours, so every launch first drains it, and the launch's own status is kept for

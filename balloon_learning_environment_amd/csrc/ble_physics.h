@@ -143,11 +143,7 @@ BLE_FN double d_exp_fast(double t) {
   pe = d_fma(pe, r, 1.0 / 6.0); pe = d_fma(pe, r, 0.5); pe = d_fma(pe, r, 1.0); pe = d_fma(pe, r, 1.0);
   return d_ldexp(pe, (int)kq);
 }
-#if defined(BLE_ABLATE) && (BLE_ABLATE & 4)
-BLE_FN double d_pow_fast(double x, double y) { return x * 0.9 + y * 1e-3; }
-#else
 BLE_FN double d_pow_fast(double x, double y) { return d_exp_fast(y * d_log_fast(x)); }
-#endif
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

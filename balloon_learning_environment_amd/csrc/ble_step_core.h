@@ -16,13 +16,6 @@
 #pragma once
 #include "ble_physics.h"
 
-// Timing-ablation switches for kernel analysis builds only (-DBLE_ABLATE=<bits>); the
-// product is always built with 0.  1: one ephemeris  2: no sun nodes  4: no atmosphere pows
-// 8: no reward sun  16: no safety layers
-#ifndef BLE_ABLATE
-#define BLE_ABLATE 0
-#endif
-
 namespace ble {
 
 struct EnvRegs {
@@ -56,13 +49,9 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   double cur_hi = win.pb, cur_lo = win.pt;       // transition pressures bounding that layer
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
-#if BLE_ABLATE & 16
-  int eff = action; (void)altitude;
-#else
   int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
   eff = envelope_safety(eff, s.sp, &s.env_fsm);
   eff = altitude_safety(eff, altitude, &s.alt_fsm);
-#endif
 
   // ---- per-step constants
   const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
@@ -96,13 +85,9 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
     const double sd0 = (double)e0.sin_decl, cd0 = (double)e0.cos_decl;
     const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = 0.5 * (double)(e0.cos_decl_rate * step_s);
-#if BLE_ABLATE & 2
-    const double f0 = 0.3 + 1e-9 * x0, f1 = 0.31 + 1e-9 * dx, f2 = 0.32 + sl0 * 0 + cl0 * 0 + sd0 * 0 + cd0 * 0 + hsd * 0 + hcd * 0 + y0 * 0 + dy * 0 + sb2 * 0 + cb2 * 0;
-#else
     const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, sb0, cb0, sd0, cd0);
     const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, sb1, cb1, sd0 + hsd, cd0 + hcd);
     const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, sb2, cb2, sd0 + 2.0 * hsd, cd0 + 2.0 * hcd);
-#endif
     const double m = 0.5 * (double)substeps;
     oms_c0 = (float)f0;
     oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
@@ -214,7 +199,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
 
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
   float r = reward_distance(s.x, s.y);
-  if (action == kDown && !(BLE_ABLATE & 8)) {   // last_command is the RAW action (balloon.py:286)
+  if (action == kDown) {   // last_command is the RAW action (balloon.py:286)
     const float fk = (float)k;
     const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
     const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p));
