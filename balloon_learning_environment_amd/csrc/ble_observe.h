@@ -735,11 +735,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
       mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
     }
-    if (g == 0) {
+    {
+      // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int level_idx = lo_idx + col[t] - 2;
-        if (col[t] < 2 || level_idx > hi_idx) continue;
+        if (g != t || col[t] < 2 || level_idx > hi_idx) continue;
         // forecast at this level from the blended column
         int ip; float wp;
         wind_axis((float)level[t], 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
