@@ -58,13 +58,14 @@ struct GpHistory {
 };
 
 struct ObsShared {
-  double L[kGpRows * (kGpRows + 1) / 2]; // packed lower triangle, rows padded with identity to a multiple of 16
+  double L[kGpRows * (kGpRows + 1) / 2]; // K + noise = Lt D Lt^T, packed lower triangle: unit-lower Lt below the
+                                         // diagonal, d on it; rows padded with identity to a multiple of 16
   double dinv[kGpRows / 16][256];        // inverses of the 16 x 16 diagonal blocks of L (row-major)
   double el_table[kElevTable];           // solar elevation at now + 180 s * (k - 240)
   double loc[kGpRows][4];                // x, y, p, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[2][kGpRows];                  // error components, then z = L^-1 y
-  double inv_diag[kGpRows];              // 1 / L[i][i]
+  double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20], sp[22];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
@@ -369,68 +370,74 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       double* new_row = sh.L + tri(nn);
       int n_cur = n_chol0;
       for (int rep = 0; rep < n_dropped; ++rep) {
-        // K = [k11 k21^T; k21 K22], L = [l11 0; l21 L22]  =>  chol(K22) = cholupdate(L22, l21).
-        // The result is written one row up and one column left of where L22 was read, which no
-        // later read of this sweep touches.  The last sweep also carries the append's forward
-        // substitution: column k of the new factor is used the moment it exists (no LDS read).
+        // K = [k11 k21^T; k21 K22] = Lt D Lt^T with Lt = [1 0; l21 L22], D = diag(d1, D2)
+        //   =>  K22 = L22 D2 L22^T + d1 l21 l21^T : a rank-1 update of the trailing LDL^T factor
+        // (Gill, Golub, Murray, Saunders 1974, method C1) with weight alpha = d1, carried as
+        // gamma = 1 / alpha so that its recurrence is one FMA:  gamma' = gamma + p^2 / d_k.
+        // Per step the sequential chains (w_k -> w_k+1, gamma, and the append's b_k -> b_k+1) hold one
+        // FMA each; the reciprocal is off the chains.  The result is written one row up and one
+        // column left of where L22 was read, which no later read of this sweep touches.  The last
+        // sweep also carries the append's forward substitution (unit lower: no division in it).
         const bool fuse = appended && rep == n_dropped - 1;
         const int rows = n_cur - 1;
         const bool own0 = lane < rows, own1 = lane + 64 < rows;
-        double x0 = own0 ? sh.L[tri(lane + 1)] : 0.0;
-        double x1 = own1 ? sh.L[tri(lane + 65)] : 0.0;
+        double w0 = own0 ? sh.L[tri(lane + 1)] : 0.0;          // l21
+        double w1 = own1 ? sh.L[tri(lane + 65)] : 0.0;
         // Old row i + 1 shifted one column; lanes that own no row read in-bounds garbage that only
-        // ever reaches their private x / b, which nobody reads (readlane targets owner lanes only).
+        // ever reaches their private w / b, which nobody reads (readlane targets owner lanes only).
         const double* old0 = sh.L + tri(own0 ? lane + 1 : 1) + 1;
         const double* old1 = sh.L + tri(own1 ? lane + 65 : 1) + 1;
         double* new0 = sh.L + tri(lane);
         double* new1 = sh.L + tri(lane + 64);
         // what lane k (rows k and k + 64) will write when the sweep is over
-        double diag0 = 0.0, diag1 = 0.0, row0 = 0.0, row1 = 0.0, inv0 = 1.0, inv1 = 1.0;
-        // loads and the reciprocal of step k + 1 are issued during step k (none of this sweep's
-        // stores aliases them; see the index argument above)
-        double lkk = sh.L[tri(1) + 1], il = d_rcp(lkk);
+        double diag0 = 1.0, diag1 = 1.0, row0 = 0.0, row1 = 0.0, inv0 = 1.0, inv1 = 1.0;
+        double gamma = d_rcp(sh.L[0]), rg = sh.L[0];            // 1 / alpha and alpha = d1 of the dropped row
+        // loads and the reciprocal of step k + 1 are issued during step k
+        double dk = sh.L[tri(1) + 1], idk = d_rcp(dk);
         double lik0 = old0[0], lik1 = old1[0];
         const int first = rows < 64 ? rows : 64;
         for (int k = 0; k < first; ++k) {                 // rows k .. rows-1 live in both halves
           const int kn = k + 1 < rows ? k + 1 : k;
-          const double lkk_next = sh.L[tri(kn + 1) + kn + 1];
+          const double dk_next = sh.L[tri(kn + 1) + kn + 1];
           const double lik0_next = old0[kn], lik1_next = old1[kn];
-          const double xk = readlane_f64(x0, k);
-          const double r2 = d_fma(lkk, lkk, xk * xk);
-          const double ir = d_rsqrt(r2);
-          const double sn = xk * il, ic = lkk * ir;
-          const double n0 = d_fma(sn, x0, lik0) * ic, n1 = d_fma(sn, x1, lik1) * ic;
-          x0 = d_fma(-sn, lik0, x0) * ic;                // c x - s l_new == (x - s l_old) / c
-          x1 = d_fma(-sn, lik1, x1) * ic;
+          const double pk = readlane_f64(w0, k);
+          const double gamma_new = d_fma(pk * pk, idk, gamma);
+          const double rg_new = d_rcp(gamma_new);
+          const double inv_dnew = idk * gamma * rg_new;          // 1 / d'_k,  d'_k = d_k gamma' / gamma
+          const double beta = pk * rg_new * idk;
+          w0 = d_fma(-pk, lik0, w0);
+          w1 = d_fma(-pk, lik1, w1);
+          const double n0 = d_fma(beta, w0, lik0), n1 = d_fma(beta, w1, lik1);
           if (own0 && lane > k) new0[k] = n0;
           if (own1) new1[k] = n1;
-          const double xj = fuse ? readlane_f64(b0, k) * ir : 0.0;      // 1 / L'[k][k] == ir
-          ssum = d_fma(xj, xj, ssum);
-          b0 = d_fma(-n0, xj, b0);
-          b1 = d_fma(-n1, xj, b1);
+          const double wk = fuse ? readlane_f64(b0, k) : 0.0;    // (Lt'^-1 k_new)_k: final, unit diagonal
+          ssum = d_fma(wk * wk, inv_dnew, ssum);
+          b0 = d_fma(-n0, wk, b0);
+          b1 = d_fma(-n1, wk, b1);
           const bool mine = lane == k;
-          diag0 = mine ? r2 * ir : diag0; row0 = mine ? xj : row0; inv0 = mine ? ir : inv0;
-          const double il_next = d_rcp(lkk_next);
-          lkk = lkk_next; il = il_next; lik0 = lik0_next; lik1 = lik1_next;
+          diag0 = mine ? dk * gamma_new * rg : diag0; row0 = mine ? wk * inv_dnew : row0; inv0 = mine ? inv_dnew : inv0;
+          const double idk_next = d_rcp(dk_next);
+          gamma = gamma_new; rg = rg_new; dk = dk_next; idk = idk_next; lik0 = lik0_next; lik1 = lik1_next;
         }
         for (int k = 64; k < rows; ++k) {                 // only the upper halves are still live
           const int kn = k + 1 < rows ? k + 1 : k;
-          const double lkk_next = sh.L[tri(kn + 1) + kn + 1];
+          const double dk_next = sh.L[tri(kn + 1) + kn + 1];
           const double lik1_next = old1[kn];
-          const double xk = readlane_f64(x1, k - 64);
-          const double r2 = d_fma(lkk, lkk, xk * xk);
-          const double ir = d_rsqrt(r2);
-          const double sn = xk * il, ic = lkk * ir;
-          const double n1 = d_fma(sn, x1, lik1) * ic;
-          x1 = d_fma(-sn, lik1, x1) * ic;
+          const double pk = readlane_f64(w1, k - 64);
+          const double gamma_new = d_fma(pk * pk, idk, gamma);
+          const double rg_new = d_rcp(gamma_new);
+          const double inv_dnew = idk * gamma * rg_new;
+          const double beta = pk * rg_new * idk;
+          w1 = d_fma(-pk, lik1, w1);
+          const double n1 = d_fma(beta, w1, lik1);
           if (own1 && lane + 64 > k) new1[k] = n1;
-          const double xj = fuse ? readlane_f64(b1, k - 64) * ir : 0.0;
-          ssum = d_fma(xj, xj, ssum);
-          b1 = d_fma(-n1, xj, b1);
+          const double wk = fuse ? readlane_f64(b1, k - 64) : 0.0;
+          ssum = d_fma(wk * wk, inv_dnew, ssum);
+          b1 = d_fma(-n1, wk, b1);
           const bool mine = lane + 64 == k;
-          diag1 = mine ? r2 * ir : diag1; row1 = mine ? xj : row1; inv1 = mine ? ir : inv1;
-          const double il_next = d_rcp(lkk_next);
-          lkk = lkk_next; il = il_next; lik1 = lik1_next;
+          diag1 = mine ? dk * gamma_new * rg : diag1; row1 = mine ? wk * inv_dnew : row1; inv1 = mine ? inv_dnew : inv1;
+          const double idk_next = d_rcp(dk_next);
+          gamma = gamma_new; rg = rg_new; dk = dk_next; idk = idk_next; lik1 = lik1_next;
         }
         if (own0) { new0[lane] = diag0; if (fuse) { new_row[lane] = row0; sh.inv_diag[lane] = inv0; } }
         if (own1) { new1[lane + 64] = diag1; if (fuse) { new_row[lane + 64] = row1; sh.inv_diag[lane + 64] = inv1; } }
@@ -443,27 +450,29 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         wave_sync_lds();
       }
       if (appended && n_dropped == 0) {
+        // new row of Lt: (Lt^-1 k_new)_j / d_j; the forward substitution against a unit-lower factor
+        // has no division in its chain
         const bool in0 = lane < nn, in1 = lane + 64 < nn;
-        const double* row0 = sh.L + tri(lane);
-        const double* row1 = sh.L + tri(lane + 64);
+        const double* lrow0 = sh.L + tri(lane);
+        const double* lrow1 = sh.L + tri(lane + 64);
         double inv_j = nn > 0 ? sh.inv_diag[0] : 0.0;
-        double l0 = in0 && lane > 0 ? row0[0] : 0.0, l1 = in1 ? row1[0] : 0.0;
+        double l0 = in0 && lane > 0 ? lrow0[0] : 0.0, l1 = in1 ? lrow1[0] : 0.0;
         for (int j = 0; j < nn; ++j) {
           const int jn = j + 1 < nn ? j + 1 : j;
           const double inv_next = sh.inv_diag[jn];
-          const double l0_next = in0 && lane > jn ? row0[jn] : 0.0, l1_next = in1 && lane + 64 > jn ? row1[jn] : 0.0;
-          const double xj = readlane_f64(j < 64 ? b0 : b1, j & 63) * inv_j;
-          ssum = d_fma(xj, xj, ssum);
-          if (lane == 0) new_row[j] = xj;
-          if (in0 && lane > j) b0 = d_fma(-l0, xj, b0);
-          if (in1 && lane + 64 > j) b1 = d_fma(-l1, xj, b1);
+          const double l0_next = in0 && lane > jn ? lrow0[jn] : 0.0, l1_next = in1 && lane + 64 > jn ? lrow1[jn] : 0.0;
+          const double wj = readlane_f64(j < 64 ? b0 : b1, j & 63);
+          ssum = d_fma(wj * wj, inv_j, ssum);
+          if (lane == 0) new_row[j] = wj * inv_j;
+          if (in0 && lane > j) b0 = d_fma(-l0, wj, b0);
+          if (in1 && lane + 64 > j) b1 = d_fma(-l1, wj, b1);
           inv_j = inv_next; l0 = l0_next; l1 = l1_next;
         }
       }
       if (appended && lane == 0) {
-        const double dd = sqrt(kGpSigma2 + kGpNoise2 - ssum);
-        new_row[nn] = dd;
-        sh.inv_diag[nn] = 1.0 / dd;
+        const double dnew = kGpSigma2 + kGpNoise2 - ssum;       // d of the new row
+        new_row[nn] = dnew;
+        sh.inv_diag[nn] = 1.0 / dnew;
       }
       // identity padding up to the MFMA tile
       for (int i = n_obs + lane; i < n_pad; i += 64) {
@@ -595,6 +604,22 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       }
       __syncthreads();
     }
+    if (!incremental) {
+      // L L^T -> Lt D Lt^T (the form the incremental slide and the sweep below work on):
+      // Lt[i][j] = L[i][j] / L[j][j], d[j] = L[j][j]^2
+      const int total = tri(n_pad);
+      for (int e = tid; e < total; e += kObsBlock) {
+        int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (tri(i) > e) --i;
+        while (tri(i + 1) <= e) ++i;
+        const int j = e - tri(i);
+        const double v = sh.L[e];
+        sh.L[e] = i == j ? v * v : v * sh.inv_diag[j];
+      }
+      __syncthreads();
+      for (int j = tid; j < n_pad; j += kObsBlock) { const double r = sh.inv_diag[j]; sh.inv_diag[j] = r * r; }
+      __syncthreads();
+    }
   }
   BLE_MARK();
   BLE_MARK();
@@ -605,7 +630,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   const int pad_above = kObsLevels - level_now - 1;
   const double dist = sqrt(x * x + y * y);
   const double to_station_x = -x / (dist + 1e-5), to_station_y = -y / (dist + 1e-5);
-  // -- inverses of the 16 x 16 diagonal blocks (thread = (block, column): forward substitution)
+  // -- inverses of the 16 x 16 (unit lower) diagonal blocks of Lt (thread = (block, column): forward substitution)
   if (tid < 128) {
     const int blk = tid >> 4, c = tid & 15, base = blk * 16;
     if (base < n_pad) {
@@ -615,7 +640,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         double t = r == c ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < r; ++k) t = d_fma(-sh.L[tri(base + r) + base + k], xcol[k], t);
-        xcol[r] = (r < c) ? 0.0 : t * sh.inv_diag[base + r];
+        xcol[r] = (r < c) ? 0.0 : t;                          // unit diagonal
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sh.dinv[blk][r * 16 + c] = xcol[r];
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
-  // -- V = L^-1 [y | K*^T] with v_mfma_f64_16x16x4.  Columns: 0, 1 = the two error vectors (so
+  // -- V = Lt^-1 [y | K*^T] with v_mfma_f64_16x16x4 (K + noise = Lt D Lt^T, Lt unit lower).  Columns: 0, 1 = the two error vectors (so
   // z = L^-1 y falls out of the same sweep), then ONLY the reachable levels lo_idx .. hi_idx -- the
   // others are (0, 1, 1) whatever the GP says (features.py:530-536).  Typically 117-126 of the 181
   // levels are reachable: 8 tiles of 16 columns = two per wave instead of three.  Tile T = 4 round +
@@ -718,12 +743,13 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
-          const double zu = sh.z[0][row], zv = sh.z[1][row];
+          const double inv_d = sh.inv_diag[row];
+          const double zu = sh.z[0][row] * inv_d, zv = sh.z[1][row] * inv_d;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const double val = V[t][I][v];
-            ssq[t] = d_fma(val, val, ssq[t]);
-            mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y = (L^-1 k*) . (L^-1 y)
+            const double val = V[t][I][v];                // (Lt^-1 k*)_row
+            ssq[t] = d_fma(val * val, inv_d, ssq[t]);     // k* K^-1 k* = sum w^2 / d
+            mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y  = sum w zeta / d,  zeta = Lt^-1 y
             mean_v[t] = d_fma(val, zv, mean_v[t]);
           }
         }
