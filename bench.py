@@ -250,12 +250,13 @@ def main():
                    'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
                    'includes_gather_to_rank0': world > 1,
                    'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)',
-                   # 432 v_mfma_f64_16x16x4 per wave x 4 waves x 2 048 flop + ~0.6 MFLOP of fp64 VALU (factor slide,
-                   # kernel evaluations) per environment; fp64 matrix and vector peaks are both 78.6 TFLOP/s
+                   # 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles (two error vectors + the ~120 reachable
+                   # levels) x 2 048 flop + ~0.6 MFLOP of fp64 VALU (factor slide, kernel evaluations) per
+                   # environment; fp64 matrix and vector peaks are both 78.6 TFLOP/s
                    'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 78.6,
-                                'achieved': n * (432 * 4 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12,
-                                'frac': n * (432 * 4 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12 / 78.6,
-                                'traffic': None, 'algorithmic_flop_per_env': 432 * 4 * 2048 + 0.6e6}}
+                                'achieved': n * (144 * 8 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12,
+                                'frac': n * (144 * 8 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12 / 78.6,
+                                'traffic': None, 'algorithmic_flop_per_env': 144 * 8 * 2048 + 0.6e6}}
     del one
 
   # what actually bounds the kernel (from the committed PMC summary of the same command, if present)
