@@ -58,10 +58,14 @@ struct GpHistory {
 };
 
 struct ObsShared {
-  double L[kGpRows * (kGpRows + 1) / 2]; // K + noise = Lt D Lt^T, packed lower triangle: unit-lower Lt below the
-                                         // diagonal, d on it; rows padded with identity to a multiple of 16
-  double dinv[kGpRows / 16][256];        // inverses of the 16 x 16 diagonal blocks of L (row-major)
-  double el_table[kElevTable];           // solar elevation at now + 180 s * (k - 240)
+  double L[kCholStride];                 // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
+                                         // below the diagonal, d on it.  Rows 120 .. 127 (MFMA tile padding) are
+                                         // identity and exist only virtually (zero_row, d = 1)
+  union {
+    double el_table[kElevTable];         // phases 0-1: solar elevation at now + 180 s * (k - 240)
+    double dinv[kGpRows / 16][136];      // phases 4-5: inverses of the 16 x 16 unit-lower diagonal blocks, packed lower
+  };
+  double zero_row[112];                  // the off-diagonal part of a virtual padding row
   double loc[kGpRows][4];                // x, y, p, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[2][kGpRows];                  // error components, then z = L^-1 y
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     }
   }
   const double el_now = sh.el_now, flux_now = sh.flux_now;
+  if (tid >= 128 && tid < 128 + 112) sh.zero_row[tid - 128] = 0.0;
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
+  const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   // Can the stored factor be slid to the new window?  The observations inside the 6 h window
   // must be a suffix of the ring (time only moves forward inside an episode), the stored factor
   // must cover a window that ends where this call started, and the new window must start inside it.
@@ -476,9 +482,11 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       }
       // identity padding up to the MFMA tile
       for (int i = n_obs + lane; i < n_pad; i += 64) {
-        double* row = sh.L + tri(i);
-        for (int j = 0; j < i; ++j) row[j] = 0.0;
-        row[i] = 1.0;
+        if (i < kGpMax) {
+          double* row = sh.L + tri(i);
+          for (int j = 0; j < i; ++j) row[j] = 0.0;
+          row[i] = 1.0;
+        }
         sh.inv_diag[i] = 1.0;
         sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0;
       }
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   } else if (wave >= 2) {
     // -- refit path: K + noise, packed lower triangle; rows n_obs .. n_pad-1 are identity (padding to a
     //    multiple of the panel width: they factor to themselves and contribute nothing)
-    const int total = tri(n_pad);
+    const int total = tri(n_fac);
     for (int e = tid - 128; e < total; e += 128) {
       int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
       while (tri(i) > e) --i;
@@ -527,8 +535,8 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
   // of the trailing matrix, half = which half of the j range.
   {
     const int slot = tid >> 1, half = tid & 1;
-    for (int c0 = 0; c0 < (incremental ? 0 : n_pad); c0 += 8) {
-      const int rows = n_pad - c0;
+    for (int c0 = 0; c0 < (incremental ? 0 : n_fac); c0 += 8) {
+      const int rows = n_fac - c0;
       const bool is_matrix = slot < rows;
       const int i = c0 + slot;                                   // matrix row
       double* rowbase = sh.L + tri(is_matrix ? i : 0);
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
     if (!incremental) {
       // L L^T -> Lt D Lt^T (the form the incremental slide and the sweep below work on):
       // Lt[i][j] = L[i][j] / L[j][j], d[j] = L[j][j]^2
-      const int total = tri(n_pad);
+      const int total = tri(n_fac);
       for (int e = tid; e < total; e += kObsBlock) {
         int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (tri(i) > e) --i;
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         sh.L[e] = i == j ? v * v : v * sh.inv_diag[j];
       }
       __syncthreads();
-      for (int j = tid; j < n_pad; j += kObsBlock) { const double r = sh.inv_diag[j]; sh.inv_diag[j] = r * r; }
+      for (int j = tid; j < n_pad; j += kObsBlock) { const double r = j < n_fac ? sh.inv_diag[j] : 1.0; sh.inv_diag[j] = r * r; }
       __syncthreads();
     }
   }
@@ -639,11 +647,12 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
       for (int r = 0; r < 16; ++r) {
         double t = r == c ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) t = d_fma(-sh.L[tri(base + r) + base + k], xcol[k], t);
+        for (int k = 0; k < r; ++k) t = d_fma(-(base + r < kGpMax ? sh.L[tri(base + r) + base + k] : 0.0), xcol[k], t);
         xcol[r] = (r < c) ? 0.0 : t;                          // unit diagonal
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sh.dinv[blk][r * 16 + c] = xcol[r];
+      for (int r = 0; r < 16; ++r)
+        if (r >= c) sh.dinv[blk][tri(r) + c] = xcol[r];
     }
   }
   __syncthreads();
@@ -691,7 +700,7 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
         d4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        const double* arow = sh.L + tri(16 * I + jq) + g;
+        const double* arow = (16 * I + jq < kGpMax ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
 #pragma unroll
         for (int J = 0; J < I; ++J)
 #pragma unroll
@@ -717,10 +726,10 @@ __global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st
 #pragma unroll
           for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
         }
-        const double* drow = sh.dinv[I] + jq * 16 + g;
+        const double* drow = sh.dinv[I] + tri(jq) + g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double a = drow[4 * c];
+          const double a = 4 * c + g <= jq ? drow[4 * c] : 0.0;      // packed lower triangle
 #pragma unroll
           for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
         }
