@@ -147,7 +147,7 @@ __device__ inline double safe_pressure_search(const double* lev, const double* s
   return significant;
 }
 
-__global__ __launch_bounds__(kObsBlock) void ble_observe_kernel(ble_state_f32 st, const float* __restrict__ wind_grid,
+__global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32 st, const float* __restrict__ wind_grid,
                                                                 int64_t grid_env_stride,
                                                                 const float* __restrict__ noise_uv,
                                                                 const uint8_t* __restrict__ reset_mask, GpHistory hist,
