@@ -23,8 +23,9 @@
 //              deviation = (s^2 - |v|^2) / s^2
 //   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
 //
-// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 66 KB (L, rows padded to 128)
-// + 16 KB (diagonal-block inverses) + 15 KB -- one workgroup per CU.  DESIGN.md 3b has the cycle budget.
+// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (factor) + 8.7 KB (block
+// inverses, aliased with the solar table) + 10 KB = 76.5 KB and <= 256 registers: two workgroups per CU,
+// which is what hides the latency-bound single-wave phases.  DESIGN.md 3b has the cycle budget.
 #pragma once
 #include <type_traits>
 
