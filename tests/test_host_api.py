@@ -37,6 +37,17 @@ def test_state_struct_matches_header_order():
   assert ctypes.sizeof(_abi.BleStateF32) == 8 * len(_abi.FIELD_NAMES)
 
 
+def test_gp_history_struct_matches_header_order():
+  header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
+  body = header[header.index('typedef struct ble_gp_history_f32 {'):header.index('} ble_gp_history_f32;')]
+  names = re.findall(r'\*\s*(\w+);', body)
+  assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_]
+  assert ctypes.sizeof(_abi.BleGpHistoryF32) == 8 * len(names)
+  assert int(re.search(r'#define BLE_OBS_DIM (\d+)', header).group(1)) == _lib.OBS_DIM
+  assert int(re.search(r'#define BLE_GP_CAPACITY (\d+)', header).group(1)) == _lib.GP_CAPACITY
+  assert int(re.search(r'#define BLE_GP_CHOL_STRIDE (\d+)', header).group(1)) == _lib.GP_CHOL_STRIDE
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
   monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
   monkeypatch.setattr(_lib, '_lib', None)
