@@ -274,7 +274,7 @@ def main():
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32 state, f64 vertical chain', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32+f64', 'data': 'synthetic',
         'config': {'workload': (f'{n} vectorised envs per GPU, random policy, per-env forecasts decoded on the device '
                                 '(BASELINE.json configs[4] shape: VAE path, synthetic weights)' if args.per_env_grids else
                                 f'{n} vectorised envs per GPU, random policy, one decoded wind grid '
