@@ -4,6 +4,7 @@ import time
 from typing import Any, Callable, Dict, Mapping, Optional, Tuple, Union
 
 import numpy as np
+import torch
 
 from balloon_learning_environment_amd.env import balloon_arena
 from balloon_learning_environment_amd.env import features
@@ -149,17 +150,48 @@ class VecBalloonEnv:
 
   def reset(self):
     self.arena.reset(self._seed)
+    self._graph = None
     return self.arena.observe(self._noise_now())
+
+  def _step_eager(self, actions, obs_out=None):
+    reward, terminal = self.arena.step(actions, self._noise if self._wind_noise else None)
+    if self._auto_reset:
+      self._terminal_buf.copy_(terminal)
+      self.arena.sim.reset_device(self._seed, mask=self._terminal_buf)
+    return self.arena.observe(self._noise_now(), out=obs_out), reward, terminal
 
   def step(self, actions):
     """actions: uint8 device tensor [N] in {0, 1, 2}.  Returns (obs [N, 1099], reward [N], terminal [N] u8);
     `terminal` refers to the transition just made; with auto_reset the returned observation of a
-    terminated environment is the first one of its next episode."""
-    reward, terminal = self.arena.step(actions, self._noise if self._wind_noise else None)
-    reward, terminal = reward.clone(), terminal.clone()
-    if self._auto_reset:
-      self.arena.sim.reset_device(self._seed, mask=terminal)
-    return self.arena.observe(self._noise_now()), reward, terminal
+    terminated environment is the first one of its next episode.  With `capture_graph()` the three
+    tensors are static buffers that the next step overwrites."""
+    if not hasattr(self, '_terminal_buf'):
+      self._terminal_buf = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+    if getattr(self, '_graph', None) is not None:
+      self._g_actions.copy_(actions)
+      self._graph.replay()
+      return self._g_obs, self._g_reward, self._g_terminal
+    obs, reward, terminal = self._step_eager(actions)
+    return obs, reward.clone(), terminal.clone()
+
+  def capture_graph(self):
+    """Records one step (wind noise, transition, masked reset, observation: four kernels plus a few
+    fills) into a HIP graph and replays it from then on -- for small batches the loop is launch-bound.
+    Call after reset() and at least one step() (lazy allocations must have happened)."""
+    n, dev_ = self.num_envs, self.device
+    self._g_actions = torch.ones(n, dtype=torch.uint8, device=dev_)
+    self._g_obs = torch.empty(n, 1099, dtype=torch.float32, device=dev_)
+    if not hasattr(self, '_terminal_buf'):
+      self._terminal_buf = torch.zeros(n, dtype=torch.uint8, device=dev_)
+    side = torch.cuda.Stream(device=dev_)
+    side.wait_stream(torch.cuda.current_stream(dev_))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+      with torch.cuda.graph(graph, stream=side):
+        _, reward, terminal = self._step_eager(self._g_actions, obs_out=self._g_obs)
+        self._g_reward, self._g_terminal = reward.clone(), terminal.clone()
+    torch.cuda.current_stream(dev_).wait_stream(side)
+    self._graph = graph
 
   @property
   def observation_space(self):

@@ -193,3 +193,27 @@ def test_vec_balloon_env(mods):
   assert total.max() <= 12.0
   # with wind noise on, forecast != truth: the WindGP uncertainty at the balloon's level is below 1
   assert (obs[:, 16 + 3 * 180] < 0.5).float().mean() > 0.5
+
+
+def test_vec_balloon_env_graph_replay_matches_eager(mods):
+  """capture_graph(): the HIP-graph replay of a step gives bit-identical states, rewards and
+  observations to the eager sequence of launches."""
+  import torch
+  _, balloon_env, _, _ = mods
+  n = 192
+  envs = [balloon_env.VecBalloonEnv(n, seed=5, wind_noise=True) for _ in range(2)]
+  for e in envs:
+    e.reset()
+  gen = torch.Generator(device='cuda'); gen.manual_seed(0)
+  acts = torch.randint(0, 3, (12, n), dtype=torch.uint8, device='cuda', generator=gen)
+  for k in range(2):
+    for e in envs:
+      e.step(acts[k])
+  envs[1].capture_graph()
+  for k in range(2, 12):
+    o0, r0, t0 = envs[0].step(acts[k])
+    o1, r1, t1 = envs[1].step(acts[k])
+    assert torch.equal(r0, r1) and torch.equal(t0, t1) and torch.equal(o0, o1)
+  for name in ('x', 'pressure', 'battery_charge', 'time_elapsed_s'):
+    assert torch.equal(envs[0].arena.sim.state[name], envs[1].arena.sim.state[name])
+  envs[1].arena.sim.check_errors()
