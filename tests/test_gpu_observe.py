@@ -276,3 +276,33 @@ def test_observe_irregular_history_matches_oracle(vec_state, carry):
           worst = max(worst, err.max()); compared += 1
   assert compared > 50
   print('irregular history (carry=%s): %d comparisons, worst |diff| %.3g' % (carry, compared, worst))
+
+
+def test_carried_factor_does_not_drift(vec_state):
+  """600 agent steps (30 h, 480 window slides): the slid LDL^T factor must stay equivalent to a fresh
+  refit -- the two modes are run side by side on identical states and compared at the end and on the
+  way (stable rank-1 updates: the difference stays at rounding level)."""
+  n, steps = 96, 600
+  rng = np.random.default_rng(23)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  sims = [vec_state.VecSimulator(n) for _ in range(2)]
+  for sim in sims:
+    sim.set_grid(torch.from_numpy(field).cuda())
+    sim.reset_device(seed=31)
+  worst = 0.0
+  for i in range(steps):
+    actions = torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda()
+    noise = torch.from_numpy((rng.standard_normal((n, 2)) * 1.2).astype(np.float32)).cuda()
+    obs = []
+    for sim, carry in zip(sims, (True, False)):
+      sim.step(actions)
+      obs.append(sim.observe(noise, carry_factor=carry))
+    if i % 50 == 49 or i == steps - 1:
+      alive = (sims[0].state['status'] == 0)
+      assert torch.equal(sims[0].state['pressure'], sims[1].state['pressure'])
+      d = (obs[0].double() - obs[1].double()).abs()[alive]
+      worst = max(worst, float(d.max()))
+  for sim in sims:
+    sim.check_errors()
+  print('carried vs refit factor after %d steps: worst |diff| %.3g' % (steps, worst))
+  assert worst <= 2e-6
