@@ -306,3 +306,34 @@ def test_carried_factor_does_not_drift(vec_state):
     sim.check_errors()
   print('carried vs refit factor after %d steps: worst |diff| %.3g' % (steps, worst))
   assert worst <= 2e-6
+
+
+def test_carried_factor_equals_fresh_factorisation(vec_state):
+  """After 580 window slides the factor carried in HBM is compared entry by entry with a fresh
+  NumPy LDL^T of the window's kernel matrix (rebuilt from the history ring): rounding level."""
+  n, steps = 32, 700
+  rng = np.random.default_rng(1)
+  sim = vec_state.VecSimulator(n)
+  sim.set_grid(torch.from_numpy((rng.standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)).cuda())
+  sim.reset_device(seed=3)
+  for i in range(steps):
+    sim.step(torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda())
+    sim.observe(torch.from_numpy((rng.standard_normal((n, 2))).astype(np.float32)).cuda())
+  gp = {k: v.cpu().numpy() for k, v in sim._gp.items()}
+  ls = np.array([357000.0, 357000.0, 326.0, 34560.0])
+  worst = 0
+  for j in range(n):
+    cnt, m = int(gp['count'][j]), int(gp['n_chol'][j])
+    idx = [(cnt - m + l) % 128 for l in range(m)]
+    x = np.concatenate([gp['xyp'][j][idx].astype(np.float64), gp['elapsed_s'][j][idx].astype(np.float64)[:, None]], 1)
+    d = (x[:, None, :] - x[None, :, :]) / ls
+    K = 3.6 ** 2 * np.exp(-np.sqrt((d * d).sum(-1))) + 0.05 * np.eye(m)
+    L = np.linalg.cholesky(K); dd = np.diag(L) ** 2; Lt = L / np.diag(L)[None, :]
+    packed = gp['chol'][j]
+    got = np.zeros((m, m)); k = 0
+    for r in range(m):
+      got[r, :r + 1] = packed[k:k + r + 1]; k += r + 1
+    want = np.tril(Lt, -1) + np.diag(dd)
+    worst = max(worst, np.abs(got - want).max() / np.abs(want).max())
+  print('carried factor vs fresh LDL^T after %d slides: worst relative difference %.3g' % (steps - 120, worst))
+  assert m == 120 and worst < 1e-11
