@@ -220,10 +220,14 @@ __global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_
   if (i >= n) return;
   double s, c;
   sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
-  uint32_t flags = 0;
-  const float a = solar_attenuation((float)s, pressure[i]);
+  // thresholds decided on the fp64 input elevation, as the transition's exact path does
+  const double el = (double)el_deg[i];
+  SunState sun;
+  sun.sin_el = (float)s; sun.cos_el = (float)c;
+  sun.day = !(el < -4.242); sun.sh33 = el >= 37.738149050524044; sun.sh27 = el >= 34.39486500086289;
+  const float a = solar_attenuation(sun.sin_el, pressure[i], sun.day);
   att[i] = a;
-  power[i] = solar_power((float)s, (float)c, a);
+  power[i] = solar_power(sun, a);
 }
 __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume, const float* t_int, const float* t_amb,
                                                             const float* pressure, const float* el_deg,
@@ -234,10 +238,14 @@ __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume,
   if (i < n) {
     double s, c;
     sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
-    const float att = solar_attenuation((float)s, pressure[i]);
-    const float lv = f_log2(volume[i]);
-    const float v23 = f_exp2((2.0f / 3.0f) * lv), v_m13 = f_exp2((-1.0f / 3.0f) * lv);
-    dtdt[i] = thermal_dtdt(v23, v_m13, t_int[i], t_amb[i], pressure[i], flux[i] * att, earth_heat_per_area(ir[i], &flags), &flags);
+    const float att = solar_attenuation((float)s, pressure[i], !((double)el_deg[i] < -4.242));
+    const double vol = (double)volume[i];
+    double yc = (double)f_exp2((-1.0f / 3.0f) * f_log2(volume[i]));
+    yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
+    flags |= (t_int[i] < 12.3f) ? kFlagAbsorptivity : 0u;
+    dtdt[i] = (float)(0.1 * thermal_increment_f64(vol, yc, (double)t_int[i], (double)t_amb[i], (double)pressure[i],
+                                                  (flux[i] * att) * (0.25f * kSolarAbsorptivityTotal),
+                                                  earth_heat_per_area_f64((double)ir[i], &flags)));
   }
   report_flags(flags, err_flags);
 }
@@ -254,10 +262,10 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
                                                         int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float prm1 = pr[i] - 1.0f;
-  const float w = acs_power(prm1);
-  const float e = acs_efficiency(kAcsEfficiency, prm1, w);
-  power[i] = w; eff[i] = e; mdot[i] = e * w * (1.0f / 3600.0f);
+  const double prm1 = (double)pr[i] - 1.0;
+  const double w = acs_power_f64(prm1);
+  const double e = acs_efficiency_f64(kAcsEfficiency, prm1, w);
+  power[i] = (float)w; eff[i] = (float)e; mdot[i] = (float)(e * w * (1.0 / 3600.0));
 }
 
 // Decoder tail of the wind-field VAE (generative/vae.py:149-186): flow fields psi [n][7][7][90]

@@ -74,6 +74,8 @@ BLE_FN float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 BLE_FN double d_rint(double x) { return __builtin_rint(x); }
 BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
+BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)
+BLE_FN double d_max(double a, double b) { return __builtin_fmax(a, b); }
 #else
 BLE_FN float f_exp2(float x) { return exp2f(x); }
 BLE_FN float f_log2(float x) { return log2f(x); }
@@ -84,6 +86,8 @@ BLE_FN float f_fma(float a, float b, float c) { return fmaf(a, b, c); }
 BLE_FN double d_fma(double a, double b, double c) { return fma(a, b, c); }
 BLE_FN double d_rint(double x) { return rint(x); }
 BLE_FN double d_sqrt(double x) { return sqrt(x); }
+BLE_FN double d_min(double a, double b) { return fmin(a, b); }
+BLE_FN double d_max(double a, double b) { return fmax(a, b); }
 #endif
 // fp64 reciprocal / reciprocal-sqrt: hardware seed (v_rcp_f64 / v_rsq_f64, measured 4.3e-8 /
 // 5.0e-8 relative on gfx950) + ONE Newton step -> ~2e-15 / 4e-15 relative.  That is five
@@ -775,74 +779,234 @@ BLE_FN SunSC sun_refract(SunSC unc) {
   return r;
 }
 
+// ---------------------------------------------------------------- fp64 asin (fdlibm e_asin.c rational form)
+BLE_FN double d_asin(double x) {
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+               pio4_hi = 7.85398163397448278999e-01;
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  const double ax = fabs(x);
+  if (ax < 0.5) {
+    const double t = x * x;
+    const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+    const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+    return x + x * (p / q);
+  }
+  const double w = 1.0 - ax;
+  const double t = w * 0.5;
+  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+  const double s = sqrt(t);
+  const double r = p / q;
+  double res;
+  if (ax >= 0.975) {
+    res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
+  } else {
+    // split s into a head with 32 zero low bits (fdlibm) to keep the subtraction exact
+    union { double d; uint64_t u; } cv;
+    cv.d = s; cv.u &= 0xffffffff00000000ULL;
+    const double df = cv.d;
+    const double c = (t - df * df) / (s + df);
+    const double pp = 2.0 * s * r - (pio2_lo - 2.0 * c);
+    const double qq = pio4_hi - 2.0 * df;
+    res = pio4_hi - (pp - qq);
+  }
+  return x > 0 ? res : -res;
+}
+
+// ---------------------------------------------------------------- full fp64 solar calculator
+// solar.solar_calculator (solar.py:43-174): elevation [deg] (refraction corrected) and flux.
+BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
+  int64_t days = unix_s / 86400;
+  int64_t sod = unix_s - days * 86400;
+  if (sod < 0) { sod += 86400; days -= 1; }
+  const double frac = (double)sod / 86400.0;
+  const double jc = (((2440587.5 + (double)days) + frac) - 2451545.0) / 36525.0;
+  const double d2r = kPiD / 180.0;
+  const double l0 = d2r * (280.46646 + jc * (36000.76983 + jc * 0.0003032));
+  double s2l, c2l;
+  sincos_f64(2.0 * l0, &s2l, &c2l);
+  const double s4l = 2.0 * s2l * c2l;
+  const double m0 = d2r * (357.52911 + jc * (35999.05029 - 0.0001537 * jc));
+  double sm, cm;
+  sincos_f64(m0, &sm, &cm);
+  const double s2m = 2.0 * sm * cm, s3m = sm * (3.0 - 4.0 * sm * sm);
+  const double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
+  double so, co;
+  sincos_f64(d2r * (125.04 - 1934.136 * jc), &so, &co);
+  const double obl = mean_obl + d2r * (0.00256 * co);
+  double sobl, cobl;
+  sincos_f64(obl, &sobl, &cobl);
+  const double th = sobl / (1.0 + cobl), var_y = th * th;
+  const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
+  const double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
+                            1.25 * ecc * ecc * s2m);
+  // cos(hour_angle) = -cos(radians(1440 frac + degrees(eot) + 4 lng) / 4)   (solar.py:113-120)
+  double sh, ch;
+  sincos_f64(d2r * (360.0 * frac + 0.25 * (eot * (180.0 / kPiD)) + lng_deg), &sh, &ch);
+  const double eoc = d2r * (sm * (1.914602 - jc * (0.004817 + 0.000014 * jc)) + s2m * (0.019993 - 0.000101 * jc) + s3m * 0.000289);
+  double sa, ca;
+  sincos_f64(l0 + eoc - d2r * (0.00569 - 0.00478 * so), &sa, &ca);
+  const double sin_decl = sobl * sa;
+  const double cos_decl = sqrt(1.0 - sin_decl * sin_decl);
+  double s = sin_lat * sin_decl - cos_lat * cos_decl * ch;
+  s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
+  const double el = d_asin(s) * (180.0 / kPiD);      // 90 - degrees(acos(s))
+  const double c = sqrt(1.0 - s * s);
+  double refr;
+  if (el > 85.0) refr = 0.0;
+  else if (el > 5.0) { const double t = s / c; refr = 58.1 / t - 0.07 / (t * t * t) + 0.000086 / (t * t * t * t * t); }
+  else if (el > -0.575) refr = 1735.0 + el * (-518.2 + el * (103.4 + el * (-12.79 + el * 0.711)));
+  else refr = -20.772 / (s / c);
+  if (flux_out) { const double r = (1 + ecc) / (1 - ecc); *flux_out = 1366.0 * (1 + 0.5 * (r * r - 1) * cm); }
+  return el + refr / 3600.0;
+}
+
+// BalloonState.latlng (spherical_geometry.py:44-76) as (sin lat, cos lat, lng [deg]) in fp64.
+BLE_FN void latlng_f64(double lat0_deg, double lng0_deg, double x, double y, double* sin_lat, double* cos_lat,
+                       double* lng_deg) {
+  double sl0, cl0;
+  sincos_f64(lat0_deg * (kPiD / 180.0), &sl0, &cl0);
+  const double d = sqrt(x * x + y * y);
+  double cos_h = 1.0, sin_h = 0.0;
+  if (d > 0.0) { cos_h = y / d; sin_h = x / d; }
+  double sa, ca;
+  sincos_f64(d / 6371000.0, &sa, &ca);
+  const double sl = ca * sl0 + sa * cl0 * cos_h;
+  const double yy = sa * cl0 * sin_h, xx = ca - sl0 * sl;
+  // d_lng = atan2(yy, xx): |d_lng| < 0.2 rad here, xx > 0 -> asin of the normalised sine
+  const double d_lng = d_asin(yy / sqrt(xx * xx + yy * yy));
+  *sin_lat = sl; *cos_lat = sqrt(1.0 - sl * sl);
+  *lng_deg = lng0_deg + d_lng * (180.0 / kPiD);
+}
+
 constexpr float kSinMinSolarEl = -0.07396924496f;  // sin(-4.242 deg), solar.py:38
 
-// solar_atmospheric_attenuation (solar.py:177-209) from sin(el).  Branch-free.  The
-// reference's pressure range check (:194-197) is done by the caller once per agent step.
-BLE_FN float solar_attenuation(float sin_el, float pressure) {
+// The solar thresholds of the transition: day / night and the attenuation cut-off at
+// MIN_SOLAR_EL_DEG = -4.242 deg (solar.py:38,199-200; balloon.py:524) and the two panel-shadow
+// elevations (solar.py:212-236).  The fast path decides them on the fp32 sin(el) (floor ~1e-7,
+// i.e. ~6e-6 deg); a stride whose sin(el) -- or whose uncorrected sin(el), for the 5 deg branch
+// point of the refraction formula, solar.py:143-155 -- is within kSunBand of a threshold is
+// re-decided on the reference's own fp64 chain (sun_exact), so a threshold never flips a
+// stride early or late (it did, ~2 strides per 10^6 env-steps: 0.07 K, 1.3 Wh steps).
+constexpr float kSinShadow33 = 0.61205375195f;   // sin(37.738149 deg): panels 3.3 m below the envelope
+constexpr float kSinShadow27 = 0.56489306688f;   // sin(34.394865 deg): panels 2.7 m below
+constexpr float kSin5 = 0.08715574443f;
+constexpr float kSunBand = 1.0e-6f;
+struct SunState { float sin_el, cos_el; bool day, sh33, sh27; };
+BLE_FN SunState sun_fast(float oms, bool* near) {
+  const SunSC unc = sun_from_one_minus_sin(oms);
+  const SunSC cor = sun_refract(unc);
+  SunState r;
+  r.sin_el = cor.sin_el; r.cos_el = cor.cos_el;
+  r.day = cor.sin_el > kSinMinSolarEl;
+  r.sh33 = cor.sin_el >= kSinShadow33;
+  r.sh27 = cor.sin_el >= kSinShadow27;
+  *near = (fabsf(cor.sin_el - kSinMinSolarEl) < kSunBand) | (fabsf(cor.sin_el - kSinShadow33) < kSunBand) |
+          (fabsf(cor.sin_el - kSinShadow27) < kSunBand) | (fabsf(unc.sin_el - kSin5) < kSunBand);
+  return r;
+}
+// solar.solar_calculator on BalloonState.latlng in fp64 (the oracle's chain op for op), cold.
+BLE_FN SunState sun_exact(double lat0_deg, double lng0_deg, double x, double y, int64_t unix_s) {
+  double sl, cl, lng;
+  latlng_f64(lat0_deg, lng0_deg, x, y, &sl, &cl, &lng);
+  const double el = solar_elevation_f64(sl, cl, lng, unix_s, nullptr);
+  double se, ce;
+  sincos_f64(el * (kPiD / 180.0), &se, &ce);
+  SunState r;
+  r.sin_el = (float)se; r.cos_el = (float)ce;
+  r.day = el > -4.242;
+  r.sh33 = el >= 37.738149050524044;
+  r.sh27 = el >= 34.39486500086289;
+  return r;
+}
+
+// solar_atmospheric_attenuation (solar.py:177-209) from sin(el); 0 at night (`day` false).
+// The reference's pressure range check (:194-197) is done by the caller once per agent step.
+BLE_FN float solar_attenuation(float sin_el, float pressure, bool day) {
   const float t = 614.0f * sin_el;
   const float root = f_sqrt(f_fma(t, t, 1229.0f));
   // sqrt(1229 + t^2) - t, written without cancellation for t > 0
   const float diff = t > 0.0f ? 1229.0f * f_rcp(root + t) : root - t;
   const float airmass = 0.34764f * (pressure * (1.0f / 101325.0f)) * diff;
   const float att = 0.5f * (f_exp(-0.65f * airmass) + f_exp(-0.95f * airmass));
-  return sin_el < kSinMinSolarEl ? 0.0f : att;
+  return day ? att : 0.0f;
 }
 // solar_power (solar.py:515-536) with balloon_shadow (:212-236) folded in.
-BLE_FN float solar_power(float sin_el, float cos_el, float attenuation) {
+BLE_FN float solar_power(const SunState& sun, float attenuation) {
   const float kCos35 = 0.81915204429f, kSin35 = 0.57357643635f;
   const float kCos65 = 0.42261826174f, kSin65 = 0.90630778704f;
-  // shadow_el = degrees(atan2(sqrt(h (10.41603 + h)), 8.69275)), h = 3.3 / 2.7
-  const float kSinShadow33 = 0.61205375195f;  // sin(37.738149 deg)
-  const float kSinShadow27 = 0.56489306688f;  // sin(34.394865 deg)
-  float sh33 = sin_el >= kSinShadow33 ? 0.4392f : 1.0f;
-  float sh27 = sin_el >= kSinShadow27 ? 0.4392f : 1.0f;
-  float c35 = f_fma(cos_el, kCos35, sin_el * kSin35);
-  float c65 = f_fma(cos_el, kCos65, sin_el * kSin65);
+  float sh33 = sun.sh33 ? 0.4392f : 1.0f;
+  float sh27 = sun.sh27 ? 0.4392f : 1.0f;
+  float c35 = f_fma(sun.cos_el, kCos35, sun.sin_el * kSin35);
+  float c65 = f_fma(sun.cos_el, kCos65, sun.sin_el * kSin65);
   return 210.0f * attenuation * f_fma(4.0f * c35, sh33, 2.0f * c65 * sh27);
 }
 
 // ---------------------------------------------------------------- thermal
 // thermal.py:52-230.
-constexpr float kStefanBoltzmann = 0.000000056704f;
-BLE_FN float absorptivity_ir(float t) { return f_fma(0.000232f, t - 210.0f, 0.04587f); }
-BLE_FN float total_absorptivity(float a, uint32_t* flags) {   // reflectivity 0.0291
-  float f = a * f_fma(1.0f - a - 0.0291f, 1.0f / (1.0f - 0.0291f), 1.0f);
-  *flags |= (f < 0.0f || f > 1.0f) ? kFlagAbsorptivity : 0u;
-  return f;
-}
 constexpr float kSolarAbsorptivityTotal =
     0.01435f * (1.0f + (1.0f - 0.01435f - 0.0291f) / (1.0f - 0.0291f));
-// Earth-IR heat per unit balloon area (thermal.py:209-213): constant over an episode.
-BLE_FN float earth_heat_per_area(float upwelling_ir, uint32_t* flags) {
-  float t_bb = f_sqrt(f_sqrt(upwelling_ir * (1.0f / kStefanBoltzmann)));
-  return upwelling_ir * 0.4605f * total_absorptivity(absorptivity_ir(t_bb), flags);
+// a^(-1/4) and a^(-1/10) for a > 0 (fp32-representable): fp32 hardware seed (~2e-7) + one
+// Newton step of y <- y (n + 1 - a y^n) / n, quadratic: ~1e-13 relative.  No fp64 division,
+// no libm.  Used by the fp64 convection model below.
+BLE_FN double d_inv_root4(double a) {
+  const double y = (double)f_sqrt(f_rsqrt((float)a));
+  const double y2 = y * y;
+  return y * d_fma(-a * y2, y2, 5.0) * 0.25;
 }
-// d_balloon_temperature_dt (thermal.py:175-230).  v23 = V^(2/3), v_m13 = V^(-1/3), p = ambient pressure.
-// One transcendental (rt = T_amb^-1/2) serves air density, viscosity and the 1/T of the Grashof
-// number: rho / mu = p (M/R) (T + 110.4) rt^5 / 1.458e-6; radius = c V^(1/3) = c v23 v_m13.
-BLE_FN float thermal_dtdt(float v23, float v_m13, float t_int, float t_amb, float p, float solar_flux_att,
-                          float q_earth_per_area, uint32_t* flags) {
-  const float kR2 = 0.38483473659f;         // (3 / (4 pi))^(2/3)
-  const float kR1 = 0.62035049090f;         // (3 / (4 pi))^(1/3)
-  float r2 = kR2 * v23;                     // radius^2
-  float dia = (2.0f * kR1) * (v23 * v_m13);
-  float inv_dia = (0.5f / kR1) * v_m13;
-  float area = 4.0f * kPi * r2;
-  float q_solar = solar_flux_att * 0.25f * kSolarAbsorptivityTotal;           // per area
-  float t2 = t_int * t_int;
-  float q_emit = kStefanBoltzmann * t2 * t2 * total_absorptivity(absorptivity_ir(t_int), flags);
-  // convective_heat_air_factor (thermal.py:150-172)
-  float rt = f_rsqrt(t_amb), rt2 = rt * rt;
-  float rv = (kAirMolarOverR / 1.458e-6f) * p * (t_amb + 110.4f) * (rt2 * rt2 * rt);      // rho / viscosity
-  float conductivity = 0.0241f * f_pow(t_amb * (1.0f / 273.15f), 0.9f);
-  float prandtl = f_fma(-3.25e-4f, t_amb, 0.804f);
-  float dt = t_amb - t_int;
-  float grashof = 9.80665f * rv * rv * (dia * dia * dia) * rt2 * fabsf(dt);
-  float rayleigh = prandtl * grashof;
-  float nusselt = 2.0f + 0.457f * f_sqrt(f_sqrt(rayleigh)) + f_pow(f_fma(2.69e-8f, rayleigh, 1.0f), 1.0f / 12.0f);
-  float q_conv = nusselt * conductivity * inv_dia * dt;                       // per area
-  return area * (q_solar + q_earth_per_area + q_conv - q_emit) * (1.0f / (1500.0f * kEnvelopeMass));
+BLE_FN double d_inv_root10(double a) {
+  const double y = (double)f_exp2(-0.1f * f_log2((float)a));
+  const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
+  return y * d_fma(-a * y5, y5, 11.0) * 0.1;
+}
+// Increment of the internal temperature over one 10 s stride, fp64:
+//   10 s * d_balloon_temperature_dt(V, 68.5, T_int, T_amb, p, el, flux, IR)     (thermal.py:175-230,
+//   convective_heat_air_factor :150-172).
+// The four heat flows (each ~10 W/m^2 x ~700 m^2) nearly cancel, and the result feeds the
+// buoyancy difference rho V - m whose map amplifies errors (ble_step_core.h): an fp32 evaluation
+// (~1e-6 W/m^2 absolute) put 1 env-step in 10^4 beyond the 1e-5 parity bar; evaluated in fp64
+// none are left.  Formulated without pow / division:
+//   yc = V^(-1/3) (caller; Newton-refined)  ->  V^(2/3) = V yc,  1/(2 r) = yc / (2 k1),  (2 r)^3 = 6 V / pi
+//   rt = T_amb^(-1/2)                       ->  rho / mu = p (M/R) (T + 110.4) rt^5 / 1.458e-6,  1/T = rt^2
+//   Ra^(1/4) = Ra (Ra^(-1/4))^3,  (T/273.15)^0.9 = T T^(-1/10) / 273.15^0.9
+// Only (1 + 2.69e-8 Ra)^(1/12) -- a term of ~2 next to 0.457 Ra^(1/4) ~ 300 -- stays an fp32 pow.
+// q_solar_area = flux * attenuation * 0.25 * absorptivity [W/m^2] (fp32: the solar geometry's own
+// floor), q_earth_area = earth_heat_per_area(IR) (per-episode constant).
+constexpr double kStefanBoltzmannD = 0.000000056704;
+BLE_FN double total_absorptivity_d(double a) { return a * d_fma(-a, 1.0 / (1.0 - 0.0291), 2.0); }   // a (1 + (1-a-r)/(1-r))
+BLE_FN double earth_heat_per_area_f64(double upwelling_ir, uint32_t* flags) {   // thermal.py:209-213
+  const double t_bb = d_sqrt(d_sqrt(upwelling_ir * (1.0 / kStefanBoltzmannD)));
+  const double f = total_absorptivity_d(d_fma(0.000232, t_bb - 210.0, 0.04587));
+  *flags |= (f < 0.0 || f > 1.0) ? kFlagAbsorptivity : 0u;
+  return upwelling_ir * 0.4605 * f;
+}
+BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double t_amb, double p, float q_solar_area,
+                                    double q_earth_area) {
+  constexpr double kR2 = 0.38483473658887897;          // (3 / (4 pi))^(2/3)
+  constexpr double kR1 = 0.62035049089940009;          // (3 / (4 pi))^(1/3)
+  const double v23 = vol * yc;
+  // emitted (thermal.py:214-217)
+  const double t2 = t_int * t_int;
+  const double q_emit = (kStefanBoltzmannD * (t2 * t2)) * total_absorptivity_d(d_fma(0.000232, t_int, 0.04587 - 0.000232 * 210.0));
+  // convection
+  const double rt = d_rsqrt(t_amb), rt2 = rt * rt, rt4 = rt2 * rt2;
+  const double rv = (p * (t_amb + 110.4)) * (rt4 * rt);                                   // x M/(R 1.458e-6) folded below
+  const double dt = t_amb - t_int;
+  constexpr double kGr = 9.80665 * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (6.0 / kPiD);
+  const double prandtl = d_fma(-3.25e-4, t_amb, 0.804);
+  double ra = (prandtl * kGr) * ((rv * rv) * (vol * rt2)) * __builtin_fabs(dt);
+  ra = d_max(ra, 1e-30);
+  const double y4 = d_inv_root4(ra);
+  const double ra14 = (ra * y4) * (y4 * y4);
+  const double tw = (double)f_pow((float)d_fma(2.69e-8, ra, 1.0), 1.0f / 12.0f);
+  const double nusselt = d_fma(0.457, ra14, 2.0 + tw);
+  constexpr double kCond = 0.0241 * 0.006415624181362592;   // 0.0241 / 273.15^0.9
+  const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb)) * yc)) * dt;
+  const double q = ((double)q_solar_area + q_earth_area) + (q_conv - q_emit);
+  return (q * v23) * (10.0 * 4.0 * kPiD * kR2 / (1500.0 * 68.5));
 }
 
 // ---------------------------------------------------------------- envelope
@@ -874,14 +1038,6 @@ BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, do
 
 // ---------------------------------------------------------------- ACS
 // acs.py:24-68.  prm1 = pressure_ratio - 1.
-BLE_FN float acs_power(float prm1) {
-  // interp1d([1.0,1.05,1.2,1.25,1.35] -> [100,100,300,400,400], extrapolate): flat end
-  // segments; branch-free as a clamp of the two ramps
-  const float seg1 = f_fma(prm1 - 0.05f, 200.0f / 0.15f, 100.0f);    // 1.05 .. 1.2
-  const float seg2 = f_fma(prm1 - 0.2f, 100.0f / 0.05f, 300.0f);     // 1.2 .. 1.25
-  const float w = prm1 <= 0.2f ? seg1 : seg2;
-  return f_clamp(w, 100.0f, 400.0f);
-}
 // Fan-efficiency table acs.py:31-41, rows = power 100/200/300/400 W, columns = pressure
 // ratio 1.05 .. 1.35 step 0.025.  `tab` points at 4 x 13 floats (LDS copy in the kernel).
 #if BLE_DEVICE_BUILD
@@ -894,16 +1050,23 @@ const float kAcsEfficiency[4 * 13] = {
     0.4f, 0.3f, 0.3f, 0.30f, 0.25f, 0.23f, 0.20f, 0.15f, 0.12f, 0.10f, 0.0f, 0.0f, 0.0f,
     0.0f, 0.3f, 0.25f, 0.25f, 0.25f, 0.20f, 0.20f, 0.20f, 0.2f, 0.15f, 0.13f, 0.12f, 0.11f,
     0.0f, 0.23f, 0.23f, 0.23f, 0.23f, 0.23f, 0.20f, 0.20f, 0.20f, 0.18f, 0.16f, 0.15f, 0.13f};
-BLE_FN float acs_efficiency(const float* tab, float prm1, float power) {
-  float fx = f_clamp((prm1 - 0.05f) * 40.0f, 0.0f, 12.0f);     // 13 nodes, step 0.025
-  float fy = f_clamp((power - 100.0f) * 0.01f, 0.0f, 3.0f);    // 4 nodes, step 100 W
+// fp64 versions for the transition (the mass flow feeds rho V - m); table entries are exact in fp32
+BLE_FN double acs_power_f64(double prm1) {
+  const double seg1 = d_fma(prm1 - 0.05, 200.0 / 0.15, 100.0);
+  const double seg2 = d_fma(prm1 - 0.2, 100.0 / 0.05, 300.0);
+  const double w = prm1 <= 0.2 ? seg1 : seg2;
+  return d_max(d_min(w, 400.0), 100.0);
+}
+BLE_FN double acs_efficiency_f64(const float* tab, double prm1, double power) {
+  const double fx = d_max(d_min((prm1 - 0.05) * 40.0, 12.0), 0.0);
+  const double fy = d_max(d_min((power - 100.0) * 0.01, 3.0), 0.0);
   int ix = (int)fx; ix = ix > 11 ? 11 : ix;
   int iy = (int)fy; iy = iy > 2 ? 2 : iy;
-  float wx = fx - (float)ix, wy = fy - (float)iy;
+  const double wx = fx - (double)ix, wy = fy - (double)iy;
   const float* r0 = tab + iy * 13 + ix;
-  float z00 = r0[0], z01 = r0[1], z10 = r0[13], z11 = r0[14];
-  float lo = f_fma(wx, z01 - z00, z00), hi = f_fma(wx, z11 - z10, z10);
-  return f_fma(wy, hi - lo, lo);
+  const double z00 = (double)r0[0], z01 = (double)r0[1], z10 = (double)r0[13], z11 = (double)r0[14];
+  const double lo = d_fma(wx, z01 - z00, z00), hi = d_fma(wx, z11 - z10, z10);
+  return d_fma(wy, hi - lo, lo);
 }
 
 // power_table.lookup (power_table.py:21-38)

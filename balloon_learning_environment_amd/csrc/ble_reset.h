@@ -18,108 +18,8 @@
 
 namespace ble {
 
-// ---------------------------------------------------------------- fp64 asin (fdlibm e_asin.c rational form)
-BLE_FN double d_asin(double x) {
-  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
-               pio4_hi = 7.85398163397448278999e-01;
-  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
-               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
-               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
-               qS4 = 7.70381505559019352791e-02;
-  const double ax = fabs(x);
-  if (ax < 0.5) {
-    const double t = x * x;
-    const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
-    const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-    return x + x * (p / q);
-  }
-  const double w = 1.0 - ax;
-  const double t = w * 0.5;
-  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
-  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-  const double s = sqrt(t);
-  const double r = p / q;
-  double res;
-  if (ax >= 0.975) {
-    res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
-  } else {
-    // split s into a head with 32 zero low bits (fdlibm) to keep the subtraction exact
-    union { double d; uint64_t u; } cv;
-    cv.d = s; cv.u &= 0xffffffff00000000ULL;
-    const double df = cv.d;
-    const double c = (t - df * df) / (s + df);
-    const double pp = 2.0 * s * r - (pio2_lo - 2.0 * c);
-    const double qq = pio4_hi - 2.0 * df;
-    res = pio4_hi - (pp - qq);
-  }
-  return x > 0 ? res : -res;
-}
-
-// ---------------------------------------------------------------- full fp64 solar calculator
-// solar.solar_calculator (solar.py:43-174): elevation [deg] (refraction corrected) and flux.
-BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
-  int64_t days = unix_s / 86400;
-  int64_t sod = unix_s - days * 86400;
-  if (sod < 0) { sod += 86400; days -= 1; }
-  const double frac = (double)sod / 86400.0;
-  const double jc = (((2440587.5 + (double)days) + frac) - 2451545.0) / 36525.0;
-  const double d2r = kPiD / 180.0;
-  const double l0 = d2r * (280.46646 + jc * (36000.76983 + jc * 0.0003032));
-  double s2l, c2l;
-  sincos_f64(2.0 * l0, &s2l, &c2l);
-  const double s4l = 2.0 * s2l * c2l;
-  const double m0 = d2r * (357.52911 + jc * (35999.05029 - 0.0001537 * jc));
-  double sm, cm;
-  sincos_f64(m0, &sm, &cm);
-  const double s2m = 2.0 * sm * cm, s3m = sm * (3.0 - 4.0 * sm * sm);
-  const double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
-  double so, co;
-  sincos_f64(d2r * (125.04 - 1934.136 * jc), &so, &co);
-  const double obl = mean_obl + d2r * (0.00256 * co);
-  double sobl, cobl;
-  sincos_f64(obl, &sobl, &cobl);
-  const double th = sobl / (1.0 + cobl), var_y = th * th;
-  const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
-  const double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
-                            1.25 * ecc * ecc * s2m);
-  // cos(hour_angle) = -cos(radians(1440 frac + degrees(eot) + 4 lng) / 4)   (solar.py:113-120)
-  double sh, ch;
-  sincos_f64(d2r * (360.0 * frac + 0.25 * (eot * (180.0 / kPiD)) + lng_deg), &sh, &ch);
-  const double eoc = d2r * (sm * (1.914602 - jc * (0.004817 + 0.000014 * jc)) + s2m * (0.019993 - 0.000101 * jc) + s3m * 0.000289);
-  double sa, ca;
-  sincos_f64(l0 + eoc - d2r * (0.00569 - 0.00478 * so), &sa, &ca);
-  const double sin_decl = sobl * sa;
-  const double cos_decl = sqrt(1.0 - sin_decl * sin_decl);
-  double s = sin_lat * sin_decl - cos_lat * cos_decl * ch;
-  s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
-  const double el = d_asin(s) * (180.0 / kPiD);      // 90 - degrees(acos(s))
-  const double c = sqrt(1.0 - s * s);
-  double refr;
-  if (el > 85.0) refr = 0.0;
-  else if (el > 5.0) { const double t = s / c; refr = 58.1 / t - 0.07 / (t * t * t) + 0.000086 / (t * t * t * t * t); }
-  else if (el > -0.575) refr = 1735.0 + el * (-518.2 + el * (103.4 + el * (-12.79 + el * 0.711)));
-  else refr = -20.772 / (s / c);
-  if (flux_out) { const double r = (1 + ecc) / (1 - ecc); *flux_out = 1366.0 * (1 + 0.5 * (r * r - 1) * cm); }
-  return el + refr / 3600.0;
-}
-
-// BalloonState.latlng (spherical_geometry.py:44-76) as (sin lat, cos lat, lng [deg]) in fp64.
-BLE_FN void latlng_f64(double lat0_deg, double lng0_deg, double x, double y, double* sin_lat, double* cos_lat,
-                       double* lng_deg) {
-  double sl0, cl0;
-  sincos_f64(lat0_deg * (kPiD / 180.0), &sl0, &cl0);
-  const double d = sqrt(x * x + y * y);
-  double cos_h = 1.0, sin_h = 0.0;
-  if (d > 0.0) { cos_h = y / d; sin_h = x / d; }
-  double sa, ca;
-  sincos_f64(d / 6371000.0, &sa, &ca);
-  const double sl = ca * sl0 + sa * cl0 * cos_h;
-  const double yy = sa * cl0 * sin_h, xx = ca - sl0 * sl;
-  // d_lng = atan2(yy, xx): |d_lng| < 0.2 rad here, xx > 0 -> asin of the normalised sine
-  const double d_lng = d_asin(yy / sqrt(xx * xx + yy * yy));
-  *sin_lat = sl; *cos_lat = sqrt(1.0 - sl * sl);
-  *lng_deg = lng0_deg + d_lng * (180.0 / kPiD);
-}
+// d_asin, solar_elevation_f64 and latlng_f64 (the full fp64 solar calculator) live in ble_physics.h: the
+// transition kernel uses them too, on the rare strides where a solar threshold is within its fp32 floor.
 
 // ---------------------------------------------------------------- sunrise / sunset search
 struct SunSite { double sin_lat, cos_lat, lng_deg; };

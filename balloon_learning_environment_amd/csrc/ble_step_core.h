@@ -83,8 +83,11 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &sl0, &cl0);
     const double x0 = (double)s.x, y0 = (double)s.y;
     const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-    const double sd0 = (double)e0.sin_decl, cd0 = (double)e0.cos_decl;
-    const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = 0.5 * (double)(e0.cos_decl_rate * step_s);
+    // (sin, cos) of the declination as an exactly normalised fp64 pair: with the fp32 pair
+    // (|sd^2 + cd^2 - 1| ~ 6e-8) the error of 1 - sin(el) near the zenith (el > 89.8 deg, 1 - sin(el)
+    // < 1e-6) was ~10 % and cos(el) -- hence the panel power -- was off by 2e-5
+    const double sd0 = (double)e0.sin_decl, cd0 = d_sqrt_fast(d_fma(-sd0, sd0, 1.0));
+    const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = -(sd0 * d_rcp(cd0)) * hsd;
     const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, sb0, cb0, sd0, cd0);
     const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, sb1, cb1, sd0 + hsd, cd0 + hcd);
     const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, sb2, cb2, sd0 + 2.0 * hsd, cd0 + 2.0 * hcd);
@@ -93,7 +96,25 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
     oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
   }
-  const float q_earth = earth_heat_per_area(c.ir, flags);
+  // Sun at stride k of this step: quadratic through the three fp64 nodes, fp32; the reference's
+  // own fp64 chain on the (rare) strides where a solar threshold is within the fp32 floor.
+  // (everything the exact path reads -- s.x, s.y, u, v, s.t_elapsed, c -- is live across the loop anyway)
+  auto sun_at = [&](int kk) -> SunState {
+    const float fkk = (float)kk;
+    bool near;
+    SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
+    if (__builtin_expect(near, 0)) {
+      const double dk = 10.0 * (double)kk;
+      r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)s.x), d_fma(dk, (double)v, (double)s.y),
+                    c.start_unix + (int64_t)(s.t_elapsed + 10 * kk));
+    }
+    return r;
+  };
+  const double q_earth = earth_heat_per_area_f64((double)c.ir, flags);
+  // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature: the
+  // factor leaves [0, 1] only for T_int < 12.3 K; T_int moves < 1 K per step, so checking the
+  // step's first and last value is checking every stride
+  *flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
 
   // ---- fp64 carried chain
   double t_amb = (double)s.t_amb, t_int = (double)s.t_int, n_air = (double)s.n_air, vol = (double)s.vol,
@@ -105,36 +126,32 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   int k = 0;
 #pragma unroll 1
   for (; k < substeps; ++k) {
-    const float pf = (float)p, t_ambf = (float)t_amb, t_intf = (float)t_int, volf = (float)vol, spf = (float)sp;
+    const float pf = (float)p, volf = (float)vol;
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
     const float fk = (float)k;
-    const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
+    const SunState sun = sun_at(k);
     const float flux = f_fma(fk, dfl, fl0);
 
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
     // equilibrium d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error
     // in the increment itself is amplified past the parity bar within a few substeps.
-    const float lv = f_log2(volf);
-    const float v23 = f_exp2((2.0f / 3.0f) * lv);                           // V^(2/3), fp32 (thermal model)
     // rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
     const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
     const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
     const double dir = num >= 0.0 ? 1.0 : -1.0;
     // 1/drag = 4 V^(-2/3): V^(-1/3) by one Newton step  y <- y (4 - V y^3) / 3  from an fp32 seed
-    const float v_m13 = f_exp2((-1.0f / 3.0f) * lv);                        // V^(-1/3), fp32 (thermal model; seed below)
-    double yc = (double)v_m13;
+    double yc = (double)f_exp2((-1.0f / 3.0f) * f_log2(volf));              // fp32 seed
     yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
     // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
     const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * (dir * num) * rp * (yc * yc);
-    const double dh_dt = arg > 0.0 ? d_sqrt_fast(arg) : 0.0;
+    const double dh_dt = d_sqrt_fast(d_max(arg, 1e-30));                    // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
     const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, cur_hi, cur_lo, p, rp, dir, t_at_p);
     const double p_new = d_fma(inv_dh * dh_dt, 10.0, p);                    // dir * dir == 1
 
     // ---- step 3: temperatures (balloon.py:451-467)
-    const float att = solar_attenuation(sun.sin_el, pf);
-    const float dtdt = thermal_dtdt(v23, v_m13, t_intf, t_ambf, pf, flux * att, q_earth, flags);
-    const double t_int_new = t_int + (double)(dtdt * kStride);
+    const float att = solar_attenuation(sun.sin_el, pf, sun.day);
+    const double t_int_new = t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (flux * att) * (0.25f * kSolarAbsorptivityTotal), q_earth);
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
@@ -142,23 +159,28 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     if (sp_new > 2380.0) status = kBurst;
     if (sp_new <= 0.0) status = kZeroPressure;
 
-    // ---- step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane
+    // ---- step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the
+    // mass flow changes rho V - m by ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified
+    // like the thermal increment's.
+    double mdot_d;
     {
-      const float valve_area = (float)(kPiD * 0.04 * 0.04 / 4.0);
-      const float gas_density = (spf + pf) * kAirMolarOverR * f_rcp(t_intf);
-      const float mdot_up = -0.62f * valve_area * f_sqrt(2.0f * spf * gas_density);
-      const float prm1 = f_max(spf, 0.0f) * (float)rp;       // pressure_ratio - 1 (balloon.py:247-250)
-      const float w_down = acs_power(prm1);
-      const float mdot_down = acs_efficiency(acs_table, prm1, w_down) * w_down * (1.0f / 3600.0f);
-      acs_w = eff == kDown ? w_down : 0.0f;
-      mdot = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0f);
+      constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
+      // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
+      const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
+      const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
+      const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
+      const double w_down = acs_power_f64(prm1);
+      const double mdot_down = acs_efficiency_f64(acs_table, prm1, w_down) * w_down * (1.0 / 3600.0);
+      acs_w = eff == kDown ? (float)w_down : 0.0f;
+      mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
+      mdot = (float)mdot_d;
     }
-    double n_air_new = n_air + (double)(mdot * (float)(kStride / kAirMolarMassD));
-    n_air_new = n_air_new > 0.0 ? n_air_new : 0.0;
+    double n_air_new = d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air);
+    n_air_new = d_max(n_air_new, 0.0);
 
     // ---- step 6: power (balloon.py:524-542)
-    const bool is_day = sun.sin_el > kSinMinSolarEl;
-    charge = is_day ? solar_power(sun.sin_el, sun.cos_el, att) : 0.0f;
+    const bool is_day = sun.day;
+    charge = is_day ? solar_power(sun, att) : 0.0f;
     load = (is_day ? kDayLoad : kNightLoad) + acs_w;
     batt = f_clamp(f_fma(charge - load, kStride / 3600.0f, batt), 0.0f, kBatteryCapacity);
     if (batt <= 0.0f) status = kOutOfPower;
@@ -193,6 +215,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   s.acs_power = acs_w; s.mdot = mdot; s.charge = charge; s.load = load;
   s.t_elapsed += 10 * k;
   s.status = (uint8_t)status;
+  *flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
 
   // solar_atmospheric_attenuation's range check (solar.py:194-197); p moves < 3 kPa per step
   *flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
@@ -200,9 +223,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
   float r = reward_distance(s.x, s.y);
   if (action == kDown) {   // last_command is the RAW action (balloon.py:286)
-    const float fk = (float)k;
-    const SunSC sun = sun_refract(sun_from_one_minus_sin(f_fma(fk, f_fma(fk, oms_c2, oms_c1), oms_c0)));
-    const float pw = solar_power(sun.sin_el, sun.cos_el, solar_attenuation(sun.sin_el, s.p));
+    const SunState sun = sun_at(k);
+    const float pw = solar_power(sun, solar_attenuation(sun.sin_el, s.p, sun.day));
     const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
     if (!excess) {
       const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);

@@ -69,8 +69,12 @@ extern "C" void emul_solar_power(int64_t n, const float* el_deg, const float* p,
   for (int64_t i = 0; i < n; ++i) {
     double s, c; sincos_f64((double)el_deg[i] * (kPiD / 180.0), &s, &c);
     uint32_t fl = 0;
-    att[i] = solar_attenuation((float)s, p[i]);
-    power[i] = solar_power((float)s, (float)c, att[i]);
+    const double el = (double)el_deg[i];
+    SunState sun;
+    sun.sin_el = (float)s; sun.cos_el = (float)c;
+    sun.day = !(el < -4.242); sun.sh33 = el >= 37.738149050524044; sun.sh27 = el >= 34.39486500086289;
+    att[i] = solar_attenuation(sun.sin_el, p[i], sun.day);
+    power[i] = solar_power(sun, att[i]);
   }
 }
 

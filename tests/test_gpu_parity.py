@@ -236,7 +236,7 @@ def test_probe_solar_power_thermal_volume_acs(ble):
   _call(lib, 'ble_probe_thermal_f32', *[_dev(a, np.float32) for a in ins], out, fl,
         ins[0].size, None)
   ref, _ = oracle.thermal_dtdt(*[a.astype(np.float64) for a in ins])
-  np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-7)
+  np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-8)     # fp64 thermal model, fp32 attenuation input
 
   d = golden('f4_sp_volume')
   ins = [d[k].astype(np.float32) for k in ('mols_air', 't_int', 'pressure')]
@@ -253,9 +253,9 @@ def test_probe_solar_power_thermal_volume_acs(ble):
   _call(lib, 'ble_probe_acs_f32', _dev(pr, np.float32), power, eff, md,
         pr.size, None)
   po, eo, mo = oracle.acs(pr.astype(np.float64))
-  np.testing.assert_allclose(power.cpu().numpy(), po, rtol=2e-5)   # pr - 1 in fp32 near the 1.05 knot
-  np.testing.assert_allclose(eff.cpu().numpy(), eo, rtol=1e-4, atol=2e-6)
-  np.testing.assert_allclose(md.cpu().numpy(), mo, rtol=1e-4, atol=1e-7)
+  np.testing.assert_allclose(power.cpu().numpy(), po, rtol=1e-6)   # fp64 tables on the fp32 input ratio
+  np.testing.assert_allclose(eff.cpu().numpy(), eo, rtol=1e-6, atol=1e-7)
+  np.testing.assert_allclose(md.cpu().numpy(), mo, rtol=1e-6, atol=1e-9)
 
 
 def test_power_table_exact(ble):
@@ -321,11 +321,12 @@ def _sampled_batch_parity(ble, n, steps, seed, threads):
   """Free-running GPU batch from reset_host.sample_initial_state; every step is checked
   against the oracle started from the GPU's own pre-step state (identical inputs).
 
-  Discrete outputs must agree for EVERY environment.  Float state: the reference's vertical
-  dynamics have unbounded gain where rho*V - m crosses zero (d(dp) ~ d(diff) / sqrt|diff|,
-  DESIGN.md "conditioning"), so a handful of environments per 10^5 env-steps land beyond
-  1e-5 whatever the arithmetic; the bar here is >= 99.99 % of environments within 1e-5 on
-  every field and no environment beyond 5e-4.
+  Discrete outputs must agree for EVERY environment and every float field of EVERY environment
+  must be within 1e-5 (north star) -- no outlier budget.  The reference's vertical dynamics
+  amplify errors (d(dp) ~ d(rho V - m) / sqrt|rho V - m|; the fp64 reference
+  itself moves by up to 6e-3 under a 1-ulp perturbation of its fp32 inputs,
+  tests/test_reference_conditioning.py), which is why the whole vertical chain including the
+  thermal and ACS increments is fp64 in the kernel and the solar thresholds are re-decided in fp64.
   """
   from balloon_learning_environment_amd import reset_host
   init = reset_host.sample_initial_state(n, seed=seed)
@@ -407,21 +408,21 @@ def test_long_rollout_checkpoints_match_oracle(ble):
   sim.check_errors()
   print(f'long rollout: {total} checked env-steps, {outliers} beyond 1e-5, worst {worst:.2g}, max elapsed {max_elapsed / 3600:.1f} h')
   assert max_elapsed > 48 * 3600
-  assert outliers <= max(2, total // 5000) and worst < 5e-4
+  assert outliers == 0 and worst <= RTOL
 
 
 def test_config_4096_envs_random_policy(ble):
   """BASELINE.json configs[1]: 4 096 vectorised envs, random policy, one decoded wind field."""
   total, outliers, worst = _sampled_batch_parity(ble, 4096, steps=12, seed=41, threads=8)
   print(f'4096 envs: {total} env-steps, {outliers} beyond 1e-5, worst {worst:.2g}')
-  assert outliers <= max(1, total // 10000) and worst < 5e-4
+  assert outliers == 0 and worst <= RTOL
 
 
 def test_config_65536_envs_full_size(ble):
   """BASELINE.json configs[2] at full size: every environment of a 65 536 batch against the oracle."""
   total, outliers, worst = _sampled_batch_parity(ble, 65536, steps=3, seed=43, threads=32)
   print(f'65536 envs: {total} env-steps, {outliers} beyond 1e-5, worst {worst:.2g}')
-  assert outliers <= total // 10000 and worst < 5e-4
+  assert outliers == 0 and worst <= RTOL
 
 
 def test_full_size_properties_and_determinism(ble):
@@ -696,7 +697,7 @@ def test_ragged_batch_sizes(ble, n):
   from balloon_learning_environment_amd import reset_host
   total, outliers, worst = _sampled_batch_parity(ble, n, steps=3, seed=100 + n, threads=2)
   print(f'n={n}: {total} env-steps, worst {worst:.2g}')
-  assert outliers == 0 or worst < 5e-4
+  assert outliers == 0 and worst <= RTOL
   sim = ble.VecSimulator(n)
   sim.set_state(reset_host.sample_initial_state(n, seed=1))
   sim.set_grid(np.zeros((21, 21, 10, 9, 2), np.float32))
