@@ -1,25 +1,42 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the vectorised BLE transition on MI355X.
 
+  python bench.py                                   # N = 1, BASELINE.json configs[2] + every 1-GPU leg
   python bench.py --gpus 1 --steps 192 --warmup 32
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N --steps K --warmup W [--config 3|4]
 
-Workload (BASELINE.json configs[2], the headline config): 65 536 environments PER GPU,
-random policy, one decoded wind grid shared by all environments (synthetic N(0, 5^2) m/s
-float32 field, seed 0), initial conditions drawn like BalloonArena.reset
-(reset_host.sample_initial_state).  One "step" = one agent step (180 s = 18 x 10 s
-substeps + wind lookup + 3 safety layers + reward/terminal) of every environment of the
-rank; ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (the
-random policy's actions are known up front, so the state stays in registers between steps).  Weak scaling: per-GPU work is fixed; with N > 1 the
-grid is broadcast once over RCCL and rewards/terminals are gathered to rank 0 every 32
-steps on a side stream (inside the timed region).  Terminated environments are frozen by the kernel
-and are NOT counted: value = (sum over timed steps of live environments) / seconds.
+One "step" = one agent step (180 s = 18 x 10 s substeps + wind lookup + 3 safety layers +
+reward/terminal) of every environment of the rank.  The random policy's actions are known up front, so
+ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (state in registers).
+
+Presets (`--config i` = BASELINE.json configs[i]; the default, 2, is the headline):
+  1  4 096 envs, one decoded wind grid, 1 GPU
+  2  65 536 envs PER GPU, one decoded wind grid (weak scaling when N > 1: grid broadcast once over RCCL,
+     rewards/terminals gathered to rank 0 every 32 steps on a side stream, inside the timed region)
+  3  65 536 envs GLOBAL, sharded contiguously over the N ranks (strong scaling), same exchanges
+  4  32 768 envs per GPU (262 144 on 8), every env flies in its own forecast decoded on the device by the
+     VAE-decoder restatement (synthetic weights); no broadcast
+
+Timing (the driver's contract): W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks.  That K-step region is repeated `--reps` times
+(default 31) from the same post-warm-up state -- a single 20-step region is one 0.5 ms kernel launch, far too
+short for one sample -- and the MEDIAN repetition is the reported value (min / max / first beside it).
+Terminated environments are frozen by the kernel and are NOT counted.
+
+Besides `value`, the default run reports (rank 0; every leg is the same code path as the headline):
+  `configs`      env-steps/s of configs[1], [3]'s per-GPU shard (8 192 envs; the real sharded run when N > 1)
+                 and [4]'s per-GPU share (32 768 envs with per-env grids), and the single-env facade
+                 (configs[0]'s counterpart: BalloonEnv.step with the device observation)
+  `observe`      the closed-loop cost: step + wind noise + the 1099-feature observation (ble_observe_f32)
+                 with a full WindGP window, its own roofline and measured traffic
+  `cpu_baseline` the fp64 C oracle on this box's host cores (N = 1 only)
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,7 +45,12 @@ sys.path.insert(0, ROOT)
 
 ALGORITHMIC_BYTES_PER_ENV_STEP = 280      # 152 B state + 128 B grid gather
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6                   # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
 GATHER_EVERY = 32
+PRESETS = {1: 'configs[1]: 4 096 vectorised envs, random policy, one decoded wind field, 1xMI355X',
+           2: 'configs[2]: 65 536 vectorised envs per GPU, random policy, one decoded wind grid (headline)',
+           3: 'configs[3]: 65 536 envs sharded across the GPUs, wind field RCCL-broadcast, rewards/terminals gathered',
+           4: 'configs[4]: 32 768 envs per GPU (262 144 on 8), per-env forecasts decoded on the device (VAE path, synthetic weights)'}
 
 
 def cpu_baseline(state, actions, field, seconds_target=10.0):
@@ -90,28 +112,191 @@ def cpu_baseline(state, actions, field, seconds_target=10.0):
           'host_cpu_count': os.cpu_count(), 'affinity_threads': cores_seen, 'cgroup_cpu_quota': quota}
 
 
+class Rollout:
+  """One preset's workload on this rank: state + grid resident in HBM, `time_reps` runs the timed region."""
+
+  def __init__(self, n, device, rank, world, *, per_env_grids=False, shared_field=None, seed_base=1000,
+               steps=192, warmup=32, substeps=18):
+    import numpy as np
+    import torch
+    from balloon_learning_environment_amd import distributed as bdist
+    from balloon_learning_environment_amd import reset_host
+    from balloon_learning_environment_amd import vec_state
+    self.torch, self.bdist, self.np = torch, bdist, np
+    self.n, self.device, self.rank, self.world = n, device, rank, world
+    self.steps, self.warmup, self.substeps = steps, warmup, substeps
+    k_total = steps + warmup
+    # synthetic inputs (host, seeded; env i of the GLOBAL batch always gets the same draw), resident in HBM
+    self.host_state = reset_host.sample_initial_state(n, seed=seed_base + rank)
+    self.sim = vec_state.VecSimulator(n, device)
+    self.sim.set_state(self.host_state)
+    self.decode_ms = None
+    if per_env_grids:     # no broadcast at all: every rank decodes its own latents into per-env grids
+      from balloon_learning_environment_amd.env import generative_wind_field
+      sampler = generative_wind_field.GenerativeWindFieldSampler(device=device, seed=0)
+      latents = sampler.sample_latents(n, seed=100 + rank)
+      grids = torch.empty((n,) + tuple(vec_state.GRID_SHAPE), dtype=torch.float32, device=device)
+      sampler.decode(latents[:min(n, 256)], grids[:min(n, 256)]); torch.cuda.synchronize()
+      d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
+      d0.record(); sampler.decode(latents, grids); d1.record(); torch.cuda.synchronize()
+      self.decode_ms = d0.elapsed_time(d1)
+      self.sim.set_grid(grids, per_env=True)
+      del sampler, latents
+    else:
+      self.sim.set_grid(shared_field)
+    gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
+    self.actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
+    self.rewards = torch.zeros((k_total, n), dtype=torch.float32, device=device)
+    self.terminals = torch.zeros((k_total, n), dtype=torch.uint8, device=device)
+    self.gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world) if world > 1 else None
+    self.launches_per_region = -(-steps // GATHER_EVERY)
+
+  def run(self, k0, k1):
+    k = k0
+    while k < k1:
+      c = min(GATHER_EVERY, k1 - k)
+      self.sim.step_n(self.actions[k:k + c], self.rewards[k:k + c], self.terminals[k:k + c], None, substeps=self.substeps)
+      if self.gatherer is not None and c == GATHER_EVERY:
+        self.gatherer.gather(self.rewards[k:k + c], self.terminals[k:k + c])
+      k += c
+    if self.gatherer is not None:
+      self.gatherer.wait()
+
+  def time_reps(self, reps):
+    """Warm-up, snapshot, then `reps` x (restore snapshot; barrier+sync; K steps; sync+barrier).
+    Returns per-repetition lists: wall seconds (MAX over ranks), live env-steps (SUM over ranks), HIP-event ms."""
+    torch, dist_mod = self.torch, self.torch.distributed
+    barrier = (lambda: dist_mod.barrier()) if self.world > 1 else (lambda: None)
+    self.run(0, self.warmup)
+    torch.cuda.synchronize()
+    snap = {k: t.clone() for k, t in self.sim.state.items()}
+    live0 = float((self.sim.state['status'] == 0).sum().item())
+    wall, live, ev_ms = [], [], []
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    for _ in range(reps):
+      for k, t in self.sim.state.items():
+        t.copy_(snap[k])
+      torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      ev0.record()            # the kernels are launched on torch's current stream
+      self.run(self.warmup, self.warmup + self.steps)
+      ev1.record()
+      torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      wall.append(self.bdist.max_over_ranks(dt, self.device))
+      ev_ms.append(ev0.elapsed_time(ev1))
+      # an env is stepped iff it was not terminal after the previous step; counted outside the timed region
+      term = self.terminals[self.warmup:self.warmup + self.steps - 1].to(torch.int64).sum(dim=1)
+      l = live0 + float((self.n - term).sum().item())
+      live.append(self.bdist.sum_over_ranks(l, self.device))
+    self.sim.check_errors()
+    self.live_fraction_end = float((self.sim.state['status'] == 0).sum().item()) / max(1, self.n)
+    return wall, live, ev_ms
+
+  def summary(self, reps):
+    wall, live, ev_ms = self.time_reps(reps)
+    rates = [l / w for l, w in zip(live, wall)]
+    order = sorted(range(reps), key=lambda i: rates[i])
+    med = order[reps // 2]
+    ev_med = statistics.median(ev_ms)
+    return {'env_steps_per_s': rates[med], 'env_steps_per_s_min': min(rates), 'env_steps_per_s_max': max(rates),
+            'env_steps_per_s_first_repetition': rates[0], 'repetitions': reps, 'steps_per_repetition': self.steps,
+            'ms_per_step': 1e3 * wall[med] / self.steps, 'ms_per_step_min': 1e3 * min(wall) / self.steps,
+            'ms_per_step_max': 1e3 * max(wall) / self.steps,
+            'kernel_ms_median': ev_med / self.launches_per_region, 'kernel_ms_min': min(ev_ms) / self.launches_per_region,
+            'live_env_steps_per_repetition': live[med], 'envs_per_gpu': self.n, 'global_envs': int(round(self.bdist.sum_over_ranks(float(self.n), self.device))),
+            'live_env_fraction_end': self.live_fraction_end, 'decode_ms': self.decode_ms}
+
+
+def observe_leg(roll, pairs, world):
+  """step + wind noise + 1099-feature observation with a full WindGP window (closed-loop cost)."""
+  torch, bdist = roll.torch, roll.bdist
+  sim, n, device = roll.sim, roll.n, roll.device
+  k_total = roll.actions.shape[0]
+  sim.set_state(roll.host_state)                         # fresh episodes
+  obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
+  sim.reset_observation_history()
+  obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world) if world > 1 else None
+  fill = 121                                            # 6 h window = 120 observations; 121st call slides it
+  # forecast != truth: the additive wind noise (ble_wind_noise_f32) is evaluated at the balloons once
+  # per step -- it is both the next step's ground-truth term and this observation's error term
+  noise = sim.wind_noise(seed=1234)
+  for i in range(fill):
+    sim.step(roll.actions[i % k_total], noise)
+    sim.wind_noise(seed=1234, out=noise)
+    sim.observe(noise, out=obs)
+  torch.cuda.synchronize()
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+  t_obs, t_pair = [], []
+  for i in range(pairs):
+    e0.record(); sim.step(roll.actions[(fill + i) % k_total], noise); sim.wind_noise(seed=1234, out=noise)
+    e1.record(); sim.observe(noise, out=obs)
+    if obs_gatherer is not None:                         # "observations gathered back" (north star), 4 396 B/env
+      obs_gatherer.gather(obs); obs_gatherer.wait()
+    e2.record()
+    torch.cuda.synchronize()
+    t_obs.append(e1.elapsed_time(e2)); t_pair.append(e0.elapsed_time(e2))
+  sim.check_errors()
+  live = float((sim.state['status'] == 0).sum().item())
+  ms_obs, ms_pair = statistics.median(t_obs), statistics.median(t_pair)
+  # algorithmic work per env-observation (DESIGN.md 3b): 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles
+  # (two error vectors + the ~120 reachable levels) x 2 048 flop + ~0.6 MFLOP of fp64 VALU (factor slide,
+  # kernel evaluations); algorithmic bytes: 4 396 out + 2 x 58 080 factor in/out + 152 state + 3 072 ring
+  flop = 144 * 8 * 2048 + 0.6e6
+  traffic = None
+  try:
+    traffic = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('observe_hbm_bytes_per_launch')
+  except Exception:
+    pass
+  tf = n * flop / (ms_obs * 1e-3) / 1e12
+  return {'pairs': pairs, 'ms_per_observation_launch': ms_obs, 'ms_per_observation_launch_min': min(t_obs),
+          'ms_per_step_plus_observation': ms_pair,
+          'env_observations_per_s': n / (ms_obs * 1e-3), 'env_steps_per_s_with_observation': n / (ms_pair * 1e-3),
+          'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
+          'includes_gather_to_rank0': world > 1,
+          'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)',
+          'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS, 'achieved': tf, 'frac': tf / FP64_PEAK_TFLOPS,
+                       'traffic': traffic, 'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': 4396 + 2 * 58080 + 152 + 3072,
+                       'hbm_gbs_algorithmic': n * (4396 + 2 * 58080 + 152 + 3072) / (ms_obs * 1e-3) / 1e9}}
+
+
+def facade_leg(steps=150):
+  """BASELINE configs[0]'s counterpart on this framework: the single-env gym facade (BalloonEnv.step ->
+  ble_step_f32 + ble_observe_f32 on one environment, host-synchronous like the reference's API)."""
+  from balloon_learning_environment_amd.env import balloon_env
+  env = balloon_env.BalloonEnv(seed=0)
+  for i in range(20):
+    env.step(i % 3)
+  t = time.perf_counter()
+  for i in range(steps):
+    _, _, terminal, _ = env.step(i % 3)
+    if terminal:
+      env.reset()
+  dt = time.perf_counter() - t
+  return {'steps_per_s': steps / dt, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+          'what': 'BalloonEnv.step (single env, device observation, host-synchronous gym API)'}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=192)
   ap.add_argument('--warmup', type=int, default=32)
-  ap.add_argument('--envs-per-gpu', type=int, default=65536)
+  ap.add_argument('--config', type=int, default=2, choices=sorted(PRESETS), help='BASELINE.json configs[i] (see the module docstring)')
+  ap.add_argument('--reps', type=int, default=31, help='repetitions of the timed K-step region (median reported)')
+  ap.add_argument('--envs-per-gpu', type=int, default=None, help='override the preset size')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--active-count', action='store_true', help='analysis only: use the in-kernel live-env counter')
+  ap.add_argument('--no-extras', action='store_true', help='only the headline leg (profiling)')
   ap.add_argument('--substeps', type=int, default=18, help='analysis only: physics substeps per agent step (18 = the metric)')
-  ap.add_argument('--per-env-grids', action='store_true',
-                  help='BASELINE config 5 shape: every env flies in its own forecast, decoded on the device by the '
-                       'VAE-decoder restatement (synthetic weights); use with --envs-per-gpu 32768 (10.4 GB of grids)')
-  ap.add_argument('--observe', type=int, default=0, metavar='N',
-                  help='extra leg (not part of `value`): N timed step+observation pairs with the full 1099-feature '
-                       'Perciatelli observation (ble_observe_f32) after the WindGP window (120 observations) has filled')
+  ap.add_argument('--per-env-grids', action='store_true', help='same as --config 4 data layout at the chosen size')
+  ap.add_argument('--observe', type=int, default=8, metavar='N',
+                  help='timed step+observation pairs of the observation leg (0 = skip)')
   args = ap.parse_args()
 
   import numpy as np
   import torch
   import torch.distributed as dist
   from balloon_learning_environment_amd import distributed as bdist
-  from balloon_learning_environment_amd import reset_host
   from balloon_learning_environment_amd import vec_state
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,83 +314,33 @@ def main():
     else:
       dist.init_process_group(backend)
 
-  n = args.envs_per_gpu
-  k_total = args.steps + args.warmup
-  # ---- synthetic inputs (host, seeded), then resident in HBM before the timed region
-  state = reset_host.sample_initial_state(n, seed=1000 + rank)
-  sim = vec_state.VecSimulator(n, device)
-  sim.set_state(state)
+  # ---- the decoded wind grid: rank 0 owns it, everyone gets it by ONE broadcast (xGMI when world > 1)
   grid = torch.zeros(vec_state.GRID_SHAPE, dtype=torch.float32, device=device)
   field = None
   if rank == 0:
     field = (np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).astype(np.float32)
     grid.copy_(torch.from_numpy(field))
-  bdist.broadcast_grid(grid, src=0)                     # once per field, over xGMI when world > 1
-  decode_ms = None
-  if args.per_env_grids:
-    # config 5: no broadcast at all -- every rank decodes its own latents into per-env grids
-    from balloon_learning_environment_amd.env import generative_wind_field
-    sampler = generative_wind_field.GenerativeWindFieldSampler(device=device, seed=0)
-    latents = sampler.sample_latents(n, seed=100 + rank)
-    grids = torch.empty((n, 21, 21, 10, 9, 2), dtype=torch.float32, device=device)
-    sampler.decode(latents[:256], grids[:256]); torch.cuda.synchronize()
-    d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
-    d0.record(); sampler.decode(latents, grids); d1.record(); torch.cuda.synchronize()
-    decode_ms = d0.elapsed_time(d1)
-    sim.set_grid(grids, per_env=True)
-  else:
-    sim.set_grid(grid)
-  gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
-  actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
-  rewards = torch.zeros((k_total, n), dtype=torch.float32, device=device)
-  terminals = torch.zeros((k_total, n), dtype=torch.uint8, device=device)
-  active = torch.zeros((k_total, vec_state.COUNT_SLOTS), dtype=torch.int64, device=device)
-  gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world) if world > 1 else None
+  bdist.broadcast_grid(grid, src=0)
 
-  def run(k0, k1):
-    k = k0
-    while k < k1:
-      c = min(GATHER_EVERY, k1 - k)
-      sim.step_n(actions[k:k + c], rewards[k:k + c], terminals[k:k + c], active[k:k + c] if args.active_count else None, substeps=args.substeps)
-      if gatherer is not None and c == GATHER_EVERY:
-        gatherer.gather(rewards[k:k + c], terminals[k:k + c])
-      k += c
-    if gatherer is not None:
-      gatherer.wait()
+  def preset_size(cfg):
+    if cfg == 1: return 4096
+    if cfg == 2: return 65536
+    if cfg == 3:
+      lo, hi = bdist.shard_range(65536, rank, world)
+      return hi - lo
+    return 32768
 
-  run(0, args.warmup)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()            # the kernels are launched on torch's current stream
-  run(args.warmup, k_total)
-  ev1.record()
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  elapsed = bdist.max_over_ranks(elapsed, device)
-  sim.check_errors()
+  def make(cfg, n=None, steps=None, warmup=None):
+    n = n if n is not None else preset_size(cfg)
+    return Rollout(n, device, rank, world, per_env_grids=(cfg == 4 or args.per_env_grids), shared_field=grid,
+                   steps=steps or args.steps, warmup=args.warmup if warmup is None else warmup, substeps=args.substeps)
 
-  # live environments per step: an env is stepped iff it was not terminal after the previous
-  # step (terminated envs are frozen by the kernel); counted after the timed region
-  live_per_step = n - terminals[args.warmup - 1:k_total - 1].to(torch.int64).sum(dim=1) if args.warmup > 0 else None
-  if live_per_step is None:
-    live_per_step = torch.cat([torch.tensor([n], device=device), n - terminals[:k_total - 1].to(torch.int64).sum(dim=1)])
-  if args.active_count:
-    assert torch.equal(active[args.warmup:].sum(dim=1), live_per_step), 'in-kernel counter disagrees'
-  live_steps = float(live_per_step.sum().item())
-  live_steps_all = bdist.sum_over_ranks(live_steps, device)
-  value = live_steps_all / elapsed
-  # one launch of ble_step_kernel = up to GATHER_EVERY consecutive agent steps (state kept in registers)
-  n_launches = -(-args.steps // GATHER_EVERY)
-  kernel_ms = ev0.elapsed_time(ev1) / n_launches         # avg launch duration incl. inter-launch gaps
-  bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (live_steps / n_launches)
-  achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+  # ---- headline leg
+  head = make(args.config, n=args.envs_per_gpu)
+  hs = head.summary(args.reps)
+  n = head.n
+  bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (hs['live_env_steps_per_repetition'] / world / head.launches_per_region)
+  achieved = bytes_per_launch / (hs['kernel_ms_median'] * 1e-3) / 1e9
   traffic = None
   pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
   if os.path.exists(pmc_path):
@@ -213,89 +348,80 @@ def main():
       traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch')
     except Exception:
       traffic = None
-
-  # ---- optional leg: observation-inclusive stepping, reported beside `value`
-  observe_leg = None
-  if args.observe > 0:
-    sim.set_state(state)                                  # fresh episodes
-    obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
-    one = torch.zeros(n, dtype=torch.uint8, device=device)
-    sim.reset_observation_history()
-    obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world) if world > 1 else None
-    fill = 121                                            # 6 h window = 120 observations; 121st call slides it
-    # forecast != truth: the additive wind noise (ble_wind_noise_f32) is evaluated at the balloons once
-    # per step -- it is both the next step's ground-truth term and this observation's error term
-    noise = sim.wind_noise(seed=1234)
-    for i in range(fill):
-      sim.step(actions[i % k_total], noise)
-      sim.wind_noise(seed=1234, out=noise)
-      sim.observe(noise, out=obs)
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
-    t_obs = 0.0; t_pair = 0.0
-    for i in range(args.observe):
-      e0.record(); sim.step(actions[(fill + i) % k_total], noise); sim.wind_noise(seed=1234, out=noise)
-      e1.record(); sim.observe(noise, out=obs)
-      if obs_gatherer is not None:                         # "observations gathered back" (north star), 4 396 B/env
-        obs_gatherer.gather(obs); obs_gatherer.wait()
-      e2.record()
-      torch.cuda.synchronize()
-      t_obs += e1.elapsed_time(e2); t_pair += e0.elapsed_time(e2)
-    sim.check_errors()
-    live = float((sim.state['status'] == 0).sum().item())
-    observe_leg = {'pairs': args.observe, 'ms_per_observation_launch': t_obs / args.observe,
-                   'ms_per_step_plus_observation': t_pair / args.observe,
-                   'env_observations_per_s': n * args.observe / (t_obs * 1e-3),
-                   'env_steps_per_s_with_observation': n * args.observe / (t_pair * 1e-3),
-                   'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
-                   'includes_gather_to_rank0': world > 1,
-                   'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)',
-                   # 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles (two error vectors + the ~120 reachable
-                   # levels) x 2 048 flop + ~0.6 MFLOP of fp64 VALU (factor slide, kernel evaluations) per
-                   # environment; fp64 matrix and vector peaks are both 78.6 TFLOP/s
-                   'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 78.6,
-                                'achieved': n * (144 * 8 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12,
-                                'frac': n * (144 * 8 * 2048 + 0.6e6) / (t_obs / args.observe * 1e-3) / 1e12 / 78.6,
-                                'traffic': None, 'algorithmic_flop_per_env': 144 * 8 * 2048 + 0.6e6}}
-    del one
-
-  # what actually bounds the kernel (from the committed PMC summary of the same command, if present)
   issue = None
-  try:
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_summary.json')))['derived']
-    issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
-             'valu_insts_per_env_step': d['valu_insts_per_wave'] / 32.0, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / 32.0,
-             'source': 'profiles/r01_summary.json (rocprofv3 --pmc, per 32-step launch)'}
-  except Exception:
-    issue = None
+  for tag in ('r02', 'r01'):
+    try:
+      d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
+      per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)
+      issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
+               'valu_insts_per_env_step': d['valu_insts_per_wave'] / per, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / per,
+               'source': f'profiles/{tag}_summary.json (rocprofv3 --pmc, per {int(per)}-step launch)'}
+      break
+    except Exception:
+      continue
+
+  # ---- the other 1-GPU legs (same code path, fewer repetitions)
+  configs = {f'configs[{args.config}]': {k: hs[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step')}}
+  observe = None
+  if not args.no_extras:
+    extra_reps = max(5, min(11, args.reps))
+    if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
+      observe = observe_leg(head, args.observe, world)
+    del head
+    torch.cuda.empty_cache()
+    for cfg in (1, 2, 3, 4):
+      if cfg == args.config:
+        continue
+      if cfg in (1, 2) and world > 1:
+        continue                                         # single-GPU presets
+      size = None
+      if cfg == 3 and world == 1:
+        size = 8192                                      # one GPU's share of configs[3] on an 8-GPU node
+      r = make(cfg, n=size, steps=min(args.steps, 64))
+      s = r.summary(extra_reps)
+      key = f'configs[{cfg}]' + (' per-GPU shard (8 192 of 65 536), 1 GPU' if (cfg == 3 and world == 1) else '')
+      configs[key] = {k: s[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step', 'decode_ms')}
+      configs[key]['workload'] = PRESETS[cfg]
+      del r
+      torch.cuda.empty_cache()
+    if rank == 0:
+      try:
+        configs['configs[0] counterpart: single-env facade'] = facade_leg()
+      except Exception as e:            # the facade is not the measured product; never lose the line over it
+        configs['configs[0] counterpart: single-env facade'] = {'error': repr(e)}
 
   if rank == 0:
     out = {
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
-        'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32+f64', 'data': 'synthetic',
-        'config': {'workload': (f'{n} vectorised envs per GPU, random policy, per-env forecasts decoded on the device '
-                                '(BASELINE.json configs[4] shape: VAE path, synthetic weights)' if args.per_env_grids else
-                                f'{n} vectorised envs per GPU, random policy, one decoded wind grid '
-                                '(BASELINE.json configs[2]: 65 536 envs, 1xMI355X headline)'),
-                   'envs_per_gpu': n, 'global_envs': n * world, 'substeps_per_step': args.substeps,
-                   'live_env_fraction_end': float(live_per_step[-1].item()) / n,
-                   'per_env_grids': bool(args.per_env_grids), 'decode_ms': decode_ms,
-                   'parallelism': f'env-sharded x{world}, grid broadcast once, reward/terminal gather to rank 0 every {GATHER_EVERY} steps'},
+        'value': hs['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': hs['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong' if args.config == 3 else 'weak',
+        'vs_baseline': None, 'dtype': 'f64 vertical chain + f32 (state stored f32)', 'data': 'synthetic',
+        'config': {'workload': PRESETS[args.config] + (' [per-env grids]' if args.per_env_grids and args.config != 4 else ''),
+                   'preset': f'configs[{args.config}]', 'envs_per_gpu': n, 'global_envs': hs['global_envs'],
+                   'substeps_per_step': args.substeps, 'live_env_fraction_end': hs['live_env_fraction_end'],
+                   'per_env_grids': bool(args.config == 4 or args.per_env_grids), 'decode_ms': hs['decode_ms'],
+                   'parallelism': f'env-sharded x{world}, ' + ('no broadcast (per-rank decode)' if args.config == 4 else 'grid broadcast once') +
+                                  f', reward/terminal gather to rank 0 every {GATHER_EVERY} steps'},
+        'repetitions': {k: hs[k] for k in ('repetitions', 'steps_per_repetition', 'env_steps_per_s_min', 'env_steps_per_s_max',
+                                            'env_steps_per_s_first_repetition', 'ms_per_step_min', 'ms_per_step_max')},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'kernel': 'ble_step_kernel', 'kernel_ms': kernel_ms, 'agent_steps_per_launch': args.steps / n_launches,
-                     'kernel_us_per_agent_step': 1e3 * kernel_ms * n_launches / args.steps,
+                     'kernel': 'ble_step_kernel', 'kernel_ms': hs['kernel_ms_median'], 'kernel_ms_min': hs['kernel_ms_min'],
+                     'agent_steps_per_launch': args.steps / -(-args.steps // GATHER_EVERY),
+                     'kernel_us_per_agent_step': 1e3 * hs['kernel_ms_median'] * (-(-args.steps // GATHER_EVERY)) / args.steps,
                      'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
-                     'note': 'kernel is fp32/fp64-VALU and transcendental bound, not HBM bound (DESIGN.md)',
+                     'note': 'frac is the SURVEY 8(d) formal fraction (algorithmic bytes / time / peak); the measured HBM traffic '
+                             '(`traffic`, bytes per launch) is a few % of the algorithmic bytes because the state stays in registers for 32 '
+                             'steps and the grid gather is served by L2: the kernel is fp64/fp32 VALU-issue bound (DESIGN.md 3)',
                      'instruction_issue': issue},
+        'configs': configs,
     }
-    if observe_leg is not None:
-      out['observe'] = observe_leg
-    if world == 1 and not args.no_cpu_baseline:
-      acts = actions[:64].cpu().numpy()
-      out['cpu_baseline'] = cpu_baseline(state, list(acts), field)
+    if observe is not None:
+      out['observe'] = observe
+    if world == 1 and not args.no_cpu_baseline and not args.no_extras:
+      from balloon_learning_environment_amd import reset_host
+      acts = np.random.default_rng(7).integers(0, 3, (64, 65536)).astype(np.uint8)
+      out['cpu_baseline'] = cpu_baseline(reset_host.sample_initial_state(65536, seed=1000), list(acts), field)
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()

@@ -526,6 +526,79 @@ def f12_features_long():
   f11_features(n_env=1, n_steps=135, name='f12_features_long', rng_seed=12, keep_last=16)
 
 
+# ----------------------------------------------------------------------------- F13
+def f13_station_seeker_episode(n_steps=960):
+  """BASELINE.json configs[0] in closed loop: the reference's StationSeekerAgent
+  (agents/station_seeker_agent.py:72-86) picks every action from the reference's
+  PerciatelliFeatureConstructor output; the balloon flies BalloonArena.step's loop
+  (env/balloon_arena.py:184-202) for micro_eval's 960 steps (eval/suites.py:43): ground-truth
+  wind (forecast + noise) at the PRE-step state -> simulate_step -> observe with the ground truth at
+  the POST-step state.  The noise is a smooth function of the step index (opensimplex is absent).
+  Stored: every action, every state, the 1099-vector of every step (float32, as the reference
+  returns it), the agent's chosen level."""
+  from balloon_learning_environment.agents import station_seeker_agent
+  from balloon_learning_environment.env import features
+  rng = np.random.default_rng(13)
+  field = make_field(0)
+  wf = ref_shims.make_grid_wind_field(field)
+  s = dict(lat=float(rng.uniform(-10, 10)), lng=float(rng.uniform(-175, 175)), start=units.datetime(2013, 3, 25, 9, 25, 32),
+           pressure=float(rng.uniform(7000, 10500)), x=float(rng.uniform(-1.0e5, 1.0e5)), y=float(rng.uniform(-1.0e5, 1.0e5)),
+           ir=float(rng.uniform(230, 320)), alpha=float(rng.uniform(0, 1)), tweak=None)
+  atm = ref_shims.make_atmosphere(s['alpha'])
+  b = balloon.Balloon(build_state(s, atm))
+  su = int(s['start'].timestamp())
+  fc = features.PerciatelliFeatureConstructor(wf, atm)
+  agent = station_seeker_agent.StationSeekerAgent(3, (1099,))
+  feats = np.zeros((n_steps + 1, 1099), np.float32)
+  cols = {k: np.zeros((1, n_steps + 1)) for k in STATE_FLOATS}
+  for k in ('time_elapsed_s', 'sunrise_h', 'sunset'):
+    cols[k] = np.zeros((1, n_steps + 1), np.int64)
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused'):
+    cols[k] = np.zeros((1, n_steps + 1), np.uint8)
+  wind_truth = np.zeros((1, n_steps + 1, 2)); noise = np.zeros((1, n_steps + 1, 2))
+  actions = np.zeros((1, n_steps), np.uint8); levels = np.zeros(n_steps + 1, np.int32); reward = np.zeros((1, n_steps))
+  valid = np.zeros((1, n_steps), np.uint8)
+
+  def truth(i):
+    w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+    noise[0, i] = (1.5 * np.sin(0.3 * i), -1.0 * np.cos(0.17 * i) + 0.2)
+    wind_truth[0, i] = (w.u.mps + noise[0, i, 0], w.v.mps + noise[0, i, 1])
+    return wind_field.WindVector(units.Velocity(mps=float(wind_truth[0, i, 0])), units.Velocity(mps=float(wind_truth[0, i, 1])))
+
+  def observe(i):
+    fc.observe(simulator_data.SimulatorObservation(balloon_observation=b.state, wind_at_balloon=truth(i)))
+    feats[i] = fc.get_features()
+    snap = snapshot(b.state, su)
+    for k in SNAP_KEYS:
+      cols[k][0, i] = snap[k]
+
+  observe(0)
+  last = n_steps
+  for i in range(n_steps):
+    named = features.NamedPerciatelliFeatures(feats[i])
+    levels[i], _ = agent.find_best_pressure_level(named)
+    a = agent.pick_action(feats[i]); actions[0, i] = a
+    if b.state.status != balloon.BalloonStatus.OK:
+      last = i
+      break
+    valid[0, i] = 1
+    w = wind_field.WindVector(units.Velocity(mps=float(wind_truth[0, i, 0])), units.Velocity(mps=float(wind_truth[0, i, 1])))
+    b.simulate_step(w, atm, control.AltitudeControlCommand(int(a)), dt.timedelta(minutes=3))
+    reward[0, i] = balloon_env.perciatelli_reward_function(simulator_data.SimulatorState(b.state, None, atm))
+    observe(i + 1)
+  print(f'f13: flew {last} steps, final status {int(b.state.status.value) if hasattr(b.state.status, "value") else b.state.status}, '
+        f'actions {np.bincount(actions[0, :last], minlength=3)}, mean reward {reward[0, :last].mean():.3f}')
+  consts = dict(center_lat_deg=np.array([s['lat']]), center_lng_deg=np.array([s['lng']]),
+                upwelling_infrared=np.array([s['ir']]), alpha=np.array([s['alpha']]))
+  save('f13_station_seeker', field_seed=np.int64(0), field_scale=np.float64(5.0), features=feats[None], wind_measured=wind_truth,
+       noise_uv=noise, actions=actions, levels=levels, reward=reward, valid=valid, n_flown=np.int64(last),
+       start_unix=np.array([su], np.int64), **consts, **cols)
+
+
 if __name__ == '__main__':
-  f1_atmosphere(); f2_solar(); f3_thermal(); f4_sp_volume(); f5_acs_power_table(); f6_safety(); f7_wind()
-  f8_trajectories(); f9_arena(); f10_reset(); f11_features(); f12_features_long()
+  which = sys.argv[1:] or ['all']
+  if 'all' in which:
+    f1_atmosphere(); f2_solar(); f3_thermal(); f4_sp_volume(); f5_acs_power_table(); f6_safety(); f7_wind()
+    f8_trajectories(); f9_arena(); f10_reset(); f11_features(); f12_features_long()
+  if 'all' in which or 'f13' in which:
+    f13_station_seeker_episode()
