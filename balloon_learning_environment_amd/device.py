@@ -17,6 +17,8 @@ def require_gpu(device) -> torch.device:
   if device.type != 'cuda' or not torch.cuda.is_available():
     raise RuntimeError('balloon_learning_environment_amd needs a HIP device (torch device "cuda[:i]"); '
                        'there is no CPU path')
+  if device.index is None:
+    device = torch.device('cuda', torch.cuda.current_device())
   return device
 
 

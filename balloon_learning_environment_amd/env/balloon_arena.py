@@ -26,37 +26,109 @@ from balloon_learning_environment_amd.utils import constants
 from balloon_learning_environment_amd.utils import units
 
 
+def _mix_seed(seed: int, count: int) -> int:
+  """Seed of the `count`-th un-seeded reset after reset(seed) (splitmix64 finaliser; count 0 -> seed)."""
+  if count == 0:
+    return int(seed)
+  z = (int(seed) + 0x9E3779B97F4A7C15 * count) & (2 ** 64 - 1)
+  z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+  z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+  return int((z ^ (z >> 31)) % (2 ** 31))
+
+
 class VecBalloonArena:
-  """N independent arenas advanced together (one lane per arena)."""
+  """N independent arenas advanced together (one lane per arena).
+
+  Wind fields.  Default: the generative sampler (env/generative_wind_field.py; synthetic decoder
+  weights) like the reference's BalloonEnv.  `per_env_fields=False`: all N environments fly in ONE
+  field, resampled by every reset() -- reset(seed) uses `seed`, each later reset() without a seed
+  derives a new one from (seed, reset count); environments auto-reset in between (reset_terminated)
+  keep flying in that field.  `per_env_fields=True`: every environment has its own decoded grid
+  (N x 317.5 KB of HBM) and gets a NEW one for each new episode: reset() decodes all of them,
+  reset_terminated() marks the lanes and refresh_fields() re-decodes the marked ones (one host
+  synchronisation, so VecBalloonEnv calls it every `field_refresh_every` steps; until then a re-started
+  lane flies in its previous field)."""
 
   def __init__(self, num_envs: int, wind_field_instance: Optional[grid_based_wind_field.GridBasedWindField] = None,
-               seed: Optional[int] = None, device='cuda:0'):
+               seed: Optional[int] = None, device='cuda:0', per_env_fields: bool = False):
     self.num_envs = int(num_envs)
     self.sim = vec_state.VecSimulator(self.num_envs, device)
     self.device = self.sim.device
-    self.wind_field = wind_field_instance or grid_based_wind_field.GridBasedWindField(
-        grid_wind_field_sampler.GaussianFieldSampler(), device)
+    if wind_field_instance is None:
+      from balloon_learning_environment_amd.env import generative_wind_field
+      wind_field_instance = grid_based_wind_field.GridBasedWindField(
+          generative_wind_field.GenerativeWindFieldSampler(device=self.device), self.device)
+    self.wind_field = wind_field_instance
+    self.per_env_fields = bool(per_env_fields)
+    self._grids = None
+    self._stale = None
+    self._field_epoch = 0
     self._step_duration = constants.AGENT_TIME_STEP
+    self._seed0, self._reset_count = None, 0
     self.reset(seed)
 
   def reset(self, seed: Optional[int] = None, on_device: bool = True, upwelling_ir='reference') -> None:
     """New episodes for every env.  on_device=True: ble_reset_f32 (Philox streams on the GPU);
-    False: the NumPy host path (reset_host.py) -- same distributions, different streams."""
-    seed = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
+    False: the NumPy host path (reset_host.py) -- same distributions, different streams.
+    reset(seed) is reproducible: the same seed gives the same episodes and wind field(s), whatever
+    happened before (the reference's env.seed(s); env.reset() contract, eval/eval_lib.py)."""
+    if seed is not None:
+      self._seed0, self._reset_count = int(np.asarray(seed).ravel()[-1]), 0
+    elif self._seed0 is None:
+      self._seed0, self._reset_count = int(time.time() * 1e6) % (2 ** 31), 0
+    else:
+      self._reset_count += 1
+    seed = _mix_seed(self._seed0, self._reset_count)
     self._seed = seed
+    self.sim.episode.zero_()            # Philox streams are keyed by (seed, env, episode): restart the count
     if on_device:
       self.sim.reset_device(seed)
     else:
       self.sim.set_state(reset_host.sample_initial_state(self.num_envs, seed=seed, upwelling_ir=upwelling_ir))
     self.wind_field.reset(np.array([seed], np.uint32), None)
-    self.sim.set_grid(self.wind_field.grid)
+    self._field_epoch = 0
+    if self.per_env_fields:
+      self._decode_fields(None)
+    else:
+      self.sim.set_grid(self.wind_field.grid)
+
+  def _decode_fields(self, lanes: Optional[torch.Tensor]) -> None:
+    sampler = getattr(self.wind_field, '_wind_field_sampler', None)
+    assert hasattr(sampler, 'decode'), 'per_env_fields needs a sampler with a batched device decode()'
+    if self._grids is None:
+      self._grids = torch.empty((self.num_envs,) + tuple(vec_state.GRID_SHAPE), dtype=torch.float32, device=self.device)
+      self._stale = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+    count = self.num_envs if lanes is None else int(lanes.numel())
+    latents = sampler.sample_latents(count, _mix_seed(self._seed, 1 + self._field_epoch))
+    self._field_epoch += 1
+    if lanes is None:
+      sampler.decode(latents, self._grids)
+    else:
+      self._grids[lanes] = sampler.decode(latents)
+    self.sim.set_grid(self._grids, per_env=True)
+    self._stale.zero_()
+
+  def refresh_fields(self) -> int:
+    """per_env_fields: new wind fields for the lanes re-started since the last call.  Returns their number."""
+    if not self.per_env_fields or self._stale is None:
+      return 0
+    lanes = torch.nonzero(self._stale, as_tuple=False).flatten()      # host synchronisation
+    if lanes.numel():
+      self._decode_fields(lanes)
+    return int(lanes.numel())
 
   def reset_terminated(self) -> int:
-    """Auto-reset: starts a new episode (same wind field) in every env whose status != OK.
-    Returns the number of envs that were reset."""
+    """Auto-reset: starts a new episode in every env whose status != OK (shared field: the same
+    wind field; per_env_fields: a new one at the next refresh_fields()).  Returns the number reset."""
     mask = (self.sim.state['status'] != 0).to(torch.uint8)
-    self.sim.reset_device(self._seed, mask=mask)
+    self.reset_lanes(mask)
     return int(mask.sum().item())
+
+  def reset_lanes(self, mask: torch.Tensor) -> None:
+    """Masked auto-reset without a host round trip (mask: uint8 [N], != 0 -> new episode)."""
+    self.sim.reset_device(self._seed, mask=mask)
+    if self.per_env_fields and self._stale is not None:
+      torch.maximum(self._stale, mask, out=self._stale)
 
   def step(self, actions: torch.Tensor, noise_uv: Optional[torch.Tensor] = None):
     """actions: uint8 device tensor [N] -> (reward [N] f32, terminal [N] u8) device tensors."""
@@ -123,6 +195,7 @@ class BalloonArena(BalloonArenaInterface):
     self._vec.device = self._vec.sim.device
     self._vec.wind_field = wind_field_instance or grid_based_wind_field.GridBasedWindField(
         grid_wind_field_sampler.GaussianFieldSampler(), device)
+    self._vec.per_env_fields, self._vec._grids, self._vec._stale = False, None, None
     self._vec._step_duration = constants.AGENT_TIME_STEP
     self._wind_field = self._vec.wind_field
     self.last_reward = None
@@ -152,6 +225,7 @@ class BalloonArena(BalloonArenaInterface):
     self._vec.wind_field = self._wind_field
     seed_ = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
     self._vec._seed = seed_
+    self._vec.sim.episode.zero_()         # reset(seed) reproduces the same episode whatever happened before
     self._vec.sim.reset_device(seed_)
     self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
     self._bind_wind_field()

@@ -47,7 +47,7 @@ def gaussian_wind_field_factory(device='cuda:0'):
 
 class BalloonEnv:
   """Old-gym (0.21) 4-tuple API like the reference."""
-  metadata: Dict[str, Any] = {}
+  metadata: Dict[str, Any] = {'render.modes': []}
 
   def __init__(self, *, station_keeping_radius_km: float = 50.0,
                arena: Optional[balloon_arena.BalloonArenaInterface] = None,
@@ -61,6 +61,8 @@ class BalloonEnv:
     self._global_iteration = 0
     self.arena = arena if arena is not None else balloon_arena.BalloonArena(feature_constructor_factory, wind_field_factory())
     self._renderer = renderer
+    if renderer is not None:
+      self.metadata = {'render.modes': renderer.render_modes}       # env/balloon_env.py:150-152
     self.reset(seed=seed if seed is not None else int(time.time() * 1e6) % (2 ** 31))
 
   def step(self, action: int) -> Tuple[np.ndarray, float, bool, Mapping[str, Any]]:
@@ -82,6 +84,9 @@ class BalloonEnv:
       self.seed(seed)
     self._rng = np.random.Generator(np.random.Philox(self._rng.integers(0, 2 ** 31)))
     observation = self.arena.reset(int(self._rng.integers(0, 2 ** 31)))
+    if self._renderer is not None:                                  # env/balloon_env.py:216-218
+      self._renderer.reset()
+      self._renderer.step(self.arena.get_simulator_state())
     if return_info:
       return observation, self._get_info(self.get_simulator_state().balloon_state)
     return observation
@@ -135,44 +140,80 @@ class VecBalloonEnv:
     obs, reward, terminal = env.step(actions_u8)       # device tensors
   """
 
-  def __init__(self, num_envs: int, *, seed: int = 0, wind_field=None, wind_noise: bool = False,
-               auto_reset: bool = True, device='cuda:0'):
-    self.arena = balloon_arena.VecBalloonArena(num_envs, wind_field, seed=seed, device=device)
+  def __init__(self, num_envs: int, *, seed: int = 0, wind_field=None, wind_noise: bool = True,
+               auto_reset: bool = True, per_env_fields: bool = False, field_refresh_every: int = 32, device='cuda:0'):
+    """wind_noise=True (default, as the reference): ground truth = forecast + SimplexWindNoise, so the WindGP
+    has an error signal to model; False is the opt-out (forecast == truth, every GP error exactly 0).
+    Wind fields: see VecBalloonArena (default: generative sampler, one shared field per reset();
+    per_env_fields=True: one decoded field per environment and per episode)."""
+    self.arena = balloon_arena.VecBalloonArena(num_envs, wind_field, seed=seed, device=device, per_env_fields=per_env_fields)
     self.num_envs, self.device = self.arena.num_envs, self.arena.device
     self._seed, self._wind_noise, self._auto_reset = int(seed), bool(wind_noise), bool(auto_reset)
+    self._field_refresh_every, self._steps_since_refresh = int(field_refresh_every), 0
     self._noise = None
+    self._graph = None
+    self._reseed = True               # the first reset() replays the constructor's seed
 
   def _noise_now(self):
     if not self._wind_noise:
       return None
-    self._noise = self.arena.sim.wind_noise(self._seed, out=self._noise)
+    self._noise = self.arena.sim.wind_noise(self.arena._seed, out=self._noise)
     return self._noise
 
-  def reset(self):
-    self.arena.reset(self._seed)
+  def seed(self, seed: int) -> None:
+    self._seed = int(seed)
+    self._reseed = True
+
+  def reset(self, seed: Optional[int] = None):
+    """reset(seed) / seed(s); reset(): reproducible new episodes and wind field(s).  reset() without a
+    seed: the next episodes of the current seed (new initial conditions, new wind field(s))."""
+    if seed is not None:
+      self.seed(seed)
+    if getattr(self, '_reseed', False):
+      self.arena.reset(self._seed); self._reseed = False
+    else:
+      self.arena.reset()
+    self.check_errors()
     self._graph = None
+    self._steps_since_refresh = 0
     return self.arena.observe(self._noise_now())
 
+  def check_errors(self) -> None:
+    """Synchronises and raises what the reference would have raised inside step / observe since the last
+    call (non-finite state, pressure out of range, WindGP window overflow, failed pressure-range search...)."""
+    self.arena.sim.check_errors()
+
   def _step_eager(self, actions, obs_out=None):
-    reward, terminal = self.arena.step(actions, self._noise if self._wind_noise else None)
+    noise = None
+    if self._wind_noise:
+      noise = self._noise if self._noise is not None else self._noise_now()     # step() before reset()
+    reward, terminal = self.arena.step(actions, noise)
     if self._auto_reset:
       self._terminal_buf.copy_(terminal)
-      self.arena.sim.reset_device(self._seed, mask=self._terminal_buf)
+      self.arena.reset_lanes(self._terminal_buf)
     return self.arena.observe(self._noise_now(), out=obs_out), reward, terminal
 
   def step(self, actions):
     """actions: uint8 device tensor [N] in {0, 1, 2}.  Returns (obs [N, 1099], reward [N], terminal [N] u8);
     `terminal` refers to the transition just made; with auto_reset the returned observation of a
     terminated environment is the first one of its next episode.  With `capture_graph()` the three
-    tensors are static buffers that the next step overwrites."""
+    tensors are static buffers that the next step overwrites.  Error conditions are latched on the device:
+    call check_errors() (reset() does) to have them raised."""
     if not hasattr(self, '_terminal_buf'):
       self._terminal_buf = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
-    if getattr(self, '_graph', None) is not None:
+    if self._graph is not None:
       self._g_actions.copy_(actions)
       self._graph.replay()
-      return self._g_obs, self._g_reward, self._g_terminal
-    obs, reward, terminal = self._step_eager(actions)
-    return obs, reward.clone(), terminal.clone()
+      out = self._g_obs, self._g_reward, self._g_terminal
+    else:
+      obs, reward, terminal = self._step_eager(actions)
+      out = obs, reward.clone(), terminal.clone()
+    if self.arena.per_env_fields and self._auto_reset:
+      self._steps_since_refresh += 1
+      if self._steps_since_refresh >= self._field_refresh_every:
+        self._steps_since_refresh = 0
+        self.arena.refresh_fields()
+    return out
 
   def capture_graph(self):
     """Records one step (wind noise, transition, masked reset, observation: four kernels plus a few

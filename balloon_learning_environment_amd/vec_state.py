@@ -42,6 +42,20 @@ def raise_for_flags(flags: int) -> None:
     raise OverflowError('WindGP window holds more than 120 observations (agent steps shorter than 180 s)')
 
 
+def _on_own_device(method):
+  """Launches go to the stream of the simulator's OWN device: make it current for the call (a kernel
+  launched while another device is current would be enqueued with the wrong context)."""
+  import functools
+
+  @functools.wraps(method)
+  def wrapped(self, *args, **kwargs):
+    if torch.cuda.current_device() == self.device.index:
+      return method(self, *args, **kwargs)
+    with torch.cuda.device(self.device):
+      return method(self, *args, **kwargs)
+  return wrapped
+
+
 class VecSimulator:
   """N balloons on one GPU.  State tensors are exposed as attributes of `.state`."""
 
@@ -90,6 +104,7 @@ class VecSimulator:
     self.grid = g
 
   # ------------------------------------------------------------------ reset on the device
+  @_on_own_device
   def reset_device(self, seed: int, mask: Optional[torch.Tensor] = None, sample: bool = True) -> None:
     """BalloonArena.reset's balloon part for the envs with mask != 0 (all if None), on the GPU:
     draws (if `sample`), Newton cold start, sunrise/sunset search, fresh clocks and FSMs."""
@@ -106,6 +121,7 @@ class VecSimulator:
         torch.maximum(self._obs_reset, mask, out=self._obs_reset)
 
   # ------------------------------------------------------------------ observation
+  @_on_own_device
   def observe(self, noise_uv: Optional[torch.Tensor] = None, append: bool = True,
               out: Optional[torch.Tensor] = None, carry_factor: bool = True) -> torch.Tensor:
     """PerciatelliFeatureConstructor.observe + get_features for every env: [n, 1099] float32
@@ -143,6 +159,7 @@ class VecSimulator:
     self._obs_reset.zero_()         # stream-ordered after the kernel
     return out
 
+  @_on_own_device
   def wind_noise(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """SimplexWindNoise at every env's current position and time: [n, 2] float32 (m/s), the
     `noise_uv` input of step() / observe().  One noise field per (seed, env, episode)."""
@@ -164,6 +181,7 @@ class VecSimulator:
         torch.maximum(self._obs_reset, mask, out=self._obs_reset)
 
   # ------------------------------------------------------------------ stepping
+  @_on_own_device
   def step(self, action: torch.Tensor, noise_uv: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):
     """One agent step for all envs (asynchronous on the current stream).
 
@@ -182,6 +200,7 @@ class VecSimulator:
     _lib.check(code, 'ble_step_f32')
     return self.reward, self.terminal
 
+  @_on_own_device
   def step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
              active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS) -> None:
     """`actions` [K, n] uint8 -> K agent steps enqueued by one library call."""

@@ -23,7 +23,8 @@ def mods():
 
 def create_arena(mods, seed=None):
   balloon_arena, _, features, wind_field = mods
-  return balloon_arena.BalloonArena(features.PerciatelliFeatureConstructor, wind_field.SimpleStaticWindField(), seed=seed)
+  # noise=False: the explicit opt-out (forecast == truth) for the tests that assert exact drifts
+  return balloon_arena.BalloonArena(features.PerciatelliFeatureConstructor, wind_field.SimpleStaticWindField(noise=False), seed=seed)
 
 
 def floats_of(s):
@@ -41,6 +42,42 @@ def test_arena_seeding(mods):
   s1, s2 = a1.get_simulator_state().balloon_state, a2.get_simulator_state().balloon_state
   assert s1.x != s2.x and s1.y != s2.y
   a1.reset()                                                                          # random seed: no exception
+
+
+def test_reseeding_an_existing_arena_reproduces_the_episode(mods):
+  """reset(seed) is a function of the seed alone (eval_lib's env.seed(s); env.reset() contract): the same
+  object re-seeded after flying gives the same initial state, observation and wind field again."""
+  import torch
+  balloon_arena, balloon_env, _, wind_field = mods
+  arena = create_arena(mods)
+  o1 = arena.reset(201); s1 = floats_of(arena.get_simulator_state().balloon_state)
+  for a in (0, 2, 1):
+    arena.step(a)
+  arena.reset(77)
+  o2 = arena.reset(201); s2 = floats_of(arena.get_simulator_state().balloon_state)
+  assert s1 == s2
+  np.testing.assert_array_equal(o1, o2)
+  env = balloon_env.BalloonEnv(seed=5)
+  env.seed(9); oa = env.reset(); sa = floats_of(env.get_simulator_state().balloon_state)
+  env.step(1); env.reset()
+  env.seed(9); ob = env.reset(); sb = floats_of(env.get_simulator_state().balloon_state)
+  assert sa == sb
+  np.testing.assert_array_equal(oa, ob)
+  # the vectorised arena: same seed -> same episodes and field; reset() without a seed -> the NEXT ones
+  vec = balloon_arena.VecBalloonArena(96, seed=3)
+  st0 = vec.sim.get_state(); g0 = vec.sim.grid.clone()
+  vec.step(torch.ones(96, dtype=torch.uint8, device='cuda'))
+  vec.reset()
+  st1 = vec.sim.get_state()
+  assert not np.array_equal(st1['x'], st0['x']) and not torch.equal(vec.sim.grid, g0)      # new episodes, new field
+  vec.reset(3)
+  st2 = vec.sim.get_state()
+  for k in st0:
+    np.testing.assert_array_equal(st0[k], st2[k], err_msg=k)
+  assert torch.equal(vec.sim.grid, g0)
+  vec.reset()
+  for k in st1:
+    np.testing.assert_array_equal(st1[k], vec.sim.get_state()[k], err_msg=k)               # the sequence is reproducible too
 
 
 @pytest.mark.parametrize('seed', [1, 5, 28, 90, 106, 378])
@@ -173,7 +210,7 @@ def test_vec_balloon_env(mods):
   import torch
   _, balloon_env, _, _ = mods
   n = 256
-  env = balloon_env.VecBalloonEnv(n, seed=9, wind_noise=True)
+  env = balloon_env.VecBalloonEnv(n, seed=9)           # defaults: wind noise ON, generative wind field, auto-reset
   obs = env.reset()
   assert obs.shape == (n, 1099) and obs.dtype == torch.float32
   space = env.observation_space
@@ -189,7 +226,7 @@ def test_vec_balloon_env(mods):
     assert (o >= space.low - 1e-6).all() and (o <= space.high + 1e-6).all()
     assert ((reward >= 0) & (reward <= 1)).all()
     assert (env.arena.sim.state['status'] == 0).all()              # auto-reset: everybody flies
-  env.arena.sim.check_errors()
+  env.check_errors()
   assert total.max() <= 12.0
   # with wind noise on, forecast != truth: the WindGP uncertainty at the balloon's level is below 1
   assert (obs[:, 16 + 3 * 180] < 0.5).float().mean() > 0.5
@@ -217,3 +254,38 @@ def test_vec_balloon_env_graph_replay_matches_eager(mods):
   for name in ('x', 'pressure', 'battery_charge', 'time_elapsed_s'):
     assert torch.equal(envs[0].arena.sim.state[name], envs[1].arena.sim.state[name])
   envs[1].arena.sim.check_errors()
+
+
+def test_vec_balloon_env_defaults_per_env_fields_and_error_polling(mods):
+  import torch
+  _, balloon_env, _, _ = mods
+  n = 128
+  # step() before reset() works (the noise is evaluated lazily) and the default has forecast != truth
+  env = balloon_env.VecBalloonEnv(n, seed=2)
+  obs, reward, terminal = env.step(torch.ones(n, dtype=torch.uint8, device='cuda'))
+  assert float(env._noise.abs().max()) > 0.0
+  quiet = balloon_env.VecBalloonEnv(n, seed=2, wind_noise=False)
+  oq = quiet.reset()
+  assert quiet._noise is None
+  # per-env wind fields: one decoded grid per environment, new ones for re-started lanes
+  env = balloon_env.VecBalloonEnv(n, seed=4, per_env_fields=True, field_refresh_every=2)
+  env.reset()
+  grids = env.arena.sim.grid
+  assert tuple(grids.shape) == (n, 21, 21, 10, 9, 2) and env.arena.sim.grid_env_stride == 21 * 21 * 10 * 9 * 2
+  assert not torch.equal(grids[0], grids[1])
+  before = grids[:8].clone()
+  env.arena.sim.state['status'][:4] = 1                         # lanes 0..3 are terminal -> auto-reset at the next step
+  for _ in range(4):
+    env.step(torch.ones(n, dtype=torch.uint8, device='cuda'))
+  env.check_errors()
+  after = env.arena.sim.grid[:8]
+  changed = [not torch.equal(after[i], before[i]) for i in range(8)]
+  assert int(env.arena.sim.episode[:4].min()) >= 2 and changed[:4] == [True] * 4 and changed[4:] == [False] * 4
+  # reseeding reproduces the per-env fields as well
+  env.reset(seed=4)
+  assert torch.equal(env.arena.sim.grid[:8], before)
+  # latched error conditions surface through check_errors(): a non-finite state
+  env.arena.sim.state['pressure'][5] = float('nan')
+  env.step(torch.ones(n, dtype=torch.uint8, device='cuda'))
+  with pytest.raises((FloatingPointError, AssertionError, ValueError)):
+    env.check_errors()

@@ -368,3 +368,61 @@ def test_feature_oracle_long_horizon():
   """136 observations: the 6 h window (120 observations) must drop the oldest ones."""
   got, want = _oracle_features('f12_features_long', 0, keep_last=16)
   np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# F13: BASELINE.json configs[0] in closed loop -- the reference's StationSeekerAgent flying the
+# reference's arena loop for micro_eval's 960 steps (generated by tests/golden/make_golden.py).
+def test_f13_station_seeker_restatement_reproduces_every_action():
+  """oracle/station_seeker_oracle.py vs the reference agent on the reference's own observations."""
+  import station_seeker_oracle as sso
+  g = golden('f13_station_seeker')
+  n = int(g['n_flown'])
+  assert n == 960 and (g['status'][0] == 0).all()              # the controller keeps the balloon alive all episode
+  feats, actions, levels = g['features'][0], g['actions'][0], g['levels']
+  for i in range(n):
+    assert sso.best_level(feats[i]) == levels[i], i
+    assert sso.pick_action(feats[i]) == actions[i], i
+  assert set(np.unique(actions)) == {0, 1, 2}
+
+
+def test_f13_transition_oracle_teacher_forced():
+  """The C oracle's transition on the closed-loop episode: ground-truth wind (forecast + noise) at the
+  pre-step state, the agent's action, 960 steps."""
+  d = golden('f13_station_seeker')
+  field = (np.random.default_rng(int(d['field_seed'])).standard_normal((21, 21, 10, 9, 2)) * float(d['field_scale'])).astype(np.float32)
+  n = int(d['n_flown'])
+  st = traj_state_at(d, 0, np.arange(n) * 0)            # n copies of env 0 ...
+  for k in STATE_FLOATS + STATE_INTS + STATE_U8:        # ... each at its own step of the episode
+    st[k][:] = d[k][0, :n]
+  reward, terminal, _, err = oracle.step(st, d['actions'][0, :n], field=field, noise_uv=d['noise_uv'][0, :n])
+  assert err == 0
+  for k in STATE_FLOATS:
+    np.testing.assert_allclose(st[k], d[k][0, 1:n + 1], rtol=2e-9, atol=2e-9, err_msg=k)
+  for k in STATE_INTS + STATE_U8:
+    np.testing.assert_array_equal(st[k], d[k][0, 1:n + 1], err_msg=k)
+  np.testing.assert_allclose(reward, d['reward'][0, :n], rtol=1e-12, atol=1e-15)
+  # wind_measured really is forecast + noise at the recorded states
+  fu, fv = oracle.wind_forecast(field, d['x'][0], d['y'][0], d['pressure'][0], d['time_elapsed_s'][0])
+  np.testing.assert_allclose(d['wind_measured'][0, :, 0], fu + d['noise_uv'][0, :, 0], rtol=0, atol=1e-12)
+
+
+def test_f13_feature_oracle_closed_loop():
+  """oracle/features_oracle.py along the whole episode (the WindGP window slides 840 times): every
+  100th vector and the last 20 against the reference's, and the restated agent's action from the
+  ORACLE's observation equals the reference agent's on every step."""
+  import features_oracle
+  import station_seeker_oracle as sso
+  g = helpers.golden('f13_station_seeker')
+  field = helpers.fixture_field(g)
+  fo = features_oracle.FeatureOracle(field, g['alpha'][0])
+  n = int(g['n_flown'])
+  for i in range(n + 1):
+    row = helpers.feature_row(g, 0, i)
+    fo.observe(row, tuple(g['noise_uv'][0, i]))
+    if i < n or i % 100 == 0:
+      f = fo.features()
+      if i % 100 == 0 or i > n - 20:
+        np.testing.assert_allclose(f, g['features'][0, i], rtol=0, atol=1e-6, err_msg=f'step {i}')
+      if i < n:
+        assert sso.pick_action(f.astype(np.float32)) == g['actions'][0, i], i
