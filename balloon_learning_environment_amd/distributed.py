@@ -21,6 +21,28 @@ def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
   return lo, lo + base + (1 if rank < rem else 0)
 
 
+# BASELINE.json configs[i] -> (environments of the whole job, per-env forecasts?) as a function of the world size
+def preset_layout(config: int, rank: int, world: int) -> dict:
+  """How preset `config` (= BASELINE.json configs[config]) lays out on `world` ranks:
+     1  4 096 envs on one GPU, shared grid         2  65 536 envs PER GPU, shared grid (weak scaling)
+     3  65 536 envs GLOBAL, contiguous shards      4  32 768 envs per GPU with per-env decoded grids, no broadcast
+  Returns global_envs, this rank's [lo, hi) slice of the global env index range, per_env_grids, broadcast."""
+  if config == 1:
+    n_global, per_env = 4096 * world, False
+  elif config == 2:
+    n_global, per_env = 65536 * world, False
+  elif config == 3:
+    n_global, per_env = 65536, False
+  elif config == 4:
+    n_global, per_env = 32768 * world, True
+  else:
+    raise ValueError(f'unknown preset {config}')
+  lo, hi = shard_range(n_global, rank, world)
+  return {'global_envs': n_global, 'lo': lo, 'hi': hi, 'n_local': hi - lo, 'per_env_grids': per_env,
+          'broadcast_grid': not per_env, 'grid_bytes_per_rank': (hi - lo) * 317520 if per_env else 317520,
+          'gather_bytes_per_step': (hi - lo) * 5}
+
+
 def broadcast_grid(grid: torch.Tensor, src: int = 0) -> torch.Tensor:
   """Rank `src` owns the wind grid (21,21,10,9,2) float32; everyone gets a copy in place."""
   if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -323,12 +323,7 @@ def main():
   bdist.broadcast_grid(grid, src=0)
 
   def preset_size(cfg):
-    if cfg == 1: return 4096
-    if cfg == 2: return 65536
-    if cfg == 3:
-      lo, hi = bdist.shard_range(65536, rank, world)
-      return hi - lo
-    return 32768
+    return bdist.preset_layout(cfg, rank, world)['n_local']
 
   def make(cfg, n=None, steps=None, warmup=None):
     n = n if n is not None else preset_size(cfg)

@@ -23,6 +23,70 @@ def test_shard_range_partitions_exactly():
       assert max(sizes) - min(sizes) <= 1
 
 
+def test_preset_layouts_match_baseline_configs():
+  """bench.py --config i: BASELINE.json configs[3] = 65 536 envs sharded over the GPUs (8 192 each on 8),
+  configs[4] = 262 144 envs on 8 GPUs with per-env forecasts (32 768 x 317 520 B = 10.4 GB per GPU)."""
+  for world in (1, 2, 4, 8):
+    l3 = [bdist.preset_layout(3, r, world) for r in range(world)]
+    assert sum(l['n_local'] for l in l3) == 65536 and all(l['global_envs'] == 65536 for l in l3)
+    assert l3[0]['lo'] == 0 and l3[-1]['hi'] == 65536 and all(a['hi'] == b['lo'] for a, b in zip(l3, l3[1:]))
+    assert all(l['broadcast_grid'] and not l['per_env_grids'] for l in l3)
+    l4 = [bdist.preset_layout(4, r, world) for r in range(world)]
+    assert all(l['n_local'] == 32768 and l['per_env_grids'] and not l['broadcast_grid'] for l in l4)
+    assert l4[0]['global_envs'] == 32768 * world
+    assert all(l['n_local'] == 65536 for l in (bdist.preset_layout(2, r, world) for r in range(world)))
+  assert bdist.preset_layout(3, 5, 8)['n_local'] == 8192 and bdist.preset_layout(3, 5, 8)['lo'] == 5 * 8192
+  assert bdist.preset_layout(4, 0, 8)['global_envs'] == 262144
+  assert abs(bdist.preset_layout(4, 0, 8)['grid_bytes_per_rank'] / 1e9 - 10.4) < 0.01
+  with pytest.raises(ValueError):
+    bdist.preset_layout(7, 0, 1)
+
+
+def _preset_worker(rank, world, port, out_dir):
+  """The exchanges of bench.py --config 3 and --config 4 at the presets' real shard sizes for a
+  2-rank job (32 768 envs per rank): one grid broadcast (config 3 only), the [32, n_local] reward /
+  terminal gather every 32 steps, max / sum over ranks."""
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    out = {}
+    for cfg in (3, 4):
+      lay = bdist.preset_layout(cfg, rank, world)
+      n = lay['n_local']
+      grid = torch.full((21, 21, 10, 9, 2), float(rank + 1))
+      if lay['broadcast_grid']:
+        bdist.broadcast_grid(grid, src=0)
+      env_ids = torch.arange(lay['lo'], lay['hi'], dtype=torch.float32)
+      reward = (env_ids[None, :] + 1000000.0 * torch.arange(32, dtype=torch.float32)[:, None]).contiguous()
+      terminal = (torch.arange(lay['lo'], lay['hi'])[None, :] % 7 == torch.arange(32)[:, None] % 7).to(torch.uint8).contiguous()
+      g = bdist.OutputGatherer(32, n, 'cpu', world)
+      g.gather(reward, terminal); g.wait()
+      live = bdist.sum_over_ranks(float(n * 32 - int(terminal.sum())), 'cpu')
+      out[cfg] = dict(grid0=float(grid.flatten()[0]), reward=g.reward, terminal=g.terminal, live=live, lay=lay)
+    torch.save(out, os.path.join(out_dir, f'p{rank}.pt'))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_preset_exchanges_world2(tmp_path):
+  world = 2
+  mp.spawn(_preset_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  outs = [torch.load(os.path.join(tmp_path, f'p{r}.pt')) for r in range(world)]
+  # config 3: both ranks fly in rank 0's grid; config 4: each keeps its own (no broadcast)
+  assert [o[3]['grid0'] for o in outs] == [1.0, 1.0] and [o[4]['grid0'] for o in outs] == [1.0, 2.0]
+  for cfg, n_global in ((3, 65536), (4, 65536)):
+    o = outs[0][cfg]
+    assert tuple(o['reward'].shape) == (world, 32, n_global // world)
+    glob = torch.cat([o['reward'][r] for r in range(world)], dim=1)            # env order restored on rank 0
+    assert torch.equal(glob[0], torch.arange(n_global, dtype=torch.float32))
+    assert torch.equal(glob[31], torch.arange(n_global, dtype=torch.float32) + 31000000.0)
+    tglob = torch.cat([o['terminal'][r] for r in range(world)], dim=1)
+    want = (torch.arange(n_global)[None, :] % 7 == torch.arange(32)[:, None] % 7).to(torch.uint8)
+    assert torch.equal(tglob, want)
+    assert outs[0][cfg]['live'] == outs[1][cfg]['live'] == float(n_global * 32 - int(want.sum()))
+    assert outs[1][cfg]['reward'].numel() == 0
+
+
 def _free_port():
   with socket.socket() as s:
     s.bind(('127.0.0.1', 0))

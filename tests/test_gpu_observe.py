@@ -337,3 +337,82 @@ def test_carried_factor_equals_fresh_factorisation(vec_state):
     worst = max(worst, np.abs(got - want).max() / np.abs(want).max())
   print('carried factor vs fresh LDL^T after %d slides: worst relative difference %.3g' % (steps - 120, worst))
   assert m == 120 and worst < 1e-11
+
+
+def _oracle_features_worker(args):
+  """(subprocess) replays one environment's recorded rows through the feature oracle."""
+  import features_oracle
+  field, alpha, rows, noises, want_steps = args
+  fo = features_oracle.FeatureOracle(field, alpha)
+  out = {}
+  for i, (row, nz) in enumerate(zip(rows, noises)):
+    fo.observe(row, nz)
+    if i in want_steps:
+      out[i] = fo.features()
+  return out
+
+
+def test_observe_full_size_65536_envs(vec_state):
+  """The observation kernel at BASELINE's headline size: 65 536 environments (3.8 GB of carried WindGP
+  factors, 64-bit history / factor offsets), flown by the step kernel for 126 steps so that the 6 h
+  window fills and slides; 256 sampled environments -- incl. the first and the last -- against the feature
+  oracle at the first, a middle and the last three observations; bitwise determinism of the whole batch."""
+  import multiprocessing as mp
+  n, steps = 65536, 126
+  rng = np.random.default_rng(12)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 6.0).astype(np.float32)
+  idx = np.unique(np.concatenate([rng.integers(0, n, 254), [0, n - 1]]))
+  idx_t = torch.from_numpy(idx).cuda()
+  want_steps = (0, 60, steps - 2, steps - 1, steps)
+  gen = torch.Generator(device='cuda')
+
+  def fly(record):
+    sim = vec_state.VecSimulator(n)
+    sim.set_grid(torch.from_numpy(field).cuda())
+    sim.reset_device(seed=31)
+    gen.manual_seed(5)
+    rows, noises, kept = [], [], {}
+    obs = torch.empty(n, 1099, dtype=torch.float32, device='cuda')
+    for i in range(steps + 1):
+      if i > 0:
+        sim.step(torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda', generator=gen))
+      noise = torch.randn((n, 2), dtype=torch.float32, device='cuda', generator=gen) * 1.5
+      sim.observe(noise, out=obs)
+      if record:
+        st = {k: t[idx_t].cpu().numpy() for k, t in sim.state.items()}
+        rows.append(st); noises.append(noise[idx_t].cpu().numpy().astype(np.float64))
+        if i in want_steps:
+          kept[i] = obs[idx_t].cpu().numpy()
+    torch.cuda.synchronize(); sim.check_errors()
+    return obs.clone(), rows, noises, kept, sim
+
+  final_a, rows, noises, kept, sim = fly(True)
+  assert int(sim._gp['count'].min()) == steps + 1 and sim._gp['chol'].numel() * 8 > 3.5e9
+  alive = rows[-1]['status'] == 0
+  jobs = []
+  for j in range(len(idx)):
+    env_rows = []
+    for st in rows:
+      row = {k: float(st[k][j]) for k in helpers.STATE_FLOATS}
+      for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+        row[k] = float(st[k][j])
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
+        row[k] = int(st[k][j])
+      env_rows.append(row)
+    jobs.append((field, float(rows[0]['alpha'][j]), env_rows, [nz[j] for nz in noises], want_steps))
+  with mp.get_context('fork').Pool(min(16, len(jobs))) as pool:
+    results = pool.map(_oracle_features_worker, jobs, chunksize=4)
+  worst = 0.0; checked = 0
+  for j, res in enumerate(results):
+    for i in want_steps:
+      if rows[i]['status'][j] != 0:
+        continue          # a terminated balloon's observation is not defined by the reference (it raises)
+      err = check(kept[i][j], res[i], f'env {idx[j]} step {i}')
+      worst = max(worst, float(err.max())); checked += 1
+  print(f'65536-env observation: {checked} sampled vectors vs oracle, worst |diff| {worst:.3g}; {int(alive.sum())}/{len(idx)} sampled envs alive')
+  assert checked > 1000
+  # bitwise determinism of the full batch (every env, every feature), second flight without recording
+  del sim
+  torch.cuda.empty_cache()
+  final_b, *_ = fly(False)
+  assert torch.equal(final_a, final_b)

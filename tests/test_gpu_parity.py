@@ -707,3 +707,60 @@ def test_ragged_batch_sizes(ble, n):
   sim.step_n(acts, rew, term)
   torch.cuda.synchronize(); sim.check_errors()
   assert float(rew.min()) >= 0.0 and int(term.max()) <= 1          # every element written, nothing beyond n touched
+
+
+# ---------------------------------------------------------------- BASELINE configs[3] / configs[4] at one GPU's share
+def test_config3_shard_8192_envs_every_env(ble):
+  """One rank's share of BASELINE.json configs[3] (65 536 envs over 8 GPUs = 8 192 per GPU; the shard of
+  rank 5 flies envs [40 960, 49 152) of the global batch, shared broadcast grid): every environment
+  against the oracle, 6 free-running steps."""
+  from balloon_learning_environment_amd import distributed as bdist
+  lay = bdist.preset_layout(3, 5, 8)
+  assert (lay['n_local'], lay['lo']) == (8192, 40960)
+  total, outliers, worst = _sampled_batch_parity(ble, lay['n_local'], steps=6, seed=1000 + 5, threads=16)
+  print(f'config 3 shard: {total} env-steps, {outliers} beyond 1e-5, worst {worst:.2g}')
+  assert outliers == 0 and worst <= RTOL
+
+
+def test_config4_share_32768_envs_per_env_grids_sampled(ble):
+  """One GPU's share of BASELINE.json configs[4]: 32 768 environments, each in its OWN forecast decoded on the
+  device (32 768 x 317 520 B = 10.4 GB of grids, 64-bit grid offsets).  Three fused steps
+  (ble_step_n_f32) of the whole batch; 384 sampled environments -- including the last one -- are
+  checked against the oracle, each on its own grid copied back from HBM."""
+  from balloon_learning_environment_amd import distributed as bdist
+  from balloon_learning_environment_amd import reset_host
+  from balloon_learning_environment_amd.env import generative_wind_field
+  lay = bdist.preset_layout(4, 0, 8)
+  n = lay['n_local']
+  assert n == 32768 and lay['per_env_grids'] and not lay['broadcast_grid']
+  sampler = generative_wind_field.GenerativeWindFieldSampler(seed=0)
+  grids = sampler.decode(sampler.sample_latents(n, seed=100))
+  assert grids.numel() * 4 == lay['grid_bytes_per_rank']
+  sim = ble.VecSimulator(n)
+  init = reset_host.sample_initial_state(n, seed=1000)
+  sim.set_state(init)
+  sim.set_grid(grids, per_env=True)
+  k = 3
+  acts = torch.from_numpy(np.random.default_rng(9).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
+  sim.step_n(acts, rew, term)
+  torch.cuda.synchronize(); sim.check_errors()
+  got = sim.get_state()
+  idx = np.unique(np.concatenate([np.random.default_rng(1).integers(0, n, 382), [0, n - 1]]))
+  host_grids = grids[torch.from_numpy(idx).cuda()].cpu().numpy()
+  acts_h = acts.cpu().numpy(); rew_h = rew.cpu().numpy(); term_h = term.cpu().numpy()
+  worst = 0.0
+  for j, i in enumerate(idx):
+    o2 = oracle_state_from_abi({key: v[i:i + 1] for key, v in init.items()})
+    for s in range(k):
+      ro, to, eo, err = oracle.step(o2, acts_h[s, i:i + 1], field=host_grids[j])
+      assert abs(rew_h[s, i] - ro[0]) <= 2e-5 and term_h[s, i] == to[0], (i, s)
+    for key in STATE_FLOATS:
+      e = float(rel_err(got[key][i], o2[key][0], FLOORS[key]))
+      worst = max(worst, e)
+      assert e <= RTOL, (i, key, e)
+    for key in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+      assert int(got[key][i]) == int(o2[key][0]), (i, key)
+  print(f'config 4 share: {len(idx)} sampled envs x {k} fused steps on per-env grids, worst {worst:.2g}')
+  # distinct forecasts really are in use: neighbouring environments see different winds at the same spot
+  assert not torch.equal(grids[0], grids[n - 1])
