@@ -724,9 +724,11 @@ def test_config3_shard_8192_envs_every_env(ble):
 
 def test_config4_share_32768_envs_per_env_grids_sampled(ble):
   """One GPU's share of BASELINE.json configs[4]: 32 768 environments, each in its OWN forecast decoded on the
-  device (32 768 x 317 520 B = 10.4 GB of grids, 64-bit grid offsets).  Three fused steps
-  (ble_step_n_f32) of the whole batch; 384 sampled environments -- including the last one -- are
-  checked against the oracle, each on its own grid copied back from HBM."""
+  device (32 768 x 317 520 B = 10.4 GB of grids, 64-bit grid offsets).  The whole batch flies three steps
+  twice -- fused (ble_step_n_f32, one launch) and as three ble_step_f32 launches -- and the two must agree
+  bit for bit; along the unfused flight 384 sampled environments (incl. the first and the last) are checked
+  step by step against the oracle, each on its own grid copied back from HBM and from the GPU's own
+  pre-step state (identical inputs)."""
   from balloon_learning_environment_amd import distributed as bdist
   from balloon_learning_environment_amd import reset_host
   from balloon_learning_environment_amd.env import generative_wind_field
@@ -736,31 +738,37 @@ def test_config4_share_32768_envs_per_env_grids_sampled(ble):
   sampler = generative_wind_field.GenerativeWindFieldSampler(seed=0)
   grids = sampler.decode(sampler.sample_latents(n, seed=100))
   assert grids.numel() * 4 == lay['grid_bytes_per_rank']
-  sim = ble.VecSimulator(n)
   init = reset_host.sample_initial_state(n, seed=1000)
-  sim.set_state(init)
-  sim.set_grid(grids, per_env=True)
   k = 3
   acts = torch.from_numpy(np.random.default_rng(9).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  fused = ble.VecSimulator(n); fused.set_state(init); fused.set_grid(grids, per_env=True)
   rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
-  sim.step_n(acts, rew, term)
-  torch.cuda.synchronize(); sim.check_errors()
-  got = sim.get_state()
+  fused.step_n(acts, rew, term)
+  torch.cuda.synchronize(); fused.check_errors()
   idx = np.unique(np.concatenate([np.random.default_rng(1).integers(0, n, 382), [0, n - 1]]))
-  host_grids = grids[torch.from_numpy(idx).cuda()].cpu().numpy()
-  acts_h = acts.cpu().numpy(); rew_h = rew.cpu().numpy(); term_h = term.cpu().numpy()
+  idx_t = torch.from_numpy(idx).cuda()
+  host_grids = grids[idx_t].cpu().numpy()
+  sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(grids, per_env=True)
   worst = 0.0
-  for j, i in enumerate(idx):
-    o2 = oracle_state_from_abi({key: v[i:i + 1] for key, v in init.items()})
-    for s in range(k):
-      ro, to, eo, err = oracle.step(o2, acts_h[s, i:i + 1], field=host_grids[j])
-      assert abs(rew_h[s, i] - ro[0]) <= 2e-5 and term_h[s, i] == to[0], (i, s)
-    for key in STATE_FLOATS:
-      e = float(rel_err(got[key][i], o2[key][0], FLOORS[key]))
-      worst = max(worst, e)
-      assert e <= RTOL, (i, key, e)
-    for key in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
-      assert int(got[key][i]) == int(o2[key][0]), (i, key)
-  print(f'config 4 share: {len(idx)} sampled envs x {k} fused steps on per-env grids, worst {worst:.2g}')
-  # distinct forecasts really are in use: neighbouring environments see different winds at the same spot
+  for s in range(k):
+    before = {key: t[idx_t].cpu().numpy() for key, t in sim.state.items()}
+    reward, terminal = sim.step(acts[s].contiguous())
+    torch.cuda.synchronize(); sim.check_errors()
+    assert torch.equal(reward, rew[s]) and torch.equal(terminal, term[s])        # fused == unfused, every env
+    after = {key: t[idx_t].cpu().numpy() for key, t in sim.state.items()}
+    a_h = acts[s][idx_t].cpu().numpy(); r_h = reward[idx_t].cpu().numpy()
+    for j in range(len(idx)):
+      o2 = oracle_state_from_abi({key: v[j:j + 1] for key, v in before.items()})
+      ro, to, eo, err = oracle.step(o2, a_h[j:j + 1], field=host_grids[j])
+      assert abs(r_h[j] - ro[0]) <= 2e-5, (idx[j], s)
+      for key in STATE_FLOATS:
+        e = float(rel_err(after[key][j], o2[key][0], FLOORS[key]))
+        worst = max(worst, e)
+        assert e <= RTOL, (idx[j], s, key, e)
+      for key in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+        assert int(after[key][j]) == int(o2[key][0]), (idx[j], s, key)
+  for key in sim.state:
+    assert torch.equal(sim.state[key], fused.state[key]), key
+  print(f'config 4 share: {len(idx)} sampled envs x {k} steps on per-env grids, worst {worst:.2g}; fused == unfused for all {n}')
+  # distinct forecasts really are in use
   assert not torch.equal(grids[0], grids[n - 1])
