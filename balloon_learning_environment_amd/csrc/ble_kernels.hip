@@ -48,8 +48,8 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
                                                           int64_t n, int substeps, int lanes, int n_steps) {
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
-  __shared__ float acs_table[4 * 13];
-  if (threadIdx.x < 4 * 13) acs_table[threadIdx.x] = kAcsEfficiency[threadIdx.x];
+  __shared__ double acs_poly[kAcsPolyDoubles];
+  if (threadIdx.x < 12) acs_build_poly(kAcsEfficiency, (int)threadIdx.x, acs_poly + 6 * threadIdx.x);
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
   const bool in_range = i < n && (int)threadIdx.x < lanes;
@@ -72,6 +72,8 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   }
   const bool was_live = live;
   int last_act = 0;
+  EnvHoisted hc;
+  if (live) hc = hoist_constants(c);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
     const int64_t o = (int64_t)k * n + i;
@@ -81,11 +83,15 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       // wind at the PRE-step position/time (balloon_arena.py:194,270-275): gather now, blend later
       const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
       WindCorners corners;
+#ifdef BLE_WHATIF_NO_GATHER
+      for (int a = 0; a < 8; ++a) for (int b = 0; b < 4; ++b) corners.c[a][b] = 1.0f + 0.01f * (float)(a + b);
+#else
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
+#endif
       float nu = 0.0f, nv = 0.0f;
       if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
-      const int eff = agent_step(s, c, act, corners, wq, nu, nv, substeps, acs_table, &r, &flags);
+      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, &r, &flags);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
         flags |= kFlagNonFinite;
       reward[o] = r;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume,
     yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
     flags |= (t_int[i] < 12.3f) ? kFlagAbsorptivity : 0u;
     dtdt[i] = (float)(0.1 * thermal_increment_f64(vol, yc, (double)t_int[i], (double)t_amb[i], (double)pressure[i],
-                                                  (flux[i] * att) * (0.25f * kSolarAbsorptivityTotal),
+                                                  (double)((flux[i] * att) * (0.25f * kSolarAbsorptivityTotal)),
                                                   earth_heat_per_area_f64((double)ir[i], &flags)));
   }
   report_flags(flags, err_flags);
@@ -262,10 +268,13 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
                                                         int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  // power and mass flow through the transition's piecewise-cubic form, the efficiency through the two-table form
   const double prm1 = (double)pr[i] - 1.0;
-  const double w = acs_power_f64(prm1);
-  const double e = acs_efficiency_f64(kAcsEfficiency, prm1, w);
-  power[i] = (float)w; eff[i] = (float)e; mdot[i] = (float)(e * w * (1.0 / 3600.0));
+  double poly[kAcsPolyDoubles];
+  for (int k = 0; k < 12; ++k) acs_build_poly(kAcsEfficiency, k, poly + 6 * k);
+  double w, md;
+  acs_down_poly(poly, prm1, &w, &md);
+  power[i] = (float)w; eff[i] = (float)acs_efficiency_f64(kAcsEfficiency, prm1, acs_power_f64(prm1)); mdot[i] = (float)md;
 }
 
 // Decoder tail of the wind-field VAE (generative/vae.py:149-186): flow fields psi [n][7][7][90]

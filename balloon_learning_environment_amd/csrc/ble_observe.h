@@ -39,8 +39,9 @@ constexpr int kObsDim = 3 * kObsColumn + 16;        // 1099
 constexpr int kGpCapacity = 128;                    // ring entries per env (BLE_GP_CAPACITY)
 constexpr int kGpMax = 120;                         // 6 h / 180 s
 constexpr int kGpRows = 128;
-constexpr int kCholStride = kGpMax * (kGpMax + 1) / 2;   // 7260 doubles = 58 080 B per environment
-constexpr int kCholPrefetch = (kCholStride / 2 + 255) / 256;   // double2 loads per lane (15)                        // kGpMax rounded up to the MFMA tile
+constexpr int kCholTri = kGpMax * (kGpMax + 1) / 2;      // 7260 doubles: the packed factor
+constexpr int kCholStride = kCholTri + kGpMax;           // + the drop vector p (below): 7380 doubles = 59 040 B per environment
+constexpr int kCholPrefetch = (kCholTri / 2 + 255) / 256;      // double2 loads per lane (15)
 constexpr int kObsBlock = 256;
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
@@ -59,17 +60,21 @@ struct GpHistory {
 };
 
 struct ObsShared {
-  double L[kCholStride];                 // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
+  double L[kCholTri];                    // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
                                          // below the diagonal, d on it.  Rows 120 .. 127 (MFMA tile padding) are
                                          // identity and exist only virtually (zero_row, d = 1)
   union {
     double el_table[kElevTable];         // phases 0-1: solar elevation at now + 180 s * (k - 240)
     double dinv[kGpRows / 16][136];      // phases 4-5: inverses of the 16 x 16 unit-lower diagonal blocks, packed lower
   };
-  double zero_row[112];                  // the off-diagonal part of a virtual padding row
+  union {
+    double zero_row[112];                // phases 4-5: the off-diagonal part of a virtual identity row
+    double pb[kGpMax][2];                // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
+  };
   double loc[kGpRows][4];                // x, y, p, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
-  double z[2][kGpRows];                  // error components, then z = L^-1 y
+  double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
+  double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20], sp[22];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
@@ -80,6 +85,17 @@ struct ObsShared {
   int range_ok;
   float role_t[3];
 };
+static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double up = __shfl_up(v, off, 64);
+    v += lane >= off ? up : 0.0;
+  }
+  return v;
+}
 
 BLE_FN int tri(int i) { return i * (i + 1) / 2; }
 
@@ -164,6 +180,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   BLE_MARK();
   const int64_t env = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef BLE_OBS_STAGGER
+  // Two workgroups share a CU and each runs VALU/MFMA-heavy phases (solar table, sweep) and latency-bound
+  // single-wave phases in sequence.  Launched together they stay in lockstep for the whole grid -- both in
+  // the same phase, competing for the same pipes.  Delaying the second resident workgroup of every CU ONCE,
+  // in the first round, shifts them by half a period; the shift then persists (a finishing workgroup is
+  // replaced at once).
+  if (blockIdx.x >= BLE_OBS_STAGGER_FROM && blockIdx.x < BLE_OBS_STAGGER_TO) {
+    const long long t_start = (long long)__builtin_readcyclecounter();
+    while ((long long)__builtin_readcyclecounter() - t_start < (long long)(BLE_OBS_STAGGER)) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
   uint32_t flags = 0;
 
   // ---- state of this environment (uniform loads)
@@ -193,6 +220,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const int e2 = tid + kObsBlock * i;
     chol_pre[i] = (chol_g != nullptr && e2 < chol_pairs) ? reinterpret_cast<const double2*>(chol_g)[e2] : make_double2(0.0, 0.0);
   }
+  const double p_pre = (chol_g != nullptr && tid < n_chol0 - 1 && n_chol0 <= kGpMax) ? chol_g[kCholTri + tid] : 0.0;
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -282,7 +310,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
   }
   const double el_now = sh.el_now, flux_now = sh.flux_now;
-  if (tid >= 128 && tid < 128 + 112) sh.zero_row[tid - 128] = 0.0;
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
   const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   // Can the stored factor be slid to the new window?  The observations inside the 6 h window
@@ -298,8 +325,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const int last_invalid = inv1 ? 127 - __clzll(inv1) : (inv0 ? 63 - __clzll(inv0) : -1);
     const int first_valid = b0 ? __ffsll((long long)b0) - 1 : (b1 ? 63 + __ffsll((long long)b1) : m);
     n_dropped = (count - n_obs) - (count0 - n_chol0);
+    // (at most one observation leaves the window per call when the agent steps are the reference's 180 s;
+    // anything else takes the refit path)
     incremental = hist.chol != nullptr && drop == 0 && last_invalid < first_valid && n_dropped >= 0 &&
-                  n_dropped <= n_chol0 && n_chol0 <= kGpMax;
+                  n_dropped <= 1 && n_dropped <= n_chol0 && n_chol0 <= kGpMax;
   }
   if (incremental) {
 #pragma unroll
@@ -307,7 +336,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       const int e2 = tid + kObsBlock * i;
       if (e2 < chol_pairs) reinterpret_cast<double2*>(sh.L)[e2] = chol_pre[i];
     }
+    if (tid < kGpMax) sh.pb[tid][0] = p_pre;
   }
+  // Rows of the factor the MFMA sweep works on.  Incremental: the window WITHOUT its newest observation
+  // (that one becomes a bordering row, folded in after the sweep); refit: the whole window.
+  const bool appended = count != count0;
+  const bool has_last = incremental && appended;
+  const int nr = has_last ? n_obs - 1 : n_obs;
   __syncthreads();   // B2
 
   // ---- phase 1: three roles
@@ -316,9 +351,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #endif
   if (tid == 0) {
     // -- ambient features (features.py:400-470)
-    auto elev = [&](int64_t when) {
-      const int64_t k = (when - now) / 180 + 240;
-      return (k >= 0 && k < kElevTable && (when - now) % 180 == 0) ? el_table[k] : site_elevation(site, when);
+    auto elev = [&](int64_t when) {          // |when - now| < 2 days: 32-bit arithmetic (a 64-bit / and % cost ~300 instructions)
+      const int32_t d = (int32_t)(when - now);
+      const int32_t q = d / 180;
+      const int32_t k = q + 240;
+      return (k >= 0 && k < kElevTable && d - q * 180 == 0) ? el_table[k] : site_elevation(site, when);
     };
     int64_t sunrise, sunset;
     next_sunrise_sunset_from(elev, sh.el_next < el_now, now, &sunrise, &sunset);
@@ -362,134 +399,81 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
   } else if (wave >= 2 && incremental) {
     if (wave == 2) {
-      // ---- slide the factor: lane owns rows `lane` and `lane + 64`
-      const bool appended = count != count0;
-      const int nn = n_obs - (appended ? 1 : 0);    // rows after the drops; the new observation is window entry nn
-      auto kern = [&](int i) {
-        const double d0 = (sh.loc[nn][0] - sh.loc[i][0]) * (1.0 / 357000.0), d1 = (sh.loc[nn][1] - sh.loc[i][1]) * (1.0 / 357000.0),
-                     d2 = (sh.loc[nn][2] - sh.loc[i][2]) * (1.0 / 326.0), d3 = (sh.loc[nn][3] - sh.loc[i][3]) * (1.0 / 34560.0);
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        return kGpSigma2 * d_exp_fast(r2 > 0.0 ? -(r2 * d_rsqrt(r2)) : 0.0);
-      };
-      // append: new row = (L^-1 k_new)^T, new diagonal = sqrt(k_nn - |row|^2); b = k_new, reduced in place
-      double b0 = (appended && lane < nn) ? kern(lane) : 0.0, b1 = (appended && lane + 64 < nn) ? kern(lane + 64) : 0.0;
-      double ssum = 0.0;
-      double* new_row = sh.L + tri(nn);
-      int n_cur = n_chol0;
-      for (int rep = 0; rep < n_dropped; ++rep) {
-        // K = [k11 k21^T; k21 K22] = Lt D Lt^T with Lt = [1 0; l21 L22], D = diag(d1, D2)
-        //   =>  K22 = L22 D2 L22^T + d1 l21 l21^T : a rank-1 update of the trailing LDL^T factor
-        // (Gill, Golub, Murray, Saunders 1974, method C1) with weight alpha = d1, carried as
-        // gamma = 1 / alpha so that its recurrence is one FMA:  gamma' = gamma + p^2 / d_k.
-        // Per step the sequential chains (w_k -> w_k+1, gamma, and the append's b_k -> b_k+1) hold one
-        // FMA each; the reciprocal is off the chains.  The result is written one row up and one
-        // column left of where L22 was read, which no later read of this sweep touches.  The last
-        // sweep also carries the append's forward substitution (unit lower: no division in it).
-        const bool fuse = appended && rep == n_dropped - 1;
-        const int rows = n_cur - 1;
+      // ---- drop the oldest observation: lane owns rows `lane` and `lane + 64` of the new factor
+      //   K = [k11 k21^T; k21 K22] = Lt D Lt^T with Lt = [1 0; l21 L22], D = diag(d1, D2)
+      //   =>  K22 = L22 D2 L22^T + d1 l21 l21^T : a rank-1 update of the trailing LDL^T factor
+      // (Gill, Golub, Murray, Saunders 1974, method C1) with weight alpha = d1, carried as gamma = 1 / alpha:
+      //   p = L22^-1 l21,  gamma_k = gamma_{k-1} + p_k^2 / d_k,  d'_k = d_k gamma_k / gamma_{k-1},
+      //   beta_k = p_k / (d_k gamma_k),  w^(k+1) = w^(k) - p_k L22[:, k],  L22'[:, k] = L22[:, k] + beta_k w^(k+1).
+      // The forward substitution p = L22^-1 l21 is the only cross-row dependency of the update -- and p is
+      // minus the first column of Lt^-1 below its first entry, i.e. one more right-hand side (e_0) of the
+      // MFMA sweep that the PREVIOUS call ran on this very factor: it was stored next to the factor.  With p known
+      // the gammas are a prefix sum and every row is an independent recurrence over its own columns: 119
+      // wave-synchronous steps of two FMAs per row (was: a 120-step chain of cross-lane broadcasts and
+      // reciprocals, 59 k cycles -- the critical path of the kernel).  The result is written one row up and one
+      // column left of where L22 was read; step k writes column k and reads column k + 1 of the same storage
+      // row, and the loads of step k + 1 are issued before the stores of step k.
+      if (n_dropped == 1) {
+        const int rows = n_chol0 - 1;                                     // == nr
         const bool own0 = lane < rows, own1 = lane + 64 < rows;
-        double w0 = own0 ? sh.L[tri(lane + 1)] : 0.0;          // l21
+        const double dk0 = own0 ? sh.L[tri(lane + 1) + lane + 1] : 1.0, dk1 = own1 ? sh.L[tri(lane + 65) + lane + 65] : 1.0;
+        const double pk0 = own0 ? sh.pb[lane][0] : 0.0, pk1 = own1 ? sh.pb[lane + 64][0] : 0.0;
+        const double idk0 = d_rcp(dk0), idk1 = d_rcp(dk1);
+        const double t0 = pk0 * pk0 * idk0, t1 = pk1 * pk1 * idk1;
+        const double s0 = wave_inclusive_scan(t0, lane);
+        const double s1 = wave_inclusive_scan(t1, lane) + readlane_f64(s0, 63);
+        const double gamma_start = d_rcp(sh.L[0]);                         // 1 / d1 of the dropped row
+        const double gnew0 = gamma_start + s0, gprev0 = gamma_start + (s0 - t0);
+        const double gnew1 = gamma_start + s1, gprev1 = gamma_start + (s1 - t1);
+        const double rg0 = d_rcp(gnew0), rg1 = d_rcp(gnew1);
+        const double dnew0 = dk0 * gnew0 * d_rcp(gprev0), dnew1 = dk1 * gnew1 * d_rcp(gprev1);
+        const double inv0 = idk0 * gprev0 * rg0, inv1 = idk1 * gprev1 * rg1;  // 1 / d'_k
+        double w0 = own0 ? sh.L[tri(lane + 1)] : 0.0;                      // l21
         double w1 = own1 ? sh.L[tri(lane + 65)] : 0.0;
-        // Old row i + 1 shifted one column; lanes that own no row read in-bounds garbage that only
-        // ever reaches their private w / b, which nobody reads (readlane targets owner lanes only).
+        // old row r + 1 shifted one column (lanes that own no row read in-bounds garbage into private registers)
         const double* old0 = sh.L + tri(own0 ? lane + 1 : 1) + 1;
         const double* old1 = sh.L + tri(own1 ? lane + 65 : 1) + 1;
         double* new0 = sh.L + tri(lane);
         double* new1 = sh.L + tri(lane + 64);
-        // what lane k (rows k and k + 64) will write when the sweep is over
-        double diag0 = 1.0, diag1 = 1.0, row0 = 0.0, row1 = 0.0, inv0 = 1.0, inv1 = 1.0;
-        double gamma = d_rcp(sh.L[0]), rg = sh.L[0];            // 1 / alpha and alpha = d1 of the dropped row
-        // loads and the reciprocal of step k + 1 are issued during step k
-        double dk = sh.L[tri(1) + 1], idk = d_rcp(dk);
-        double lik0 = old0[0], lik1 = old1[0];
-        const int first = rows < 64 ? rows : 64;
-        for (int k = 0; k < first; ++k) {                 // rows k .. rows-1 live in both halves
-          const int kn = k + 1 < rows ? k + 1 : k;
-          const double dk_next = sh.L[tri(kn + 1) + kn + 1];
-          const double lik0_next = old0[kn], lik1_next = old1[kn];
-          const double pk = readlane_f64(w0, k);
-          const double gamma_new = d_fma(pk * pk, idk, gamma);
-          const double rg_new = d_rcp(gamma_new);
-          const double inv_dnew = idk * gamma * rg_new;          // 1 / d'_k,  d'_k = d_k gamma' / gamma
-          const double beta = pk * rg_new * idk;
-          w0 = d_fma(-pk, lik0, w0);
-          w1 = d_fma(-pk, lik1, w1);
-          const double n0 = d_fma(beta, w0, lik0), n1 = d_fma(beta, w1, lik1);
+        wave_sync_lds();                                                    // every old diagonal / p has been read
+        if (own0) sh.pb[lane][1] = pk0 * rg0 * idk0;                         // beta_k
+        if (own1) sh.pb[lane + 64][1] = pk1 * rg1 * idk1;
+        wave_sync_lds();
+        const double2* pbv = reinterpret_cast<const double2*>(&sh.pb[0][0]);
+        double2 pbk = pbv[0];
+        double l0 = old0[0], l1 = old1[0];
+        const int first = rows - 1 < 64 ? rows - 1 : 64;                    // row r has columns 0 .. r - 1
+        for (int k = 0; k < first; ++k) {
+          const int kn = k + 1 < rows - 1 ? k + 1 : k;
+          const double2 pb_next = pbv[kn];
+          const double l0_next = old0[kn], l1_next = old1[kn];
+          w0 = d_fma(-pbk.x, l0, w0);
+          w1 = d_fma(-pbk.x, l1, w1);
+          const double n0 = d_fma(pbk.y, w0, l0), n1 = d_fma(pbk.y, w1, l1);
           if (own0 && lane > k) new0[k] = n0;
           if (own1) new1[k] = n1;
-          const double wk = fuse ? readlane_f64(b0, k) : 0.0;    // (Lt'^-1 k_new)_k: final, unit diagonal
-          ssum = d_fma(wk * wk, inv_dnew, ssum);
-          b0 = d_fma(-n0, wk, b0);
-          b1 = d_fma(-n1, wk, b1);
-          const bool mine = lane == k;
-          diag0 = mine ? dk * gamma_new * rg : diag0; row0 = mine ? wk * inv_dnew : row0; inv0 = mine ? inv_dnew : inv0;
-          const double idk_next = d_rcp(dk_next);
-          gamma = gamma_new; rg = rg_new; dk = dk_next; idk = idk_next; lik0 = lik0_next; lik1 = lik1_next;
+          pbk = pb_next; l0 = l0_next; l1 = l1_next;
         }
-        for (int k = 64; k < rows; ++k) {                 // only the upper halves are still live
-          const int kn = k + 1 < rows ? k + 1 : k;
-          const double dk_next = sh.L[tri(kn + 1) + kn + 1];
-          const double lik1_next = old1[kn];
-          const double pk = readlane_f64(w1, k - 64);
-          const double gamma_new = d_fma(pk * pk, idk, gamma);
-          const double rg_new = d_rcp(gamma_new);
-          const double inv_dnew = idk * gamma * rg_new;
-          const double beta = pk * rg_new * idk;
-          w1 = d_fma(-pk, lik1, w1);
-          const double n1 = d_fma(beta, w1, lik1);
+        for (int k = 64; k < rows - 1; ++k) {                               // only the upper halves are still live
+          const int kn = k + 1 < rows - 1 ? k + 1 : k;
+          const double2 pb_next = pbv[kn];
+          const double l1_next = old1[kn];
+          w1 = d_fma(-pbk.x, l1, w1);
+          const double n1 = d_fma(pbk.y, w1, l1);
           if (own1 && lane + 64 > k) new1[k] = n1;
-          const double wk = fuse ? readlane_f64(b1, k - 64) : 0.0;
-          ssum = d_fma(wk * wk, inv_dnew, ssum);
-          b1 = d_fma(-n1, wk, b1);
-          const bool mine = lane + 64 == k;
-          diag1 = mine ? dk * gamma_new * rg : diag1; row1 = mine ? wk * inv_dnew : row1; inv1 = mine ? inv_dnew : inv1;
-          const double idk_next = d_rcp(dk_next);
-          gamma = gamma_new; rg = rg_new; dk = dk_next; idk = idk_next; lik1 = lik1_next;
+          pbk = pb_next; l1 = l1_next;
         }
-        if (own0) { new0[lane] = diag0; if (fuse) { new_row[lane] = row0; sh.inv_diag[lane] = inv0; } }
-        if (own1) { new1[lane + 64] = diag1; if (fuse) { new_row[lane + 64] = row1; sh.inv_diag[lane + 64] = inv1; } }
-        n_cur = rows;
         wave_sync_lds();
+        if (own0) { new0[lane] = dnew0; sh.inv_diag[lane] = inv0; }
+        if (own1) { new1[lane + 64] = dnew1; sh.inv_diag[lane + 64] = inv1; }
+      } else {
+        if (lane < nr) sh.inv_diag[lane] = d_rcp(sh.L[tri(lane) + lane]);
+        if (lane + 64 < nr) sh.inv_diag[lane + 64] = d_rcp(sh.L[tri(lane + 64) + lane + 64]);
       }
-      if (!(appended && n_dropped > 0)) {
-        if (lane < n_cur) sh.inv_diag[lane] = d_rcp(sh.L[tri(lane) + lane]);
-        if (lane + 64 < n_cur) sh.inv_diag[lane + 64] = d_rcp(sh.L[tri(lane + 64) + lane + 64]);
-        wave_sync_lds();
-      }
-      if (appended && n_dropped == 0) {
-        // new row of Lt: (Lt^-1 k_new)_j / d_j; the forward substitution against a unit-lower factor
-        // has no division in its chain
-        const bool in0 = lane < nn, in1 = lane + 64 < nn;
-        const double* lrow0 = sh.L + tri(lane);
-        const double* lrow1 = sh.L + tri(lane + 64);
-        double inv_j = nn > 0 ? sh.inv_diag[0] : 0.0;
-        double l0 = in0 && lane > 0 ? lrow0[0] : 0.0, l1 = in1 ? lrow1[0] : 0.0;
-        for (int j = 0; j < nn; ++j) {
-          const int jn = j + 1 < nn ? j + 1 : j;
-          const double inv_next = sh.inv_diag[jn];
-          const double l0_next = in0 && lane > jn ? lrow0[jn] : 0.0, l1_next = in1 && lane + 64 > jn ? lrow1[jn] : 0.0;
-          const double wj = readlane_f64(j < 64 ? b0 : b1, j & 63);
-          ssum = d_fma(wj * wj, inv_j, ssum);
-          if (lane == 0) new_row[j] = wj * inv_j;
-          if (in0 && lane > j) b0 = d_fma(-l0, wj, b0);
-          if (in1 && lane + 64 > j) b1 = d_fma(-l1, wj, b1);
-          inv_j = inv_next; l0 = l0_next; l1 = l1_next;
-        }
-      }
-      if (appended && lane == 0) {
-        const double dnew = kGpSigma2 + kGpNoise2 - ssum;       // d of the new row
-        new_row[nn] = dnew;
-        sh.inv_diag[nn] = 1.0 / dnew;
-      }
-      // identity padding up to the MFMA tile
-      for (int i = n_obs + lane; i < n_pad; i += 64) {
-        if (i < kGpMax) {
-          double* row = sh.L + tri(i);
-          for (int j = 0; j < i; ++j) row[j] = 0.0;
-          row[i] = 1.0;
-        }
-        sh.inv_diag[i] = 1.0;
-        sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0;
+      // rows nr .. of the MFMA tiles are virtual identity rows; they carry no weight in the sums below
+      for (int i = nr + lane; i < kGpRows; i += 64) {
+        sh.inv_diag[i] = 0.0;
+        if (i >= n_obs) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
       }
     }
   } else if (wave >= 2) {
@@ -639,22 +623,25 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int pad_above = kObsLevels - level_now - 1;
   const double dist = sqrt(x * x + y * y);
   const double to_station_x = -x / (dist + 1e-5), to_station_y = -y / (dist + 1e-5);
+  const int n_pad_s = (nr + 15) & ~15;           // rows of the sweep, padded with virtual identity rows to the MFMA tile
   // -- inverses of the 16 x 16 (unit lower) diagonal blocks of Lt (thread = (block, column): forward substitution)
   if (tid < 128) {
     const int blk = tid >> 4, c = tid & 15, base = blk * 16;
-    if (base < n_pad) {
+    if (base < n_pad_s) {
       double xcol[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         double t = r == c ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) t = d_fma(-(base + r < kGpMax ? sh.L[tri(base + r) + base + k] : 0.0), xcol[k], t);
+        for (int k = 0; k < r; ++k) t = d_fma(-(base + r < nr ? sh.L[tri(base + r) + base + k] : 0.0), xcol[k], t);
         xcol[r] = (r < c) ? 0.0 : t;                          // unit diagonal
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (r >= c) sh.dinv[blk][tri(r) + c] = xcol[r];
     }
+  } else if (tid < 128 + 112) {
+    sh.zero_row[tid - 128] = 0.0;                 // (aliases the (p, beta) pairs of phase 1, dead since B3)
   }
   __syncthreads();
   BLE_MARK();
@@ -662,16 +649,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
-  // -- V = Lt^-1 [y | K*^T] with v_mfma_f64_16x16x4 (K + noise = Lt D Lt^T, Lt unit lower).  Columns: 0, 1 = the two error vectors (so
-  // z = L^-1 y falls out of the same sweep), then ONLY the reachable levels lo_idx .. hi_idx -- the
-  // others are (0, 1, 1) whatever the GP says (features.py:530-536).  Typically 117-126 of the 181
-  // levels are reachable: 8 tiles of 16 columns = two per wave instead of three.  Tile T = 4 round +
-  // wave.  MFMA register layout (measured on gfx950): A lane l holds A[l % 16][l / 16], B lane l
-  // holds B[l / 16][l % 16], D lane l register v holds D[4 v + l / 16][l % 16] -- a D tile is
-  // therefore directly the four B operands of the next product, and V never leaves the registers.
+  // -- V = Lt^-1 [y | k_new | e_0 | K*^T] with v_mfma_f64_16x16x4 (K + noise = Lt D Lt^T, Lt unit lower, nr rows).
+  // Columns 0, 1 = the two error vectors (zeta = Lt^-1 y); 2 = the kernel between the newest observation and the
+  // older ones -- it sits AT the query column, so that is K* for the "level" p_balloon -- whose solution is the
+  // bordering row of the factor; 3 = e_0, whose solution is next call's drop vector; then ONLY the reachable
+  // levels lo_idx .. hi_idx -- the others are (0, 1, 1) whatever the GP says (features.py:530-536).  Typically
+  // 117-124 of the 181 levels are reachable: 8 tiles of 16 columns = two per wave.  Tile T = 4 round + wave.
+  // MFMA register layout (measured on gfx950): A lane l holds A[l % 16][l / 16], B lane l holds
+  // B[l / 16][l % 16], D lane l register v holds D[4 v + l / 16][l % 16] -- a D tile is therefore directly
+  // the four B operands of the next product, and V never leaves the registers.
   typedef double d4 __attribute__((ext_vector_type(4)));
   const int g = lane >> 4, jq = lane & 15;
-  const int nb = n_pad >> 4;
+  const int nb = n_pad_s >> 4;
   int lo_idx = (int)((p_lo - 5000.0) * (1.0 / 50.0)), hi_idx = (int)((p_hi - 5000.0) * (1.0 / 50.0));
   lo_idx = lo_idx < 0 ? 0 : (lo_idx > 181 ? 181 : lo_idx);
   hi_idx = hi_idx < -1 ? -1 : (hi_idx > 180 ? 180 : hi_idx);
@@ -680,7 +669,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   while (hi_idx < 180 && 5000.0 + 50.0 * (double)(hi_idx + 1) <= p_hi) ++hi_idx;
   while (hi_idx >= 0 && 5000.0 + 50.0 * (double)hi_idx > p_hi) --hi_idx;
   const int n_reach = hi_idx >= lo_idx ? hi_idx - lo_idx + 1 : 0;
-  const int n_tiles = (2 + n_reach + 15) >> 4;                                       // 1 .. 12
+  constexpr int kSpecial = 4;
+  const int n_tiles = (kSpecial + n_reach + 15) >> 4;                                // 1 .. 12
   // Each wave sweeps its tiles {wave, wave + 4, wave + 8} TOGETHER (independent accumulators keep the
   // matrix pipe busy); NT = 2 of them when <= 8 tiles are active (the usual case), else 3.
   auto sweep = [&](auto nt_tag) {
@@ -691,8 +681,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       col[t] = 16 * (4 * t + wave) + jq;
-      level[t] = 5000.0 + 50.0 * (double)(lo_idx + col[t] - 2);
+      level[t] = 5000.0 + 50.0 * (double)(lo_idx + col[t] - kSpecial);
     }
+    if (wave == 0 && jq == 2) level[0] = p;         // column 2: the newest observation's own pressure
+    const double y_last_u = sh.z[0][nr], y_last_v = sh.z[1][nr];   // raw errors of the newest observation (z is overwritten below)
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
 #pragma unroll
@@ -701,7 +693,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         d4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        const double* arow = (16 * I + jq < kGpMax ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
+        const double* arow = (16 * I + jq < nr ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
 #pragma unroll
         for (int J = 0; J < I; ++J)
 #pragma unroll
@@ -715,7 +707,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
           const double a_row = sh.a[row], p_row = sh.loc[row][2];
-          const double live = row < n_obs ? kGpSigma2 : 0.0;
+          const double live = row < nr ? kGpSigma2 : 0.0;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused)
@@ -723,7 +715,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             const double r2 = a_row + dp * dp;
             R[t][v] = live * d_exp_fast(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)));
           }
-          if (wave == 0) R[0][v] = jq == 0 ? sh.z[0][row] : (jq == 1 ? sh.z[1][row] : R[0][v]);   // uniform branch: tile 0
+          if (wave == 0) {                                    // uniform branch: tile 0 holds the special columns
+            const double y0 = row < nr ? sh.z[0][row] : 0.0, y1 = row < nr ? sh.z[1][row] : 0.0;
+            const double e0 = row == 0 && nr > 0 ? 1.0 : 0.0;
+            R[0][v] = jq == 0 ? y0 : (jq == 1 ? y1 : (jq == 3 ? e0 : R[0][v]));
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
         }
@@ -737,16 +733,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       }
     }
     __syncthreads();                 // wave 0 has read the raw error vectors
-    if (wave == 0 && jq < 2) {       // columns 0, 1 of tile 0
+    if (wave == 0 && jq < kSpecial) {       // the special columns of tile 0
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
         for (int v = 0; v < 4; ++v) sh.z[jq][16 * I + 4 * v + g] = V[0][I][v];
     }
     __syncthreads();
-    double ssq[NT], mean_u[NT], mean_v[NT];
+    // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
+    // the same sum against omega = Lt^-1 k_new
+    double ssq[NT], mean_u[NT], mean_v[NT], cross[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { ssq[t] = 0.0; mean_u[t] = 0.0; mean_v[t] = 0.0; }
+    for (int t = 0; t < NT; ++t) { ssq[t] = 0.0; mean_u[t] = 0.0; mean_v[t] = 0.0; cross[t] = 0.0; }
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
       if (I < nb) {
@@ -754,13 +752,14 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
           const double inv_d = sh.inv_diag[row];
-          const double zu = sh.z[0][row] * inv_d, zv = sh.z[1][row] * inv_d;
+          const double zu = sh.z[0][row] * inv_d, zv = sh.z[1][row] * inv_d, zw = sh.z[2][row] * inv_d;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const double val = V[t][I][v];                // (Lt^-1 k*)_row
-            ssq[t] = d_fma(val * val, inv_d, ssq[t]);     // k* K^-1 k* = sum w^2 / d
-            mean_u[t] = d_fma(val, zu, mean_u[t]);        // k* K^-1 y  = sum w zeta / d,  zeta = Lt^-1 y
+            ssq[t] = d_fma(val * val, inv_d, ssq[t]);
+            mean_u[t] = d_fma(val, zu, mean_u[t]);
             mean_v[t] = d_fma(val, zv, mean_v[t]);
+            cross[t] = d_fma(val, zw, cross[t]);
           }
         }
       }
@@ -770,20 +769,47 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       ssq[t] += __shfl_xor(ssq[t], 16, 64); ssq[t] += __shfl_xor(ssq[t], 32, 64);
       mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
       mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
+      cross[t] += __shfl_xor(cross[t], 16, 64); cross[t] += __shfl_xor(cross[t], 32, 64);
     }
+    // ---- the bordering row (the newest observation, window entry nr): Lt_full = [Lt 0; r^T 1], r = omega / d,
+    //   d_new = k_nn + noise - sum omega^2 / d,   (Lt_full^-1 b)_last = b_last - sum_i r_i (Lt^-1 b)_i
+    if (wave == 0 && g == 0 && jq < kSpecial) {
+      const double last = jq == 0 ? y_last_u - cross[0]                 // zeta_u of the newest observation
+                        : jq == 1 ? y_last_v - cross[0]
+                        : jq == 2 ? (kGpSigma2 + kGpNoise2) - ssq[0]     // d of the new row
+                                  : -cross[0];                          // (Lt_full^-1 e_0)_last
+      sh.last[jq] = last;
+    }
+    // new row of the factor and next call's drop vector, straight from the solved columns
+    if (has_last) {
+      for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i] * sh.inv_diag[i];
+    }
+    __syncthreads();
+    if (has_last && tid == 0) sh.L[tri(nr) + nr] = sh.last[2];
+    if (chol_g != nullptr) {          // p = -(Lt_full^-1 e_0)[1:]
+      for (int i = tid; i + 1 < n_obs; i += kObsBlock)
+        chol_g[kCholTri + i] = (i + 1 < nr) ? -sh.z[3][i + 1] : -sh.last[3];
+    }
+    const double inv_dn = has_last ? 1.0 / sh.last[2] : 0.0;
+    const double zl_u = has_last ? sh.last[0] * inv_dn : 0.0, zl_v = has_last ? sh.last[1] * inv_dn : 0.0;
     {
       // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int level_idx = lo_idx + col[t] - 2;
-        if (g != t || col[t] < 2 || level_idx > hi_idx) continue;
+        const int level_idx = lo_idx + col[t] - kSpecial;
+        if (g != t || col[t] < kSpecial || level_idx > hi_idx) continue;
+        // the newest observation's row: K*(level, newest) = s^2 exp(-|level - p| / 326) (same x, y, t as the query)
+        const double dpl = (level[t] - p) * (1.0 / 326.0);
+        const double val_last = kGpSigma2 * d_exp_fast(-__builtin_fabs(dpl)) - cross[t];
+        const double ss = d_fma(val_last * val_last, inv_dn, ssq[t]);
+        const double mu = d_fma(val_last, zl_u, mean_u[t]), mv = d_fma(val_last, zl_v, mean_v[t]);
         // forecast at this level from the blended column
         int ip; float wp;
         wind_axis((float)level[t], 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
         const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
         const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
-        const double u = mean_u[t] + (double)fu, v = mean_v[t] + (double)fv;
-        double var = kGpSigma2 - ssq[t];
+        const double u = mu + (double)fu, v = mv + (double)fv;
+        double var = kGpSigma2 - ss;
         var = var < 0.0 ? 0.0 : var;
         const double deviation = n_obs > 0 ? var / kGpSigma2 : 0.0;     // wind_gp.py:166-168
         const double speed = sqrt(u * u + v * v);
@@ -821,6 +847,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
 #endif
   // the factor of this window goes back to HBM for the next call
+  __syncthreads();                                 // the bordering row is in LDS
   if (chol_g != nullptr) {
     const int pairs = (tri(n_obs) + 1) >> 1;       // (an odd tail stores one unused double inside the slab)
     for (int e2 = tid; e2 < pairs; e2 += kObsBlock) reinterpret_cast<double2*>(chol_g)[e2] = reinterpret_cast<const double2*>(sh.L)[e2];

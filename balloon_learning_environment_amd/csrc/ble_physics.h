@@ -357,18 +357,25 @@ BLE_FN double atm_height_f64c(int i) {
     case 4: return 47000.0; case 5: return 51000.0; case 6: return 71000.0; default: return 85000.0;
   }
 }
-BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
+// The alpha-only part of the window: lapse rates of layers 0-2 and the two transitions (17 km, 21 km) that
+// bound every pressure a flying balloon can reach -- two pows; constant over an episode, so the fused
+// multi-step kernel evaluates it once per launch.
+struct AtmBase { double l0, l1, l2, t1, p1, t2, p2; };
+BLE_FN AtmBase atm_base(double alpha) {
+  const double g = 9.80665;
+  AtmBase b;
+  b.l0 = atm_lapse_f64(0, alpha); b.l1 = atm_lapse_f64(1, alpha); b.l2 = atm_lapse_f64(2, alpha);
+  b.t1 = 300.0 + b.l0 * (17000.0 - -610.0);
+  b.p1 = 108870.8213 * d_pow_fast(b.t1 * (1.0 / 300.0), -g * d_rcp(kAirSpecificGasD * b.l0));
+  b.t2 = b.t1 + b.l1 * (21000.0 - 17000.0);
+  b.p2 = b.p1 * d_pow_fast(b.t2 * d_rcp(b.t1), -g * d_rcp(kAirSpecificGasD * b.l1));
+  return b;
+}
+BLE_FN AtmWindow atm_window_from(const AtmBase& b, double alpha, double p, uint32_t* flags) {
   const double g = 9.80665;
   AtmWindow w;
   *flags |= !(p <= 108870.8213) ? kFlagPressureRange : 0u;
-  // Layers 0 and 1 (ground .. 17 km .. 21 km) hold every pressure a flying balloon can
-  // reach; their transition pressures are computed unconditionally (two pows, no
-  // divergence), the layers above only if a lane really is up there.
-  const double l0 = atm_lapse_f64(0, alpha), l1 = atm_lapse_f64(1, alpha), l2 = atm_lapse_f64(2, alpha);
-  const double t1 = 300.0 + l0 * (17000.0 - -610.0);
-  const double p1 = 108870.8213 * d_pow_fast(t1 * (1.0 / 300.0), -g * d_rcp(kAirSpecificGasD * l0));
-  const double t2 = t1 + l1 * (21000.0 - 17000.0);
-  const double p2 = p1 * d_pow_fast(t2 * d_rcp(t1), -g * d_rcp(kAirSpecificGasD * l1));
+  const double l0 = b.l0, l1 = b.l1, l2 = b.l2, t1 = b.t1, p1 = b.p1, t2 = b.t2, p2 = b.p2;
   const bool in0 = p > p1;
   w.i0 = in0 ? 0 : 1;
   w.pb = in0 ? 108870.8213 : p1; w.pt = in0 ? p1 : p2;
@@ -398,6 +405,9 @@ BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
   }
   w.r_pb = d_rcp(w.pb); w.r_pt = d_rcp(w.pt);
   return w;
+}
+BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
+  return atm_window_from(atm_base(alpha), alpha, p, flags);
 }
 // height and temperature at p inside layer i0 of the window (standard_atmosphere.py:135-150)
 BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, double* height, double* temperature) {
@@ -904,8 +914,8 @@ BLE_FN SunState sun_fast(float oms, bool* near) {
   r.day = cor.sin_el > kSinMinSolarEl;
   r.sh33 = cor.sin_el >= kSinShadow33;
   r.sh27 = cor.sin_el >= kSinShadow27;
-  *near = (fabsf(cor.sin_el - kSinMinSolarEl) < kSunBand) | (fabsf(cor.sin_el - kSinShadow33) < kSunBand) |
-          (fabsf(cor.sin_el - kSinShadow27) < kSunBand) | (fabsf(unc.sin_el - kSin5) < kSunBand);
+  *near = f_min(f_min(fabsf(cor.sin_el - kSinMinSolarEl), fabsf(cor.sin_el - kSinShadow33)),
+                f_min(fabsf(cor.sin_el - kSinShadow27), fabsf(unc.sin_el - kSin5))) < kSunBand;
   return r;
 }
 // solar.solar_calculator on BalloonState.latlng in fp64 (the oracle's chain op for op), cold.
@@ -973,8 +983,8 @@ BLE_FN double d_inv_root10(double a) {
 //   rt = T_amb^(-1/2)                       ->  rho / mu = p (M/R) (T + 110.4) rt^5 / 1.458e-6,  1/T = rt^2
 //   Ra^(1/4) = Ra (Ra^(-1/4))^3,  (T/273.15)^0.9 = T T^(-1/10) / 273.15^0.9
 // Only (1 + 2.69e-8 Ra)^(1/12) -- a term of ~2 next to 0.457 Ra^(1/4) ~ 300 -- stays an fp32 pow.
-// q_solar_area = flux * attenuation * 0.25 * absorptivity [W/m^2] (fp32: the solar geometry's own
-// floor), q_earth_area = earth_heat_per_area(IR) (per-episode constant).
+// q_solar_area = flux * attenuation * 0.25 * absorptivity [W/m^2] (the transition passes an fp32 product: the
+// solar geometry's own floor), q_earth_area = earth_heat_per_area(IR) (per-episode constant).
 constexpr double kStefanBoltzmannD = 0.000000056704;
 BLE_FN double total_absorptivity_d(double a) { return a * d_fma(-a, 1.0 / (1.0 - 0.0291), 2.0); }   // a (1 + (1-a-r)/(1-r))
 BLE_FN double earth_heat_per_area_f64(double upwelling_ir, uint32_t* flags) {   // thermal.py:209-213
@@ -983,7 +993,8 @@ BLE_FN double earth_heat_per_area_f64(double upwelling_ir, uint32_t* flags) {   
   *flags |= (f < 0.0 || f > 1.0) ? kFlagAbsorptivity : 0u;
   return upwelling_ir * 0.4605 * f;
 }
-BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double t_amb, double p, float q_solar_area,
+template <bool kExactTwelfthRoot = false>
+BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double t_amb, double p, double q_solar_area,
                                     double q_earth_area) {
   constexpr double kR2 = 0.38483473658887897;          // (3 / (4 pi))^(2/3)
   constexpr double kR1 = 0.62035049089940009;          // (3 / (4 pi))^(1/3)
@@ -1001,11 +1012,14 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
   ra = d_max(ra, 1e-30);
   const double y4 = d_inv_root4(ra);
   const double ra14 = (ra * y4) * (y4 * y4);
-  const double tw = (double)f_pow((float)d_fma(2.69e-8, ra, 1.0), 1.0f / 12.0f);
+  // (the cold-start Newton of the reset / observation kernels converges on differences of this function:
+  // there the twelfth root is fp64 too)
+  const double tw = kExactTwelfthRoot ? d_pow_fast(d_fma(2.69e-8, ra, 1.0), 1.0 / 12.0)
+                                      : (double)f_pow((float)d_fma(2.69e-8, ra, 1.0), 1.0f / 12.0f);
   const double nusselt = d_fma(0.457, ra14, 2.0 + tw);
   constexpr double kCond = 0.0241 * 0.006415624181362592;   // 0.0241 / 273.15^0.9
   const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb)) * yc)) * dt;
-  const double q = ((double)q_solar_area + q_earth_area) + (q_conv - q_emit);
+  const double q = (q_solar_area + q_earth_area) + (q_conv - q_emit);
   return (q * v23) * (10.0 * 4.0 * kPiD * kR2 / (1500.0 * 68.5));
 }
 
@@ -1067,6 +1081,38 @@ BLE_FN double acs_efficiency_f64(const float* tab, double prm1, double power) {
   const double z00 = (double)r0[0], z01 = (double)r0[1], z10 = (double)r0[13], z11 = (double)r0[14];
   const double lo = d_fma(wx, z01 - z00, z00), hi = d_fma(wx, z11 - z10, z10);
   return d_fma(wy, hi - lo, lo);
+}
+
+// The ACS's DOWN branch as the transition evaluates it: power W(pr) = get_most_efficient_power and mass flow
+// eff(pr, W(pr)) W(pr) / 3600 (balloon.py:500-510).  Along the curve W(pr) the bilinear efficiency table is a
+// piecewise polynomial of pr alone: every power node (100 / 200 / 300 / 400 W) is reached exactly at a
+// pressure-ratio node (1.05 / 1.125 / 1.2 / 1.25), so inside each of the 12 ratio intervals W is linear, both
+// interpolation weights are linear and the mass flow is a cubic.  Entry i: c0..c3 of the mass flow [kg/s] and
+// w0, w1 of the power [W] in t = prm1 - (0.05 + 0.025 i), t clamped to [0, 0.025] (flat outside the table,
+// acs.py:44-68 `fill_value=None` / the flat end segments of the power curve).  Identical to the two-table
+// form to 1e-16 (tests: probe vs oracle); 3 LDS reads + 5 FMAs instead of two dependent table walks.
+constexpr int kAcsPolyDoubles = 12 * 6;
+BLE_FN void acs_build_poly(const float* tab, int i, double* c) {
+  const double x0 = 0.05 + 0.025 * (double)i;
+  const double w0 = acs_power_f64(x0), w1 = (acs_power_f64(x0 + 0.025) - w0) * 40.0;
+  const double wm = acs_power_f64(x0 + 0.0125);
+  int iy = (int)d_max(d_min((wm - 100.0) * 0.01, 3.0), 0.0); iy = iy > 2 ? 2 : iy;
+  const double a0 = (w0 - 100.0) * 0.01 - (double)iy, a1 = w1 * 0.01;
+  const double z00 = (double)tab[iy * 13 + i], z01 = (double)tab[iy * 13 + i + 1];
+  const double z10 = (double)tab[iy * 13 + 13 + i], z11 = (double)tab[iy * 13 + 14 + i];
+  const double l0 = z00, l1 = (z01 - z00) * 40.0, h0 = z10, h1 = (z11 - z10) * 40.0;
+  const double e0 = l0 + a0 * (h0 - l0), e1 = l1 + a0 * (h1 - l1) + a1 * (h0 - l0), e2 = a1 * (h1 - l1);
+  c[0] = e0 * w0 * (1.0 / 3600.0); c[1] = (e0 * w1 + e1 * w0) * (1.0 / 3600.0);
+  c[2] = (e1 * w1 + e2 * w0) * (1.0 / 3600.0); c[3] = e2 * w1 * (1.0 / 3600.0);
+  c[4] = w0; c[5] = w1;
+}
+BLE_FN void acs_down_poly(const double* poly, double prm1, double* power_w, double* mdot) {
+  int i = (int)((prm1 - 0.05) * 40.0);             // truncation: [-1, 1) -> 0
+  i = i < 0 ? 0 : (i > 11 ? 11 : i);
+  const double t = d_max(d_min(prm1 - d_fma(0.025, (double)i, 0.05), 0.025), 0.0);
+  const double* c = poly + 6 * i;
+  *mdot = d_fma(d_fma(d_fma(c[3], t, c[2]), t, c[1]), t, c[0]);
+  *power_w = d_fma(c[5], t, c[4]);
 }
 
 // power_table.lookup (power_table.py:21-38)

@@ -87,24 +87,12 @@ BLE_FN double solar_attenuation_f64(double el_deg, double p) {   // solar.py:177
   const double airmass = 0.34764 * (p / 101325.0) * (sqrt(1229.0 + t * t) - t);
   return 0.5 * (d_exp_fast(-0.65 * airmass) + d_exp_fast(-0.95 * airmass));
 }
-BLE_FN double total_absorptivity_f64(double a) { return a * (1.0 + (1.0 - a - 0.0291) / (1.0 - 0.0291)); }
-BLE_FN double thermal_dtdt_f64(double volume, double t_int, double t_amb, double p, double att, double flux, double ir) {
-  const double sb = 0.000000056704;
-  const double radius = d_pow_fast(3 * volume / (4 * kPiD), 1.0 / 3);
-  const double area = 4 * kPiD * radius * radius;
-  const double q_solar = flux * att * 0.25 * area * total_absorptivity_f64(0.01435);
-  const double q_earth = ir * 0.4605 * area * total_absorptivity_f64(0.04587 + 0.000232 * (d_pow_fast(ir / sb, 0.25) - 210));
-  const double q_emit = sb * (t_int * t_int) * (t_int * t_int) * area * total_absorptivity_f64(0.04587 + 0.000232 * (t_int - 210));
-  const double visc = 1.458e-6 * (t_amb * sqrt(t_amb)) / (t_amb + 110.4);
-  const double cond = 0.0241 * d_pow_fast(t_amb / 273.15, 0.9);
-  const double prandtl = 0.804 - 3.25e-4 * t_amb;
-  const double rho = p * kAirMolarMassD / (kGasConstantD * t_amb);
-  const double dia = 2 * radius;
-  const double grashof = (9.80665 * rho * rho * dia * dia * dia / (t_amb * visc * visc)) * fabs(t_amb - t_int);
-  const double ra = prandtl * grashof;
-  const double nusselt = 2 + 0.457 * sqrt(sqrt(ra)) + d_pow_fast(1 + 2.69e-8 * ra, 1.0 / 12.0);
-  const double q_conv = area * (nusselt * cond / dia) * (t_amb - t_int);
-  return (q_solar + q_earth + q_conv - q_emit) / (1500 * 68.5);
+// d_balloon_temperature_dt for the cold start: the transition's pow-free fp64 model (ble_physics.h), with the
+// twelfth root in fp64 as well.  yc = V^(-1/3).
+BLE_FN double thermal_dtdt_f64(double volume, double yc, double t_int, double t_amb, double p, double att, double flux,
+                               double q_earth_area) {
+  constexpr double kSolarAbs = 0.01435 * (1.0 + (1.0 - 0.01435 - 0.0291) / (1.0 - 0.0291));
+  return 0.1 * thermal_increment_f64<true>(volume, yc, t_int, t_amb, p, flux * att * (0.25 * kSolarAbs), q_earth_area);
 }
 struct StableParams { double t_amb, t_int, mols_air, volume, sp; };
 BLE_FN StableParams stable_params(double alpha, double p, double el_deg, double flux, double ir, uint32_t* flags) {
@@ -118,10 +106,13 @@ BLE_FN StableParams stable_params(double alpha, double p, double el_deg, double 
   const double att = solar_attenuation_f64(el_deg, p);
   double ti = 206.0;
   const double delta = 0.01;
+  constexpr double kInvCbrt1804 = 0.08214626507693945;     // 1804^(-1/3)
+  uint32_t ignored = 0;                                     // total_absorptivity of the Earth term: checked by the transition
+  const double q_earth = earth_heat_per_area_f64(ir, &ignored);
 #pragma unroll 1
   for (int k = 0; k < 10; ++k) {
-    const double d1 = thermal_dtdt_f64(1804.0, ti - delta / 2, o.t_amb, p, att, flux, ir);
-    const double d2 = thermal_dtdt_f64(1804.0, ti + delta / 2, o.t_amb, p, att, flux, ir);
+    const double d1 = thermal_dtdt_f64(1804.0, kInvCbrt1804, ti - delta / 2, o.t_amb, p, att, flux, q_earth);
+    const double d2 = thermal_dtdt_f64(1804.0, kInvCbrt1804, ti + delta / 2, o.t_amb, p, att, flux, q_earth);
     const double d2t = (d2 - d1) / delta;
     const double mean = (d1 + d2) / 2.0;
     if (fabs(d2t) > 0.0) ti -= mean / d2t;

@@ -28,18 +28,30 @@ struct EnvConst {
   float lat0_deg, lng0_deg, ir, alpha;
   int64_t start_unix;
 };
+// What depends on the per-episode constants only: evaluated once per launch by the fused multi-step
+// kernel (two pows, one sincos per agent step otherwise).
+struct EnvHoisted {
+  AtmBase atm;
+  double sin_lat0, cos_lat0;
+};
+BLE_FN EnvHoisted hoist_constants(const EnvConst& c) {
+  EnvHoisted h;
+  h.atm = atm_base((double)c.alpha);
+  sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &h.sin_lat0, &h.cos_lat0);
+  return h;
+}
 
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
 // The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
 // blend happens after the per-step constants so that the gather's latency is covered.
-BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorners& corners, const WindQuery& wq,
-                      float noise_u, float noise_v, int substeps, const float* acs_table, float* reward,
+BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int action, const WindCorners& corners, const WindQuery& wq,
+                      float noise_u, float noise_v, int substeps, const double* acs_poly, float* reward,
                       uint32_t* flags) {
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   const float p0_in = s.p;
   double p = (double)s.p;
-  const AtmWindow win = atm_window((double)c.alpha, p, flags);
+  const AtmWindow win = atm_window_from(hc.atm, (double)c.alpha, p, flags);
   double altitude, t_at_p;
   atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
   int lay = 0;                                   // p is in the window's centre layer by construction
@@ -79,8 +91,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     const double ch = d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
     const double sb1 = sb0 * ch + cb0 * sh, cb1 = cb0 * ch - sb0 * sh;
     const double sb2 = sb1 * ch + cb1 * sh, cb2 = cb1 * ch - sb1 * sh;
-    double sl0, cl0;
-    sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &sl0, &cl0);
+    const double sl0 = hc.sin_lat0, cl0 = hc.cos_lat0;
     const double x0 = (double)s.x, y0 = (double)s.y;
     const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
     // (sin, cos) of the declination as an exactly normalised fp64 pair: with the fp32 pair
@@ -103,6 +114,9 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     const float fkk = (float)kk;
     bool near;
     SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
+#ifdef BLE_WHATIF_NO_BAND
+    near = false;
+#endif
     if (__builtin_expect(near, 0)) {
       const double dk = 10.0 * (double)kk;
       r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)s.x), d_fma(dk, (double)v, (double)s.y),
@@ -130,7 +144,11 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
     const float fk = (float)k;
+#ifdef BLE_WHATIF_NO_SUN
+    SunState sun; sun.sin_el = 0.5f + 1e-3f * fk; sun.cos_el = 0.8f; sun.day = true; sun.sh33 = false; sun.sh27 = false;
+#else
     const SunState sun = sun_at(k);
+#endif
     const float flux = f_fma(fk, dfl, fl0);
 
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
@@ -151,7 +169,11 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-    const double t_int_new = t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (flux * att) * (0.25f * kSolarAbsorptivityTotal), q_earth);
+#ifdef BLE_WHATIF_NO_THERMAL
+    const double t_int_new = t_int + 1e-3 * (double)(flux * att);
+#else
+    const double t_int_new = t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth);
+#endif
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
@@ -163,18 +185,22 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, int action, const WindCorne
     // mass flow changes rho V - m by ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified
     // like the thermal increment's.
     double mdot_d;
+#ifdef BLE_WHATIF_NO_ACS
+    mdot_d = eff == kUp ? -0.01 : (eff == kDown ? 0.01 : 0.0); acs_w = eff == kDown ? 200.0f : 0.0f; mdot = (float)mdot_d;
+#else
     {
       constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
       // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
       const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
       const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
       const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
-      const double w_down = acs_power_f64(prm1);
-      const double mdot_down = acs_efficiency_f64(acs_table, prm1, w_down) * w_down * (1.0 / 3600.0);
+      double w_down, mdot_down;
+      acs_down_poly(acs_poly, prm1, &w_down, &mdot_down);
       acs_w = eff == kDown ? (float)w_down : 0.0f;
       mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
       mdot = (float)mdot_d;
     }
+#endif
     double n_air_new = d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air);
     n_air_new = d_max(n_air_new, 0.0);
 

@@ -207,7 +207,7 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
  */
 #define BLE_OBS_DIM 1099
 #define BLE_GP_CAPACITY 128
-#define BLE_GP_CHOL_STRIDE 7260 /* 120 * 121 / 2 doubles */
+#define BLE_GP_CHOL_STRIDE 7380 /* 120 * 121 / 2 doubles (packed factor) + 120 (the drop vector of the next slide) */
 typedef struct ble_gp_history_f32 {
   float* xyp;         /* [n][BLE_GP_CAPACITY][3]  x m, y m, pressure Pa */
   int32_t* elapsed_s; /* [n][BLE_GP_CAPACITY]     time_elapsed of the observation */

@@ -14,6 +14,8 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
                              const float* wind_uv, float* reward, uint8_t* terminal, uint8_t* effective_action,
                              uint32_t* err_flags, int64_t n, int substeps) {
   uint32_t flags_all = 0;
+  double acs_poly[kAcsPolyDoubles];
+  for (int k = 0; k < 12; ++k) acs_build_poly(kAcsEfficiency, k, acs_poly + 6 * k);
   for (int64_t i = 0; i < n; ++i) {
     if (st->status[i] != kOk) { reward[i] = 0.0f; terminal[i] = 1; if (effective_action) effective_action[i] = action[i]; continue; }
     EnvRegs s;
@@ -34,7 +36,7 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
       wind_gather(wind_grid, wq, &wc);
     }
     uint32_t flags = 0; float r;
-    int eff = agent_step(s, c, action[i], wc, wq, nu, nv, substeps, kAcsEfficiency, &r, &flags);
+    int eff = agent_step(s, c, hoist_constants(c), action[i], wc, wq, nu, nv, substeps, acs_poly, &r, &flags);
     flags_all |= flags;
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
     st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;
