@@ -74,6 +74,8 @@ struct ObsShared {
   double loc[kGpRows][4];                // x, y, p, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
+  double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
+  double exp2_frac[32];                  // 2^(j / 32): exp(x) = 2^k * 2^(j/32) * P5(r), |r| <= ln2 / 64
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20], sp[22];
@@ -86,6 +88,19 @@ struct ObsShared {
   float role_t[3];
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
+
+// exp(x) for the kernel matrix K* (x = -distance <= 0): x = (32 k + j) ln2 / 32 + r, table of 2^(j/32) in LDS,
+// degree-5 Taylor in r (|r| <= ln2 / 64: truncation 2e-15).  15 instructions and 6 constants instead of the
+// 20 + 16 of the table-free d_exp_fast -- the sweep evaluates it 64 times per lane.
+__device__ __forceinline__ double exp_tab(double x, const double* tab) {
+  const double n = d_rint(x * 46.16624130844682903);                 // 32 / ln 2
+  double r = d_fma(n, -2.16608493865351192653e-02, x);               // ln2 / 32 hi (low bits zero)
+  r = d_fma(n, -5.96317165397058656257e-12, r);                      // ln2 / 32 lo
+  const int ni = (int)n;
+  const double t = tab[ni & 31];
+  const double pr = d_fma(r, d_fma(r, d_fma(r, d_fma(r, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  return d_ldexp(t * d_fma(r, pr, 1.0), ni >> 5);
+}
 
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
@@ -179,7 +194,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #endif
   BLE_MARK();
   const int64_t env = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: `if (wave == ...)` is a real branch, not an exec mask
 #ifdef BLE_OBS_STAGGER
   // Two workgroups share a CU and each runs VALU/MFMA-heavy phases (solar table, sweep) and latency-bound
   // single-wave phases in sequence.  Launched together they stay in lockstep for the whole grid -- both in
@@ -257,14 +273,52 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
 
   // ---- phase 0b: solar elevation table, search levels, pressure column
+  // The table needs the solar elevation at 721 instants 180 s apart.  The time-only half of the solar
+  // calculator (declination, equation of time: five sincos) varies on the scale of days: it is evaluated
+  // exactly at 6 nodes 7.2 h apart (lanes 0..5) and interpolated (degree 5, Newton forward form; error
+  // |f^(6)| h^6 17 / 720 ~ 2e-16) -- only the site half (hour angle, zenith, refraction) runs per entry.
   double* el_table = sh.el_table;
-  for (int k = tid; k < kElevTable; k += kObsBlock) {
+  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
+  if (tid < 6) {
+    double jc, frac;
+    unix_day_fraction(now - 43200 + 25920 * (int64_t)tid, &jc, &frac);
+    const SolarEphemeris e = solar_ephemeris_f64(jc);
+    sh.eph[tid][0] = e.sin_decl; sh.eph[tid][1] = e.cos_decl; sh.eph[tid][2] = e.eot_quarter_deg;
+  } else if (tid == 6) {
     double flux;
-    const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, now + 180 * (int64_t)(k - 240), &flux);
-    el_table[k] = el;
-    if (k == 240) { sh.el_now = el; sh.flux_now = flux; }
+    sh.el_now = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, now, &flux);
+    sh.flux_now = flux;
+  } else if (tid == kObsBlock - 1) {
+    sh.el_next = site_elevation(site, now + 1);
   }
-  if (tid == kObsBlock - 1) sh.el_next = site_elevation(site, now + 1);
+  __syncthreads();
+  {
+    double dd[3][6];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) dd[f][j] = sh.eph[j][f];
+#pragma unroll
+      for (int lvl = 1; lvl < 6; ++lvl)
+#pragma unroll
+        for (int j = 5; j >= lvl; --j) dd[f][j] -= dd[f][j - 1];          // forward differences, in place
+    }
+    int64_t days0 = now / 86400;
+    int32_t sod_now = (int32_t)(now - days0 * 86400);
+    if (sod_now < 0) sod_now += 86400;
+    for (int k = tid; k < kElevTable; k += kObsBlock) {
+      const double u = (double)k * (1.0 / 144.0);                          // (t_k - t_0) / 25 920 s
+      const double w2 = (u - 1.0) * 0.5, w3 = (u - 2.0) * (1.0 / 3.0), w4 = (u - 3.0) * 0.25, w5 = (u - 4.0) * 0.2;
+      double val[3];
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+        val[f] = d_fma(u, d_fma(w2, d_fma(w3, d_fma(w4, d_fma(w5, dd[f][5], dd[f][4]), dd[f][3]), dd[f][2]), dd[f][1]), dd[f][0]);
+      int32_t sod = sod_now + 180 * (k - 240);
+      sod = sod < 0 ? sod + 86400 : sod;                                   // |offset| <= 86 400 s
+      sod = sod >= 86400 ? sod - 86400 : sod;
+      el_table[k] = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
+    }
+  }
   const double l0 = atm_lapse_f64(0, alpha);
   const double p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
   if (wave == 3 && lane < 20) {
@@ -349,16 +403,30 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #ifdef BLE_OBS_TIMING
   const long long role_t0 = (long long)__builtin_readcyclecounter();
 #endif
-  if (tid == 0) {
-    // -- ambient features (features.py:400-470)
+  if (wave == 0) {
+    // -- ambient features (features.py:400-470).  solar.get_next_sunrise_sunset (solar.py:432-483) is two
+    //    pairs of independent searches -- (noon, midnight), then (sunrise, sunset): each pair runs on lanes
+    //    0 / 1 at once (same code, different bounds), the bounds of the second pair come by shuffle.
     auto elev = [&](int64_t when) {          // |when - now| < 2 days: 32-bit arithmetic (a 64-bit / and % cost ~300 instructions)
       const int32_t d = (int32_t)(when - now);
       const int32_t q = d / 180;
       const int32_t k = q + 240;
       return (k >= 0 && k < kElevTable && d - q * 180 == 0) ? el_table[k] : site_elevation(site, when);
     };
-    int64_t sunrise, sunset;
-    next_sunrise_sunset_from(elev, sh.el_next < el_now, now, &sunrise, &sunset);
+    const bool second = (lane & 1) != 0;
+    const bool afternoon = sh.el_next < el_now;
+    const int64_t h12 = 12 * 3600, h24 = 24 * 3600;
+    // stage 1: noon (max elevation; lane 0) and midnight (min; lane 1), each inside its own half day
+    const int64_t lo1 = (second != afternoon) ? now + h12 : now;           // noon: [t, t+12h] in the morning, else [t+12h, t+24h]; midnight the other half
+    const int64_t ext = find_solar_elevation(elev, lo1, lo1 + h12, second ? 0 : 1, 0.0);
+    const int64_t noon = __shfl(ext, 0, 64), midnight = __shfl(ext, 1, 64);
+    // stage 2: sunrise (lane 0) between the midnight before noon and noon; sunset (lane 1) between noon and midnight
+    const int64_t lo2 = second ? (afternoon ? noon - h24 : noon) : (afternoon ? midnight : midnight - h24);
+    const int64_t hi2 = second ? midnight : noon;
+    int64_t edge = find_solar_elevation(elev, lo2, hi2, 2, -4.242);
+    if (edge < now) edge += h24;
+    const int64_t sunrise = __shfl(edge, 0, 64), sunset = __shfl(edge, 1, 64);
+   if (lane == 0) {
     double cycle;
     if (sunset < sunrise) {   // day
       const int64_t prev = sunrise - 86400;
@@ -388,6 +456,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     out[13] = (solar_power_f64(el_now, p) > 120.4 && soc > 0.99) ? 1.0f : 0.0f;     // balloon.py:231-238
     out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) / 200.0);
     out[15] = (float)ratio;
+   }
   } else if (wave == 1) {
     if (lane < 22) {
       const double ceiling = pressure_ceiling(sh.lev, sh.pot);
@@ -440,28 +509,25 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         if (own1) sh.pb[lane + 64][1] = pk1 * rg1 * idk1;
         wave_sync_lds();
         const double2* pbv = reinterpret_cast<const double2*>(&sh.pb[0][0]);
-        double2 pbk = pbv[0];
-        double l0 = old0[0], l1 = old1[0];
-        const int first = rows - 1 < 64 ? rows - 1 : 64;                    // row r has columns 0 .. r - 1
-        for (int k = 0; k < first; ++k) {
-          const int kn = k + 1 < rows - 1 ? k + 1 : k;
-          const double2 pb_next = pbv[kn];
-          const double l0_next = old0[kn], l1_next = old1[kn];
-          w0 = d_fma(-pbk.x, l0, w0);
-          w1 = d_fma(-pbk.x, l1, w1);
-          const double n0 = d_fma(pbk.y, w0, l0), n1 = d_fma(pbk.y, w1, l1);
-          if (own0 && lane > k) new0[k] = n0;
-          if (own1) new1[k] = n1;
-          pbk = pb_next; l0 = l0_next; l1 = l1_next;
-        }
-        for (int k = 64; k < rows - 1; ++k) {                               // only the upper halves are still live
-          const int kn = k + 1 < rows - 1 ? k + 1 : k;
-          const double2 pb_next = pbv[kn];
-          const double l1_next = old1[kn];
-          w1 = d_fma(-pbk.x, l1, w1);
-          const double n1 = d_fma(pbk.y, w1, l1);
-          if (own1 && lane + 64 > k) new1[k] = n1;
-          pbk = pb_next; l1 = l1_next;
+        // four columns per round: their (p, beta) pairs and old entries are loaded together (one LDS round
+        // trip per round instead of per column), then the four dependent FMA pairs run from registers
+        const int last_col = rows - 2;                                     // row r has columns 0 .. r - 1
+        for (int k0 = 0; k0 <= last_col; k0 += 4) {
+          double2 pbq[4]; double l0q[4], l1q[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + j <= last_col ? k0 + j : last_col;
+            pbq[j] = pbv[kk]; l0q[j] = old0[kk]; l1q[j] = old1[kk];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            w0 = d_fma(-pbq[j].x, l0q[j], w0);
+            w1 = d_fma(-pbq[j].x, l1q[j], w1);
+            const double n0 = d_fma(pbq[j].y, w0, l0q[j]), n1 = d_fma(pbq[j].y, w1, l1q[j]);
+            if (own0 && lane > k) new0[k] = n0;
+            if (own1 && lane + 64 > k && k <= last_col) new1[k] = n1;
+          }
         }
         wave_sync_lds();
         if (own0) { new0[lane] = dnew0; sh.inv_diag[lane] = inv0; }
@@ -626,6 +692,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int n_pad_s = (nr + 15) & ~15;           // rows of the sweep, padded with virtual identity rows to the MFMA tile
   // -- inverses of the 16 x 16 (unit lower) diagonal blocks of Lt (thread = (block, column): forward substitution)
   if (tid < 128) {
+    sh.z[3][tid] = (tid == 0 && nr > 0) ? 1.0 : 0.0;            // right-hand side e_0 of the drop-vector column
     const int blk = tid >> 4, c = tid & 15, base = blk * 16;
     if (base < n_pad_s) {
       double xcol[16];
@@ -685,6 +752,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
     if (wave == 0 && jq == 2) level[0] = p;         // column 2: the newest observation's own pressure
     const double y_last_u = sh.z[0][nr], y_last_v = sh.z[1][nr];   // raw errors of the newest observation (z is overwritten below)
+    const int spec_sel = jq == 1 ? 1 : (jq == 3 ? 3 : 0);
+    const bool use_spec = jq < kSpecial && jq != 2;
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
 #pragma unroll
@@ -713,12 +782,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused)
             const double dp = (level[t] - p_row) * (1.0 / 326.0);
             const double r2 = a_row + dp * dp;
-            R[t][v] = live * d_exp_fast(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)));
+            R[t][v] = live * exp_tab(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)), sh.exp2_frac);
           }
-          if (wave == 0) {                                    // uniform branch: tile 0 holds the special columns
-            const double y0 = row < nr ? sh.z[0][row] : 0.0, y1 = row < nr ? sh.z[1][row] : 0.0;
-            const double e0 = row == 0 && nr > 0 ? 1.0 : 0.0;
-            R[0][v] = jq == 0 ? y0 : (jq == 1 ? y1 : (jq == 3 ? e0 : R[0][v]));
+          if (wave == 0) {                                    // scalar branch: tile 0 holds the special columns
+            // one unconditional LDS read + selects (a load under a per-lane condition becomes an exec-mask branch);
+            // z[3] holds e_0 until the solved column overwrites it
+            const double spec = sh.z[spec_sel][row];
+            R[0][v] = use_spec ? (row < nr ? spec : 0.0) : R[0][v];
           }
 #pragma unroll
           for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
@@ -726,7 +796,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         const double* drow = sh.dinv[I] + tri(jq) + g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double a = 4 * c + g <= jq ? drow[4 * c] : 0.0;      // packed lower triangle
+          const double packed = drow[4 * c];                        // always inside dinv[I][136]; masked above the diagonal
+          const double a = 4 * c + g <= jq ? packed : 0.0;            // packed lower triangle
 #pragma unroll
           for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
         }
@@ -800,7 +871,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         if (g != t || col[t] < kSpecial || level_idx > hi_idx) continue;
         // the newest observation's row: K*(level, newest) = s^2 exp(-|level - p| / 326) (same x, y, t as the query)
         const double dpl = (level[t] - p) * (1.0 / 326.0);
-        const double val_last = kGpSigma2 * d_exp_fast(-__builtin_fabs(dpl)) - cross[t];
+        const double val_last = kGpSigma2 * exp_tab(-__builtin_fabs(dpl), sh.exp2_frac) - cross[t];
         const double ss = d_fma(val_last * val_last, inv_dn, ssq[t]);
         const double mu = d_fma(val_last, zl_u, mean_u[t]), mv = d_fma(val_last, zl_v, mean_v[t]);
         // forecast at this level from the blended column

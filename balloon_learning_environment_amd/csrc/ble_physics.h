@@ -827,13 +827,21 @@ BLE_FN double d_asin(double x) {
 }
 
 // ---------------------------------------------------------------- full fp64 solar calculator
-// solar.solar_calculator (solar.py:43-174): elevation [deg] (refraction corrected) and flux.
-BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
+// solar.solar_calculator (solar.py:43-174) in two parts: the TIME-ONLY ephemeris (declination, equation of
+// time, flux -- five sincos; smooth on the scale of days) and the SITE part (hour angle, zenith, refraction).
+struct SolarEphemeris {
+  double sin_decl, cos_decl;
+  double eot_quarter_deg;    // 0.25 * degrees(equation_of_time): the equation-of-time term of the hour angle [deg]
+  double flux;               // W/m^2
+};
+BLE_FN void unix_day_fraction(int64_t unix_s, double* julian_century, double* frac) {
   int64_t days = unix_s / 86400;
   int64_t sod = unix_s - days * 86400;
   if (sod < 0) { sod += 86400; days -= 1; }
-  const double frac = (double)sod / 86400.0;
-  const double jc = (((2440587.5 + (double)days) + frac) - 2451545.0) / 36525.0;
+  *frac = (double)sod / 86400.0;
+  *julian_century = (((2440587.5 + (double)days) + *frac) - 2451545.0) / 36525.0;
+}
+BLE_FN SolarEphemeris solar_ephemeris_f64(double jc) {
   const double d2r = kPiD / 180.0;
   const double l0 = d2r * (280.46646 + jc * (36000.76983 + jc * 0.0003032));
   double s2l, c2l;
@@ -853,14 +861,23 @@ BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg
   const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
   const double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
                             1.25 * ecc * ecc * s2m);
-  // cos(hour_angle) = -cos(radians(1440 frac + degrees(eot) + 4 lng) / 4)   (solar.py:113-120)
-  double sh, ch;
-  sincos_f64(d2r * (360.0 * frac + 0.25 * (eot * (180.0 / kPiD)) + lng_deg), &sh, &ch);
   const double eoc = d2r * (sm * (1.914602 - jc * (0.004817 + 0.000014 * jc)) + s2m * (0.019993 - 0.000101 * jc) + s3m * 0.000289);
   double sa, ca;
   sincos_f64(l0 + eoc - d2r * (0.00569 - 0.00478 * so), &sa, &ca);
-  const double sin_decl = sobl * sa;
-  const double cos_decl = sqrt(1.0 - sin_decl * sin_decl);
+  SolarEphemeris e;
+  e.sin_decl = sobl * sa;
+  e.cos_decl = sqrt(1.0 - e.sin_decl * e.sin_decl);
+  e.eot_quarter_deg = 0.25 * (eot * (180.0 / kPiD));
+  const double r = (1 + ecc) / (1 - ecc);
+  e.flux = 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
+  return e;
+}
+// elevation [deg], refraction corrected, at a site (sin lat, cos lat, lng [deg]) and day fraction
+BLE_FN double solar_elevation_site_f64(double sin_lat, double cos_lat, double lng_deg, double frac, double sin_decl,
+                                       double cos_decl, double eot_quarter_deg) {
+  // cos(hour_angle) = -cos(radians(1440 frac + degrees(eot) + 4 lng) / 4)   (solar.py:113-120)
+  double sh, ch;
+  sincos_f64((kPiD / 180.0) * (360.0 * frac + eot_quarter_deg + lng_deg), &sh, &ch);
   double s = sin_lat * sin_decl - cos_lat * cos_decl * ch;
   s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
   const double el = d_asin(s) * (180.0 / kPiD);      // 90 - degrees(acos(s))
@@ -870,8 +887,14 @@ BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg
   else if (el > 5.0) { const double t = s / c; refr = 58.1 / t - 0.07 / (t * t * t) + 0.000086 / (t * t * t * t * t); }
   else if (el > -0.575) refr = 1735.0 + el * (-518.2 + el * (103.4 + el * (-12.79 + el * 0.711)));
   else refr = -20.772 / (s / c);
-  if (flux_out) { const double r = (1 + ecc) / (1 - ecc); *flux_out = 1366.0 * (1 + 0.5 * (r * r - 1) * cm); }
   return el + refr / 3600.0;
+}
+BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
+  double jc, frac;
+  unix_day_fraction(unix_s, &jc, &frac);
+  const SolarEphemeris e = solar_ephemeris_f64(jc);
+  if (flux_out) *flux_out = e.flux;
+  return solar_elevation_site_f64(sin_lat, cos_lat, lng_deg, frac, e.sin_decl, e.cos_decl, e.eot_quarter_deg);
 }
 
 // BalloonState.latlng (spherical_geometry.py:44-76) as (sin lat, cos lat, lng [deg]) in fp64.
