@@ -75,6 +75,8 @@ struct ObsShared {
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
   double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
+  double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
+  double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
   double exp2_frac[32];                  // 2^(j / 32): exp(x) = 2^k * 2^(j/32) * P5(r), |r| <= ln2 / 64
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
@@ -218,8 +220,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   float* out = obs + env * kObsDim;
 
   SunSite site;
-  latlng_f64((double)st.center_lat_deg[env], (double)st.center_lng_deg[env], x, y, &site.sin_lat, &site.cos_lat,
-             &site.lng_deg);
+  if (wave == 1) {           // BalloonState.latlng once per environment (one wave; the others get it through LDS)
+    latlng_f64((double)st.center_lat_deg[env], (double)st.center_lng_deg[env], x, y, &site.sin_lat, &site.cos_lat,
+               &site.lng_deg);
+    if (lane == 0) { sh.site[0] = site.sin_lat; sh.site[1] = site.cos_lat; sh.site[2] = site.lng_deg; }
+  }
 
   // ---- phase 0a: history ring
   int count = hist.count[env];
@@ -262,15 +267,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       ox = h_xyp[slot * 3]; oy = h_xyp[slot * 3 + 1]; op = h_xyp[slot * 3 + 2];
       ot = h_t[slot]; oeu = h_err[slot * 2]; oev = h_err[slot * 2 + 1];
     }
-    const int32_t age = ot > elapsed ? ot - elapsed : elapsed - ot;
-    valid = age < kGpHorizonS;             // strict, wind_gp.py:183
   }
-  int pos = 0;
-  if (wave < 2) {
-    const unsigned long long ballot = __ballot(valid);
-    pos = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) { sh.wave_count[wave] = __popcll(ballot); sh.ballot[wave] = ballot; }
-  }
+  // (the ring entries are consumed after the elevation table below: their HBM round trips -- count, then the
+  // slots -- hide behind that computation instead of stalling all four waves here)
 
   // ---- phase 0b: solar elevation table, search levels, pressure column
   // The table needs the solar elevation at 721 instants 180 s apart.  The time-only half of the solar
@@ -285,13 +284,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const SolarEphemeris e = solar_ephemeris_f64(jc);
     sh.eph[tid][0] = e.sin_decl; sh.eph[tid][1] = e.cos_decl; sh.eph[tid][2] = e.eot_quarter_deg;
   } else if (tid == 6) {
-    double flux;
-    sh.el_now = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, now, &flux);
-    sh.flux_now = flux;
-  } else if (tid == kObsBlock - 1) {
-    sh.el_next = site_elevation(site, now + 1);
+    double jc, frac;
+    unix_day_fraction(now, &jc, &frac);
+    sh.flux_now = solar_flux_f64(jc);
   }
   __syncthreads();
+  site.sin_lat = sh.site[0]; site.cos_lat = sh.site[1]; site.lng_deg = sh.site[2];
   {
     double dd[3][6];
 #pragma unroll
@@ -317,6 +315,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sod = sod < 0 ? sod + 86400 : sod;                                   // |offset| <= 86 400 s
       sod = sod >= 86400 ? sod - 86400 : sod;
       el_table[k] = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
+    }
+    if (tid == kObsBlock - 1) {        // elevation one second from now (is_solar_afternoon, solar.py:239-256), same interpolant
+      const double u = (43200.0 + 1.0) * (1.0 / 25920.0);
+      const double w2 = (u - 1.0) * 0.5, w3 = (u - 2.0) * (1.0 / 3.0), w4 = (u - 3.0) * 0.25, w5 = (u - 4.0) * 0.2;
+      double val[3];
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+        val[f] = d_fma(u, d_fma(w2, d_fma(w3, d_fma(w4, d_fma(w5, dd[f][5], dd[f][4]), dd[f][3]), dd[f][2]), dd[f][1]), dd[f][0]);
+      int32_t sod = sod_now + 1;
+      sod = sod >= 86400 ? sod - 86400 : sod;
+      sh.el_next = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
     }
   }
   const double l0 = atm_lapse_f64(0, alpha);
@@ -346,6 +355,16 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         }
     sh.column[lane] = acc;
   }
+  if (tid < kGpCapacity && tid < m) {
+    const int32_t age = ot > elapsed ? ot - elapsed : elapsed - ot;
+    valid = age < kGpHorizonS;             // strict, wind_gp.py:183
+  }
+  int pos = 0;
+  if (wave < 2) {
+    const unsigned long long ballot = __ballot(valid);
+    pos = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) { sh.wave_count[wave] = __popcll(ballot); sh.ballot[wave] = ballot; }
+  }
   __syncthreads();   // B1
   BLE_MARK();
 
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.a[at] = dx * dx + dy * dy + dt * dt;
     }
   }
-  const double el_now = sh.el_now, flux_now = sh.flux_now;
+  const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
   const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   // Can the stored factor be slid to the new window?  The observations inside the 6 h window
@@ -525,8 +544,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             w0 = d_fma(-pbq[j].x, l0q[j], w0);
             w1 = d_fma(-pbq[j].x, l1q[j], w1);
             const double n0 = d_fma(pbq[j].y, w0, l0q[j]), n1 = d_fma(pbq[j].y, w1, l1q[j]);
-            if (own0 && lane > k) new0[k] = n0;
-            if (own1 && lane + 64 > k && k <= last_col) new1[k] = n1;
+            *((own0 && lane > k) ? new0 + k : sh.pad + lane) = n0;
+            *((own1 && lane + 64 > k && k <= last_col) ? new1 + k : sh.pad + lane) = n1;
           }
         }
         wave_sync_lds();
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       for (int i = tid; i + 1 < n_obs; i += kObsBlock)
         chol_g[kCholTri + i] = (i + 1 < nr) ? -sh.z[3][i + 1] : -sh.last[3];
     }
-    const double inv_dn = has_last ? 1.0 / sh.last[2] : 0.0;
+    const double inv_dn = has_last ? d_rcp(sh.last[2]) : 0.0;
     const double zl_u = has_last ? sh.last[0] * inv_dn : 0.0, zl_v = has_last ? sh.last[1] * inv_dn : 0.0;
     {
       // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g
@@ -882,20 +901,22 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         const double u = mu + (double)fu, v = mv + (double)fv;
         double var = kGpSigma2 - ss;
         var = var < 0.0 ? 0.0 : var;
-        const double deviation = n_obs > 0 ? var / kGpSigma2 : 0.0;     // wind_gp.py:166-168
-        const double speed = sqrt(u * u + v * v);
+        // (reciprocal + Newton instead of the ~30-instruction fp64 division / sqrt sequences: 2e-15 relative)
+        const double deviation = n_obs > 0 ? var * (1.0 / kGpSigma2) : 0.0;     // wind_gp.py:166-168
+        const double s2 = u * u + v * v;
+        const double speed = s2 > 0.0 ? s2 * d_rsqrt(s2) : 0.0;
         double angle;
         if (dist < 1e-5) {
           angle = 0.0;
         } else if (speed < 1e-5) {
           angle = kPiD;
         } else {
-          double c = (u * to_station_x + v * to_station_y) / (speed + 1e-5);
+          double c = (u * to_station_x + v * to_station_y) * d_rcp(speed + 1e-5);
           c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
           angle = kPiD / 2 - d_asin(c);
         }
         float* o = out + 16 + 3 * (pad_above + level_idx);
-        o[0] = (float)deviation; o[1] = (float)(angle / kPiD); o[2] = (float)(speed / (speed + 30.0));
+        o[0] = (float)deviation; o[1] = (float)(angle * (1.0 / kPiD)); o[2] = (float)(speed * d_rcp(speed + 30.0));
       }
     }
   };

@@ -872,6 +872,15 @@ BLE_FN SolarEphemeris solar_ephemeris_f64(double jc) {
   e.flux = 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
   return e;
 }
+// solar flux alone (solar.py:170-172)
+BLE_FN double solar_flux_f64(double jc) {
+  const double m0 = (kPiD / 180.0) * (357.52911 + jc * (35999.05029 - 0.0001537 * jc));
+  double sm, cm;
+  sincos_f64(m0, &sm, &cm);
+  const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
+  const double r = (1 + ecc) / (1 - ecc);
+  return 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
+}
 // elevation [deg], refraction corrected, at a site (sin lat, cos lat, lng [deg]) and day fraction
 BLE_FN double solar_elevation_site_f64(double sin_lat, double cos_lat, double lng_deg, double frac, double sin_decl,
                                        double cos_decl, double eot_quarter_deg) {
