@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       int32_t sod = sod_now + 180 * (k - 240);
       sod = sod < 0 ? sod + 86400 : sod;                                   // |offset| <= 86 400 s
       sod = sod >= 86400 ? sod - 86400 : sod;
-      el_table[k] = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
+      el_table[k] = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod * (1.0 / 86400.0), val[0], val[1], val[2]);
     }
     if (tid == kObsBlock - 1) {        // elevation one second from now (is_solar_afternoon, solar.py:239-256), same interpolant
       const double u = (43200.0 + 1.0) * (1.0 / 25920.0);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     double sc, cc;
     sincos_f64(cycle, &sc, &cc);
     const double batt = (double)st.battery_charge[env], soc = batt / 3058.56;
-    const double dist = sqrt(x * x + y * y);
+    const double dist = sqrt(x * x + y * y);  // (one lane, once)
     const double sp_now = (double)st.superpressure[env];
     const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) / p;
     const int cmd = st.last_command[env];
@@ -706,8 +706,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const double p_clamped = p < 5000.0 ? 5000.0 : (p > 14000.0 ? 14000.0 : p);
   const int level_now = (int)d_rint((p_clamped - 5000.0) / 50.0);       // Python round(): half to even
   const int pad_above = kObsLevels - level_now - 1;
-  const double dist = sqrt(x * x + y * y);
-  const double to_station_x = -x / (dist + 1e-5), to_station_y = -y / (dist + 1e-5);
+  const double dist2 = x * x + y * y;
+  const double dist = dist2 > 0.0 ? dist2 * d_rsqrt(dist2) : 0.0;
+  const double inv_dist = d_rcp(dist + 1e-5);
+  const double to_station_x = -x * inv_dist, to_station_y = -y * inv_dist;
   const int n_pad_s = (nr + 15) & ~15;           // rows of the sweep, padded with virtual identity rows to the MFMA tile
   // -- inverses of the 16 x 16 (unit lower) diagonal blocks of Lt (thread = (block, column): forward substitution)
   if (tid < 128) {
@@ -920,8 +922,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       }
     }
   };
-  if (n_tiles <= 8) sweep(std::integral_constant<int, 2>{});
-  else sweep(std::integral_constant<int, 3>{});
+  // tile T = 4 t + wave: a wave needs its third tile (t = 2) only if tile 8 + wave exists.  About one
+  // environment in five has 125+ reachable levels (9 tiles): there wave 0 sweeps three tiles, the others two
+  // (both instantiations run the same three barriers).
+  if (wave + 8 < n_tiles) sweep(std::integral_constant<int, 3>{});
+  else sweep(std::integral_constant<int, 2>{});
   // padding above and below the 181 real levels, and the unreachable levels: certain, wrong way, infinitely fast
   for (int c = tid; c < kObsColumn; c += kObsBlock) {
     if (c < pad_above + lo_idx || c > pad_above + hi_idx) {
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   {
     for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
+    out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
   }
 #endif
   // the factor of this window goes back to HBM for the next call

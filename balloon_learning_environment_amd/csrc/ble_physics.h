@@ -802,14 +802,14 @@ BLE_FN double d_asin(double x) {
     const double t = x * x;
     const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
     const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-    return x + x * (p / q);
+    return x + x * (p * d_rcp(q));                     // q in [0.3, 1]: reciprocal + Newton, 2e-15
   }
   const double w = 1.0 - ax;
   const double t = w * 0.5;
   const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
   const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-  const double s = sqrt(t);
-  const double r = p / q;
+  const double s = t > 0.0 ? d_sqrt_fast(t) : 0.0;
+  const double r = p * d_rcp(q);
   double res;
   if (ax >= 0.975) {
     res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
@@ -818,7 +818,7 @@ BLE_FN double d_asin(double x) {
     union { double d; uint64_t u; } cv;
     cv.d = s; cv.u &= 0xffffffff00000000ULL;
     const double df = cv.d;
-    const double c = (t - df * df) / (s + df);
+    const double c = (t - df * df) * d_rcp(s + df);
     const double pp = 2.0 * s * r - (pio2_lo - 2.0 * c);
     const double qq = pio4_hi - 2.0 * df;
     res = pio4_hi - (pp - qq);
@@ -890,13 +890,17 @@ BLE_FN double solar_elevation_site_f64(double sin_lat, double cos_lat, double ln
   double s = sin_lat * sin_decl - cos_lat * cos_decl * ch;
   s = s > 1.0 ? 1.0 : (s < -1.0 ? -1.0 : s);
   const double el = d_asin(s) * (180.0 / kPiD);      // 90 - degrees(acos(s))
-  const double c = sqrt(1.0 - s * s);
+  // refraction (solar.py:141-157) through one reciprocal: 1 / tan(el) = c / s  (fp64 divisions expand to ~30
+  // instructions each and this runs 721 times per observation)
+  const double c2 = 1.0 - s * s;
+  const double c = c2 > 0.0 ? d_sqrt_fast(c2) : 0.0;
+  const double it = c * d_rcp(s == 0.0 ? 1e-300 : s), it2 = it * it;
   double refr;
   if (el > 85.0) refr = 0.0;
-  else if (el > 5.0) { const double t = s / c; refr = 58.1 / t - 0.07 / (t * t * t) + 0.000086 / (t * t * t * t * t); }
+  else if (el > 5.0) refr = it * (58.1 + it2 * (-0.07 + it2 * 0.000086));
   else if (el > -0.575) refr = 1735.0 + el * (-518.2 + el * (103.4 + el * (-12.79 + el * 0.711)));
-  else refr = -20.772 / (s / c);
-  return el + refr / 3600.0;
+  else refr = -20.772 * it;
+  return el + refr * (1.0 / 3600.0);
 }
 BLE_FN double solar_elevation_f64(double sin_lat, double cos_lat, double lng_deg, int64_t unix_s, double* flux_out) {
   double jc, frac;
