@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main(tag):
   base = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
-  out = {'tag': tag, 'kernel': 'ble_step_kernel'}
+  out = {'tag': tag, 'kernel': 'ble_step_kernel', 'agent_steps_per_profiled_launch': 32.0}
   # kernel stats
   with open(os.path.join(base, 'trace', 'trace_kernel_stats.csv')) as f:
     rows = list(csv.DictReader(f))
@@ -72,8 +72,8 @@ def main(tag):
     out['hbm'] = {'fetch_bytes_raw': fetch, 'write_bytes_raw': write, 'hbm_bytes_per_launch': fetch + write,
                   'hbm_bytes_per_launch_fetch_x2': 2 * fetch + write,
                   'tcc_hit': avg.get('TCC_HIT_sum'), 'tcc_miss': avg.get('TCC_MISS_sum')}
-    json.dump({'hbm_bytes_per_launch': fetch + write, 'source': f'profiles/{tag}_summary.json'},
-              open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
+    traffic = {'hbm_bytes_per_launch': fetch + write, 'hbm_bytes_per_launch_fetch_x2': 2 * fetch + write,
+               'source': f'profiles/{tag}_summary.json'}
   # ---- observation kernel (bench.py --observe leg)
   obs_md = []
   obs_stats = os.path.join(base, 'trace_obs', 'trace_obs_kernel_stats.csv')
@@ -88,7 +88,7 @@ def main(tag):
         out['observe_kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
                                        'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3}
     oc = collections.defaultdict(list)
-    for name in ('pmc_obs1', 'pmc_obs2'):
+    for name in ('pmc_obs1', 'pmc_obs2', 'pmc_obs3', 'pmc_obs_fetch', 'pmc_obs_write'):
       p = os.path.join(base, name, f'{name}_counter_collection.csv')
       if os.path.exists(p):
         with open(p) as f:
@@ -99,18 +99,35 @@ def main(tag):
                                          'agpr': int(r['Accum_VGPR_Count']), 'sgpr': int(r['SGPR_Count']),
                                          'scratch': int(r['Scratch_Size']), 'lds': int(r['LDS_Block_Size'])}
     # the last launches are the steady state (window full); average the final 8
-    out['observe_pmc_per_launch_steady'] = {k: sum(v[-8:]) / len(v[-8:]) for k, v in oc.items()}
+    steady = {k: sum(v[-8:]) / len(v[-8:]) for k, v in oc.items()}
+    out['observe_pmc_per_launch_steady'] = steady
+    if 'FETCH_SIZE' in steady and 'WRITE_SIZE' in steady:
+      # the factor (59 KB per env, 90 % of the reads) is fetched with 16 B per lane: the guide's x2 correction
+      # applies to FETCH_SIZE; WRITE_SIZE is uncalibrated (guide) and reported as is
+      of, ow = steady['FETCH_SIZE'] * 1024.0, steady['WRITE_SIZE'] * 1024.0
+      out['observe_hbm'] = {'fetch_bytes_raw': of, 'write_bytes_raw': ow, 'hbm_bytes_per_launch_fetch_x2': 2 * of + ow,
+                            'algorithmic_bytes_per_launch': 65536 * (4396 + 2 * 59040 + 152 + 3072)}
+      try:
+        traffic
+      except NameError:
+        traffic = {}
+      traffic['observe_hbm_bytes_per_launch'] = 2 * of + ow
+      traffic['observe_note'] = 'FETCH_SIZE x2 (16 B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE, steady-state launch, 65 536 envs' 
+  try:
+    json.dump(traffic, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
+  except NameError:
+    pass
   json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'), 'w'), indent=1)
   with open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.md'), 'w') as f:
-    f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 192 --warmup 32` (one launch = 32 agent steps) ({tag})\n\n')
+    f.write(f'# rocprofv3 --kernel-trace --stats, `python bench.py --steps 192 --warmup 32 --reps 5 --no-extras` (one launch = 32 agent steps) ({tag})\n\n')
     f.write('\n'.join(md) + '\n\n')
     f.write('## ble_step_kernel PMC (per launch averages; separate --pmc passes)\n\n```json\n')
     f.write(json.dumps({k: out[k] for k in ('dispatch', 'derived', 'hbm') if k in out}, indent=1))
     f.write('\n```\n')
     if obs_md:
-      f.write('\n# `python bench.py --steps 32 --warmup 32 --observe 8`: 121 window-filling + 8 timed step/observation pairs\n\n')
+      f.write('\n# `python profiles/obs_only.py 65536`: 121 window-filling + 8 steady-state step/noise/observation triples\n\n')
       f.write('\n'.join(obs_md) + '\n\n## ble_observe_kernel PMC (steady state: last 8 launches)\n\n```json\n')
-      f.write(json.dumps({k: out[k] for k in ('observe_dispatch', 'observe_pmc_per_launch_steady') if k in out}, indent=1))
+      f.write(json.dumps({k: out[k] for k in ('observe_dispatch', 'observe_pmc_per_launch_steady', 'observe_hbm') if k in out}, indent=1))
       f.write('\n```\n')
   print(json.dumps(out, indent=1))
 
