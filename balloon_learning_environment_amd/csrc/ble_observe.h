@@ -190,9 +190,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   __shared__ ObsShared sh;
 #ifdef BLE_OBS_TIMING
   long long tmark[12]; int nmark = 0;
+  long long tsub[5] = {0, 0, 0, 0, 0};
 #define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BLE_SUB(i) do { tsub[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define BLE_MARK() do {} while (0)
+#define BLE_SUB(i) do {} while (0)
 #endif
   BLE_MARK();
   const int64_t env = blockIdx.x;
@@ -239,9 +242,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
   for (int i = 0; i < kCholPrefetch; ++i) {
     const int e2 = tid + kObsBlock * i;
-    chol_pre[i] = (chol_g != nullptr && e2 < chol_pairs) ? reinterpret_cast<const double2*>(chol_g)[e2] : make_double2(0.0, 0.0);
+    // (the whole slab, whatever n_chol says: the request does not wait for that load; unused pairs are never copied)
+    chol_pre[i] = (chol_g != nullptr && e2 < kCholTri / 2) ? reinterpret_cast<const double2*>(chol_g)[e2] : make_double2(0.0, 0.0);
   }
-  const double p_pre = (chol_g != nullptr && tid < n_chol0 - 1 && n_chol0 <= kGpMax) ? chol_g[kCholTri + tid] : 0.0;
+  const double p_pre = (chol_g != nullptr && tid < kGpMax) ? chol_g[kCholTri + tid] : 0.0;
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -277,6 +281,36 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   // exactly at 6 nodes 7.2 h apart (lanes 0..5) and interpolated (degree 5, Newton forward form; error
   // |f^(6)| h^6 17 / 720 ~ 2e-16) -- only the site half (hour angle, zenith, refraction) runs per entry.
   double* el_table = sh.el_table;
+  // (independent of the site and of the ephemeris nodes: before the first barrier, next to wave 0's nodes and
+  // wave 1's latlng, instead of after the table where waves 2 / 3 made the others wait at B1)
+  const double l0 = atm_lapse_f64(0, alpha);
+  const double p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
+  if (wave == 3 && lane < 20) {
+    // np.linspace(1000, p_floor, 20); p / T(p) at each level (pressure_range_builder.py:222-235)
+    const double level = lane == 19 ? p_floor : 1000.0 + (double)lane * ((p_floor - 1000.0) / 19.0);
+    const AtmWindow w = atm_window(alpha, level, &flags);
+    double h, t;
+    atm_at_pressure_f64(w, alpha, level, &h, &t);
+    sh.lev[lane] = level; sh.pot[lane] = level / t;
+  }
+  if (wave == 2 && lane < 20) {
+    // get_forecast_column: blend (x, y, t) first, pressure afterwards (grid_based_wind_field.py:96-132)
+    const WindQuery wq = wind_query(xf, yf, 5000.0f, elapsed);
+    const float* grid = wind_grid + env * grid_env_stride;
+    const int ip = lane >> 1, comp = lane & 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
+          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
+        }
+    sh.column[lane] = acc;
+  }
+  BLE_SUB(0);        // prologue issued (state, latlng on wave 1, ring + factor loads)
   if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
   if (tid < 6) {
     double jc, frac;
@@ -289,6 +323,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     sh.flux_now = solar_flux_f64(jc);
   }
   __syncthreads();
+  BLE_SUB(1);        // ephemeris nodes + site ready
   site.sin_lat = sh.site[0]; site.cos_lat = sh.site[1]; site.lng_deg = sh.site[2];
   {
     double dd[3][6];
@@ -328,33 +363,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.el_next = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
     }
   }
-  const double l0 = atm_lapse_f64(0, alpha);
-  const double p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
-  if (wave == 3 && lane < 20) {
-    // np.linspace(1000, p_floor, 20); p / T(p) at each level (pressure_range_builder.py:222-235)
-    const double level = lane == 19 ? p_floor : 1000.0 + (double)lane * ((p_floor - 1000.0) / 19.0);
-    const AtmWindow w = atm_window(alpha, level, &flags);
-    double h, t;
-    atm_at_pressure_f64(w, alpha, level, &h, &t);
-    sh.lev[lane] = level; sh.pot[lane] = level / t;
-  }
-  if (wave == 2 && lane < 20) {
-    // get_forecast_column: blend (x, y, t) first, pressure afterwards (grid_based_wind_field.py:96-132)
-    const WindQuery wq = wind_query(xf, yf, 5000.0f, elapsed);
-    const float* grid = wind_grid + env * grid_env_stride;
-    const int ip = lane >> 1, comp = lane & 1;
-    float acc = 0.0f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
-          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
-        }
-    sh.column[lane] = acc;
-  }
+  BLE_SUB(2);        // elevation table filled
+  BLE_SUB(3);        // search levels / pressure column done
   if (tid < kGpCapacity && tid < m) {
     const int32_t age = ot > elapsed ? ot - elapsed : elapsed - ot;
     valid = age < kGpHorizonS;             // strict, wind_gp.py:183
@@ -941,6 +951,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   {
     for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
+    for (int k = 0; k < 4; ++k) out[kObsDim - 20 + k] = (float)(tsub[k] - tmark[0]);
     out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
   }
 #endif

@@ -47,7 +47,7 @@ if do_obs:
     to.append(e0.elapsed_time(e1))
   out['obs_ms_median'] = statistics.median(to); out['obs_ms_min'] = min(to)
   if 'timing' in sys.argv[3]:
-    t = obs[:, -16:].double().mean(0).cpu().numpy()
+    t = obs[:, -20:].double().mean(0).cpu().numpy()
     out['marks'] = [float(v) for v in t]
 try:
   sim.check_errors()
