@@ -240,9 +240,11 @@ def observe_leg(roll, pairs, world):
   live = float((sim.state['status'] == 0).sum().item())
   ms_obs, ms_pair = statistics.median(t_obs), statistics.median(t_pair)
   # algorithmic work per env-observation: 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles
-  # (two error vectors + the ~120 reachable levels) x 2 048 flop + ~0.6 MFLOP of fp64 VALU (factor slide,
-  # kernel evaluations); algorithmic bytes: 4 396 out + 2 x 58 080 factor in/out + 152 state + 3 072 ring
-  flop = 144 * 8 * 2048 + 0.6e6
+  # (4 special columns + the ~121 reachable levels) + 32 for the diagonal-block inverses, x 2 048 flop, + ~0.9 MFLOP
+  # of fp64 VALU (kernel matrix K*, elevation table, drop recurrences, cold starts); algorithmic bytes: 4 396 out
+  # + 2 x 59 040 factor-and-drop-vector in/out + 152 state + 3 072 ring
+  flop = (144 * 8 + 32) * 2048 + 0.9e6
+  obs_bytes = 4396 + 2 * 59040 + 152 + 3072
   traffic = None
   try:
     traffic = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('observe_hbm_bytes_per_launch')
@@ -254,10 +256,10 @@ def observe_leg(roll, pairs, world):
           'env_observations_per_s': n / (ms_obs * 1e-3), 'env_steps_per_s_with_observation': n / (ms_pair * 1e-3),
           'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
           'includes_gather_to_rank0': world > 1,
-          'kernel': 'ble_observe_kernel (fp64 WindGP: factor slid in HBM, MFMA forward substitution)',
+          'kernel': 'ble_observe_kernel (fp64 WindGP: factor carried in HBM and slid with a stored drop vector, MFMA forward substitution)',
           'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS, 'achieved': tf, 'frac': tf / FP64_PEAK_TFLOPS,
-                       'traffic': traffic, 'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': 4396 + 2 * 58080 + 152 + 3072,
-                       'hbm_gbs_algorithmic': n * (4396 + 2 * 58080 + 152 + 3072) / (ms_obs * 1e-3) / 1e9}}
+                       'traffic': traffic, 'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': obs_bytes,
+                       'hbm_gbs_algorithmic': n * obs_bytes / (ms_obs * 1e-3) / 1e9, 'hbm_gbs_measured': (traffic / (ms_obs * 1e-3) / 1e9) if traffic else None}}
 
 
 def facade_leg(steps=150):
