@@ -123,3 +123,18 @@ def test_host_reward_mirror_matches_oracle(x, y, batt, acs_w, cmd, t):
   got = balloon_env.perciatelli_reward_function(simulator_data.SimulatorState(s, None, simulator_data.Atmosphere(0.5)))
   ref = oracle.reward_only(x, y, 8000.0, batt, acs_w, cmd, 0.0, 0.0, int(now.timestamp()), 0)
   assert got == pytest.approx(ref, rel=1e-12)
+
+
+def test_gym_registration_module_without_gym():
+  """env/gym.py mirrors the reference's register_env(); gym itself is optional."""
+  import importlib
+  import pytest
+  mod = importlib.import_module('balloon_learning_environment_amd.env.gym')
+  assert mod.ENV_ID == 'BalloonLearningEnvironment-v0' and mod.ENTRY_POINT.endswith(':BalloonEnv')
+  try:
+    import gym  # noqa: F401
+  except ImportError:
+    with pytest.raises(ImportError):
+      mod.register_env()
+  else:
+    mod.register_env(); mod.register_env()      # idempotent
