@@ -199,6 +199,7 @@ class BalloonArena(BalloonArenaInterface):
     self._vec._step_duration = constants.AGENT_TIME_STEP
     self._wind_field = self._vec.wind_field
     self.last_reward = None
+    self._row = None          # host copy of the balloon's row, valid until the next device-side change
     self.reset(seed)
 
   def _bind_wind_field(self) -> None:
@@ -225,6 +226,7 @@ class BalloonArena(BalloonArenaInterface):
     self._vec.wind_field = self._wind_field
     seed_ = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
     self._vec._seed = seed_
+    self._row = None
     self._vec.sim.episode.zero_()         # reset(seed) reproduces the same episode whatever happened before
     self._vec.sim.reset_device(seed_)
     self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
@@ -234,13 +236,13 @@ class BalloonArena(BalloonArenaInterface):
     return self.feature_constructor.get_features()
 
   def step(self, action: control.AltitudeControlCommand) -> np.ndarray:
-    state = self._vec.sim.state
     # balloon.py:288-290: stepping a terminal balloon is an error in the single-env API
-    status = balloon.BalloonStatus(int(state['status'][0].item()))
+    status = self.get_balloon_state().status
     assert status == balloon.BalloonStatus.OK, (
         f'Stepping balloon after a terminal event occured. ({status.name})')
     a = torch.tensor([int(action)], dtype=torch.uint8, device=self._vec.device)
     reward, _ = self._vec.step(a, self._host_wind())
+    self._row = None
     self._vec.sim.check_errors()
     self.last_reward = float(reward[0].item())
     self.feature_constructor.observe(self.get_measurements())
@@ -250,6 +252,7 @@ class BalloonArena(BalloonArenaInterface):
     return simulator_data.SimulatorState(self.get_balloon_state(), self._wind_field, self._vec.get_atmosphere())
 
   def set_simulator_state(self, new_state: simulator_data.SimulatorState) -> None:
+    self._row = None
     self._vec.sim.state['alpha'][0] = float(new_state.atmosphere.alpha)
     self.set_balloon_state(new_state.balloon_state)
     self._wind_field = new_state.wind_field
@@ -257,9 +260,14 @@ class BalloonArena(BalloonArenaInterface):
     self._bind_wind_field()
 
   def get_balloon_state(self) -> balloon.BalloonState:
-    return self._vec.get_balloon_state(0)
+    """A fresh BalloonState built from ONE read-back of the device row per transition (the reference hands out
+    its live state object; callers that mutate the result must pass it to set_balloon_state)."""
+    if self._row is None:
+      self._row = self._vec.row(0)
+    return balloon.state_from_row(self._row)
 
   def set_balloon_state(self, new_state: balloon.BalloonState) -> None:
+    self._row = None
     self._vec.set_balloon_state(new_state, 0)
 
   def get_measurements(self) -> simulator_data.SimulatorObservation:
