@@ -33,11 +33,15 @@ struct EnvConst {
 struct EnvHoisted {
   AtmBase atm;
   double sin_lat0, cos_lat0;
+  double q_earth;          // earth-IR heat per unit area (thermal.py:209-213): a function of the episode's IR alone
+  uint32_t flags;          // its total_absorptivity range check
 };
 BLE_FN EnvHoisted hoist_constants(const EnvConst& c) {
   EnvHoisted h;
   h.atm = atm_base((double)c.alpha);
   sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &h.sin_lat0, &h.cos_lat0);
+  h.flags = 0;
+  h.q_earth = earth_heat_per_area_f64((double)c.ir, &h.flags);
   return h;
 }
 
@@ -124,7 +128,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     }
     return r;
   };
-  const double q_earth = earth_heat_per_area_f64((double)c.ir, flags);
+  const double q_earth = hc.q_earth;
+  *flags |= hc.flags;
   // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature: the
   // factor leaves [0, 1] only for T_int < 12.3 K; T_int moves < 1 K per step, so checking the
   // step's first and last value is checking every stride
