@@ -83,11 +83,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       // wind at the PRE-step position/time (balloon_arena.py:194,270-275): gather now, blend later
       const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
       WindCorners corners;
-#ifdef BLE_WHATIF_NO_GATHER
-      for (int a = 0; a < 8; ++a) for (int b = 0; b < 4; ++b) corners.c[a][b] = 1.0f + 0.01f * (float)(a + b);
-#else
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
-#endif
       float nu = 0.0f, nv = 0.0f;
       if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;

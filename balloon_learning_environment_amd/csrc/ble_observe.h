@@ -201,17 +201,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int64_t env = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: `if (wave == ...)` is a real branch, not an exec mask
-#ifdef BLE_OBS_STAGGER
-  // Two workgroups share a CU and each runs VALU/MFMA-heavy phases (solar table, sweep) and latency-bound
-  // single-wave phases in sequence.  Launched together they stay in lockstep for the whole grid -- both in
-  // the same phase, competing for the same pipes.  Delaying the second resident workgroup of every CU ONCE,
-  // in the first round, shifts them by half a period; the shift then persists (a finishing workgroup is
-  // replaced at once).
-  if (blockIdx.x >= BLE_OBS_STAGGER_FROM && blockIdx.x < BLE_OBS_STAGGER_TO) {
-    const long long t_start = (long long)__builtin_readcyclecounter();
-    while ((long long)__builtin_readcyclecounter() - t_start < (long long)(BLE_OBS_STAGGER)) __builtin_amdgcn_s_sleep(64);
-  }
-#endif
   uint32_t flags = 0;
 
   // ---- state of this environment (uniform loads)

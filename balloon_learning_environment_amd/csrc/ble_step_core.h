@@ -118,9 +118,6 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     const float fkk = (float)kk;
     bool near;
     SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
-#ifdef BLE_WHATIF_NO_BAND
-    near = false;
-#endif
     if (__builtin_expect(near, 0)) {
       const double dk = 10.0 * (double)kk;
       r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)s.x), d_fma(dk, (double)v, (double)s.y),
@@ -149,11 +146,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
     const float fk = (float)k;
-#ifdef BLE_WHATIF_NO_SUN
-    SunState sun; sun.sin_el = 0.5f + 1e-3f * fk; sun.cos_el = 0.8f; sun.day = true; sun.sh33 = false; sun.sh27 = false;
-#else
     const SunState sun = sun_at(k);
-#endif
     const float flux = f_fma(fk, dfl, fl0);
 
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
@@ -174,11 +167,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-#ifdef BLE_WHATIF_NO_THERMAL
-    const double t_int_new = t_int + 1e-3 * (double)(flux * att);
-#else
     const double t_int_new = t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth);
-#endif
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
@@ -190,9 +179,6 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     // mass flow changes rho V - m by ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified
     // like the thermal increment's.
     double mdot_d;
-#ifdef BLE_WHATIF_NO_ACS
-    mdot_d = eff == kUp ? -0.01 : (eff == kDown ? 0.01 : 0.0); acs_w = eff == kDown ? 200.0f : 0.0f; mdot = (float)mdot_d;
-#else
     {
       constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
       // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
@@ -205,7 +191,6 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
       mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
       mdot = (float)mdot_d;
     }
-#endif
     double n_air_new = d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air);
     n_air_new = d_max(n_air_new, 0.0);
 
