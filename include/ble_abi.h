@@ -213,9 +213,11 @@ typedef struct ble_gp_history_f32 {
   int32_t* elapsed_s; /* [n][BLE_GP_CAPACITY]     time_elapsed of the observation */
   float* err_uv;      /* [n][BLE_GP_CAPACITY][2]  measured - forecast, m/s */
   int32_t* count;     /* [n] observations appended this episode; ring slot = count % BLE_GP_CAPACITY */
-  double* chol;       /* optional [n][BLE_GP_CHOL_STRIDE]: packed lower Cholesky factor of the current window's
-                         K + noise, carried from call to call so that the per-step refit of the reference
-                         (wind_gp.py:186-188) becomes an O(n^2) slide; NULL = refit in LDS every call */
+  double* chol;       /* optional [n][BLE_GP_CHOL_STRIDE]: the current window's K + noise = Lt D Lt^T (unit-lower Lt,
+                         d on the diagonal, packed lower triangle, 7260 doubles) followed by the drop vector
+                         p = L22^-1 l21 of the next slide (120 doubles), carried from call to call so that the
+                         per-step refit of the reference (wind_gp.py:186-188) becomes an O(n^2) slide;
+                         opaque to the caller; NULL = refit in LDS every call */
   int32_t* n_chol;    /* [n] rows of `chol` in use (required when chol != NULL), zero-initialised */
 } ble_gp_history_f32;
 int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
