@@ -77,7 +77,7 @@ struct ObsShared {
   double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
   double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
   double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
-  double exp2_frac[32];                  // 2^(j / 32): exp(x) = 2^k * 2^(j/32) * P5(r), |r| <= ln2 / 64
+  double exp2_frac[32];                  // s^2 2^(j / 32): s^2 exp(x) = 2^k * (s^2 2^(j/32)) * P5(r), |r| <= ln2 / 64
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20], sp[22];
@@ -91,7 +91,7 @@ struct ObsShared {
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
-// exp(x) for the kernel matrix K* (x = -distance <= 0): x = (32 k + j) ln2 / 32 + r, table of 2^(j/32) in LDS,
+// (scale *) exp(x) for the kernel matrix K* (x = -distance <= 0; the table carries the scale s^2): x = (32 k + j) ln2 / 32 + r, table of 2^(j/32) in LDS,
 // degree-5 Taylor in r (|r| <= ln2 / 64: truncation 2e-15).  15 instructions and 6 constants instead of the
 // 20 + 16 of the table-free d_exp_fast -- the sweep evaluates it 64 times per lane.
 __device__ __forceinline__ double exp_tab(double x, const double* tab) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     sh.column[lane] = acc;
   }
   BLE_SUB(0);        // prologue issued (state, latlng on wave 1, ring + factor loads)
-  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
+  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = kGpSigma2 * d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
   if (tid < 6) {
     double jc, frac;
     unix_day_fraction(now - 43200 + 25920 * (int64_t)tid, &jc, &frac);
@@ -774,14 +774,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const double y_last_u = sh.z[0][nr], y_last_v = sh.z[1][nr];   // raw errors of the newest observation (z is overwritten below)
     const int spec_sel = jq == 1 ? 1 : (jq == 3 ? 3 : 0);
     const bool use_spec = jq < kSpecial && jq != 2;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) V[t][I] = (d4){0.0, 0.0, 0.0, 0.0};
       if (I < nb) {
+        // the first product of each chain takes a literal-zero accumulator (no register zeroing)
         d4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         const double* arow = (16 * I + jq < nr ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
 #pragma unroll
         for (int J = 0; J < I; ++J)
@@ -789,20 +787,25 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           for (int c = 0; c < 4; ++c) {
             const double a = arow[16 * J + 4 * c];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], (J == 0 && c == 0) ? zero4 : acc[t], 0, 0, 0);
           }
         d4 R[NT];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
           const double a_row = sh.a[row], p_row = sh.loc[row][2];
-          const double live = row < nr ? kGpSigma2 : 0.0;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused)
+            // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused);
+            // s^2 is folded into the exp table; r = r2 / sqrt(r2) with a denormal-proof guard for r2 == 0
             const double dp = (level[t] - p_row) * (1.0 / 326.0);
             const double r2 = a_row + dp * dp;
-            R[t][v] = live * exp_tab(-(r2 * d_rsqrt(r2 > 0.0 ? r2 : 1.0)), sh.exp2_frac);
+            R[t][v] = exp_tab(-(r2 * d_rsqrt(r2 + 1e-300)), sh.exp2_frac);
+          }
+          if (16 * I + 16 > nr) {                             // scalar: only the last block holds virtual rows
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[t][v] = row < nr ? R[t][v] : 0.0;
           }
           if (wave == 0) {                                    // scalar branch: tile 0 holds the special columns
             // one unconditional LDS read + selects (a load under a per-lane condition becomes an exec-mask branch);
@@ -810,8 +813,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             const double spec = sh.z[spec_sel][row];
             R[0][v] = use_spec ? (row < nr ? spec : 0.0) : R[0][v];
           }
+          if (I > 0) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
+            for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
+          }
         }
         const double* drow = sh.dinv[I] + tri(jq) + g;
 #pragma unroll
@@ -819,8 +824,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           const double packed = drow[4 * c];                        // always inside dinv[I][136]; masked above the diagonal
           const double a = 4 * c + g <= jq ? packed : 0.0;            // packed lower triangle
 #pragma unroll
-          for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], V[t][I], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], c == 0 ? zero4 : V[t][I], 0, 0, 0);
         }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) V[t][I] = zero4;
       }
     }
     __syncthreads();                 // wave 0 has read the raw error vectors
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         if (g != t || col[t] < kSpecial || level_idx > hi_idx) continue;
         // the newest observation's row: K*(level, newest) = s^2 exp(-|level - p| / 326) (same x, y, t as the query)
         const double dpl = (level[t] - p) * (1.0 / 326.0);
-        const double val_last = kGpSigma2 * exp_tab(-__builtin_fabs(dpl), sh.exp2_frac) - cross[t];
+        const double val_last = exp_tab(-__builtin_fabs(dpl), sh.exp2_frac) - cross[t];        // (s^2 is in the table)
         const double ss = d_fma(val_last * val_last, inv_dn, ssq[t]);
         const double mu = d_fma(val_last, zl_u, mean_u[t]), mv = d_fma(val_last, zl_v, mean_v[t]);
         // forecast at this level from the blended column
