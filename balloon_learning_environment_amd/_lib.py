@@ -18,7 +18,7 @@ from balloon_learning_environment_amd import _abi
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BLE_HIP_LIB') or os.path.join(_PKG_DIR, 'libble_hip.so')   # override: experiments only
-_SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_step_core.h', 'ble_physics.h', 'ble_reset.h',
+_SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_step_core.h', 'ble_physics.h', 'ble_intrinsics.h', 'ble_reset.h',
                                                           'ble_observe.h', 'ble_noise.h', 'ble_decode.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
@@ -47,7 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
       hipcc = 'hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH, _SOURCES[0]]
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', os.path.join(_PKG_DIR, 'csrc'),
+           '-o', LIB_PATH, _SOURCES[0]]
     if verbose:
       cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
     subprocess.check_call(cmd)

@@ -1,0 +1,34 @@
+// ble_intrinsics.h -- the gfx950 instruction layer under the lane functions of ble_physics.h.
+// Device only (hipcc --offload-arch=gfx950).  The include guard is shared with the libm stand-in that the test
+// tooling force-includes first (g++ -include tests/emul/ble_intrinsics.h); the package builds only this one.
+#ifndef BLE_INTRINSICS_H_
+#define BLE_INTRINSICS_H_
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define BLE_FN __device__ __forceinline__
+#define BLE_CONST_TABLE __device__ __constant__ const
+#define BLE_NO_CONTRACT _Pragma("clang fp contract(off)")
+
+namespace ble {
+
+BLE_FN float f_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+BLE_FN float f_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+BLE_FN float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+BLE_FN float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32
+BLE_FN float f_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32
+BLE_FN float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BLE_FN double d_rint(double x) { return __builtin_rint(x); }
+BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
+BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)
+BLE_FN double d_max(double a, double b) { return __builtin_fmax(a, b); }
+BLE_FN double d_rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }   // v_rcp_f64: 4.3e-8 relative (measured)
+BLE_FN double d_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }   // v_rsq_f64: 5.0e-8 relative (measured)
+BLE_FN double d_frexp_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }   // [0.5, 1)
+BLE_FN int d_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+BLE_FN double d_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
+
+}  // namespace ble
+#endif  // BLE_INTRINSICS_H_

@@ -13,20 +13,13 @@
 //   dH = (T(p)/L) * expm1(k * log1p(d/p)),  k = -R_d L / g
 // instead of differencing two 17 km heights.
 //
-// The file also compiles as plain C++ (g++) so that tests/emul can triage numerics on
-// a machine without a GPU; that build is test tooling and is never loaded by the
-// package.  Reference paths are relative to /root/reference/balloon_learning_environment/.
+// Reference paths are relative to /root/reference/balloon_learning_environment/.
 #pragma once
-#include <math.h>
-#include <stdint.h>
-
-#if defined(__HIPCC__)
-#define BLE_FN __device__ __forceinline__
-#define BLE_DEVICE_BUILD 1
-#else
-#define BLE_FN static inline
-#define BLE_DEVICE_BUILD 0
-#endif
+// BLE_FN, BLE_CONST_TABLE and the thin intrinsic layer (f_exp2, f_log2, f_rcp, ..., d_rcp_seed, d_ldexp, d_min,
+// d_max): ble_intrinsics.h maps them onto gfx950 instructions.  (tests/emul force-includes a libm-based
+// stand-in with the same include guard to triage numerics on a machine without a GPU; nothing host-side
+// lives in this directory.)
+#include "ble_intrinsics.h"
 
 namespace ble {
 
@@ -63,49 +56,11 @@ enum : int { kOk = 0, kOutOfPower = 1, kBurst = 2, kZeroPressure = 3 };
 enum : uint32_t { kFlagPressureRange = 1u, kFlagAbsorptivity = 2u, kFlagSolarRange = 4u,
                   kFlagPowerTable = 16u, kFlagNonFinite = 32u };
 
-// ---------------------------------------------------------------- fast math wrappers
-#if BLE_DEVICE_BUILD
-BLE_FN float f_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
-BLE_FN float f_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
-BLE_FN float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
-BLE_FN float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32
-BLE_FN float f_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32
-BLE_FN float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-BLE_FN double d_rint(double x) { return __builtin_rint(x); }
-BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
-BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)
-BLE_FN double d_max(double a, double b) { return __builtin_fmax(a, b); }
-#else
-BLE_FN float f_exp2(float x) { return exp2f(x); }
-BLE_FN float f_log2(float x) { return log2f(x); }
-BLE_FN float f_rcp(float x) { return 1.0f / x; }
-BLE_FN float f_sqrt(float x) { return sqrtf(x); }
-BLE_FN float f_rsqrt(float x) { return 1.0f / sqrtf(x); }
-BLE_FN float f_fma(float a, float b, float c) { return fmaf(a, b, c); }
-BLE_FN double d_fma(double a, double b, double c) { return fma(a, b, c); }
-BLE_FN double d_rint(double x) { return rint(x); }
-BLE_FN double d_sqrt(double x) { return sqrt(x); }
-BLE_FN double d_min(double a, double b) { return fmin(a, b); }
-BLE_FN double d_max(double a, double b) { return fmax(a, b); }
-#endif
+// ---------------------------------------------------------------- fp64 helpers over the intrinsic layer
 // fp64 reciprocal / reciprocal-sqrt: hardware seed (v_rcp_f64 / v_rsq_f64, measured 4.3e-8 /
 // 5.0e-8 relative on gfx950) + ONE Newton step -> ~2e-15 / 4e-15 relative.  That is five
 // orders below what the vertical chain needs (1e-10) and avoids both the second step and the
 // v_div_scale/v_div_fixup ladder (inputs here are normal, positive, far from overflow).
-#if BLE_DEVICE_BUILD
-BLE_FN double d_rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }
-BLE_FN double d_rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
-BLE_FN double d_frexp_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }   // [0.5, 1)
-BLE_FN int d_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
-BLE_FN double d_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
-#else
-BLE_FN double d_rcp_seed(double x) { return (double)(1.0f / (float)x); }
-BLE_FN double d_rsq_seed(double x) { return (double)(1.0f / sqrtf((float)x)); }
-BLE_FN double d_frexp_mant(double x) { int e; return frexp(x, &e); }
-BLE_FN int d_frexp_exp(double x) { int e; frexp(x, &e); return e; }
-BLE_FN double d_ldexp(double x, int e) { return ldexp(x, e); }
-#endif
 BLE_FN double d_rcp(double x) {
   double r = d_rcp_seed(x);
   return d_fma(d_fma(-x, r, 1.0), r, r);
@@ -531,11 +486,6 @@ BLE_FN int envelope_safety(int action, float superpressure, uint8_t* fsm) {
   return action;
 }
 // power_safety.py:52-126.  Times in seconds relative to start_unix.
-#if defined(__clang__)
-#define BLE_NO_CONTRACT _Pragma("clang fp contract(off)")
-#else
-#define BLE_NO_CONTRACT
-#endif
 BLE_FN int power_safety(int action, int32_t now, float battery_wh, int32_t* sunrise_h, int32_t* sunset,
                         uint8_t* paused) {
   BLE_NO_CONTRACT
@@ -1090,12 +1040,7 @@ BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, do
 // acs.py:24-68.  prm1 = pressure_ratio - 1.
 // Fan-efficiency table acs.py:31-41, rows = power 100/200/300/400 W, columns = pressure
 // ratio 1.05 .. 1.35 step 0.025.  `tab` points at 4 x 13 floats (LDS copy in the kernel).
-#if BLE_DEVICE_BUILD
-__device__ __constant__
-#else
-static
-#endif
-const float kAcsEfficiency[4 * 13] = {
+BLE_CONST_TABLE float kAcsEfficiency[4 * 13] = {
     0.4f, 0.4f, 0.3f, 0.2f, 0.2f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
     0.4f, 0.3f, 0.3f, 0.30f, 0.25f, 0.23f, 0.20f, 0.15f, 0.12f, 0.10f, 0.0f, 0.0f, 0.0f,
     0.0f, 0.3f, 0.25f, 0.25f, 0.25f, 0.20f, 0.20f, 0.20f, 0.2f, 0.15f, 0.13f, 0.12f, 0.11f,

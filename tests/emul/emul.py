@@ -18,14 +18,14 @@ _SO = os.path.join(_HERE, 'libble_emul.so')
 
 
 def build():
-  srcs = [os.path.join(_HERE, 'ble_emul.cpp'),
+  srcs = [os.path.join(_HERE, 'ble_emul.cpp'), os.path.join(_HERE, 'ble_intrinsics.h'),
           os.path.join(_ROOT, 'balloon_learning_environment_amd', 'csrc', 'ble_physics.h'),
           os.path.join(_ROOT, 'balloon_learning_environment_amd', 'csrc', 'ble_step_core.h'),
           os.path.join(_ROOT, 'balloon_learning_environment_amd', 'csrc', 'ble_noise.h'),
           os.path.join(_ROOT, 'balloon_learning_environment_amd', 'csrc', 'ble_decode.h'),
           os.path.join(_ROOT, 'balloon_learning_environment_amd', 'csrc', 'ble_reset.h')]
   if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-    subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-o', _SO, srcs[0]])
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-include', os.path.join(_HERE, 'ble_intrinsics.h'), '-o', _SO, srcs[0]])
   return _SO
 
 
