@@ -392,7 +392,8 @@ def main():
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
         'value': hs['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': hs['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong' if args.config == 3 else 'weak',
-        'vs_baseline': None, 'dtype': 'f64 vertical chain + f32 (state stored f32)', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32+f64', 'data': 'synthetic',
+        'dtype_note': 'state stored f32; vertical chain (p, T, V, n_air, thermal and ACS increments) computed in f64, solar geometry / wind blend in f32',
         'config': {'workload': PRESETS[args.config] + (' [per-env grids]' if args.per_env_grids and args.config != 4 else ''),
                    'preset': f'configs[{args.config}]', 'envs_per_gpu': n, 'global_envs': hs['global_envs'],
                    'substeps_per_step': args.substeps, 'live_env_fraction_end': hs['live_env_fraction_end'],
