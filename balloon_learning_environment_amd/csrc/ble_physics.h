@@ -69,6 +69,9 @@ BLE_FN double d_rsqrt(double x) {
   double y = d_rsq_seed(x);
   return y * d_fma(-0.5 * x * y, y, 1.5);
 }
+// sqrt(x) = x rsqrt(x): 4e-15 relative, three instructions fewer than d_sqrt_fast's corrected form -- enough for the
+// vertical chain (needs ~1e-10 after the map's amplification)
+BLE_FN double d_sqrt_rs(double x) { return x * d_rsqrt(x); }   // x > 0
 BLE_FN double d_sqrt_fast(double x) {   // x > 0
   double y = d_rsqrt(x);
   double sq = x * y;
@@ -926,8 +929,8 @@ BLE_FN float solar_attenuation(float sin_el, float pressure, bool day) {
   const float root = f_sqrt(f_fma(t, t, 1229.0f));
   // sqrt(1229 + t^2) - t, written without cancellation for t > 0
   const float diff = t > 0.0f ? 1229.0f * f_rcp(root + t) : root - t;
-  const float airmass = 0.34764f * (pressure * (1.0f / 101325.0f)) * diff;
-  const float att = 0.5f * (f_exp(-0.65f * airmass) + f_exp(-0.95f * airmass));
+  const float airmass = (pressure * (0.34764f / 101325.0f)) * diff;
+  const float att = 0.5f * (f_exp2(airmass * (-0.65f * kLog2e)) + f_exp2(airmass * (-0.95f * kLog2e)));   // constants folded: 3 multiplies fewer
   return day ? att : 0.0f;
 }
 // solar_power (solar.py:515-536) with balloon_shadow (:212-236) folded in.
@@ -1030,7 +1033,7 @@ BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, do
   double vu = ((6830.0 + mols_air) * kGasConstantD * t_int) * rp;
   double b = -(1804.0 - 0.0199 * p);
   double c4 = 4.0 * 0.0199 * vu * p;
-  double v = 0.5 * (d_sqrt_fast(d_fma(b, b, c4)) - b);
+  double v = 0.5 * (d_sqrt_rs(d_fma(b, b, c4)) - b);
   bool slack = vu <= 1804.0;
   *volume = slack ? vu : v;
   *sp = slack ? 0.0 : (v - 1804.0) * (1.0 / 0.0199);

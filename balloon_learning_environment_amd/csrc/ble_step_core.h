@@ -160,8 +160,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     double yc = (double)f_exp2((-1.0f / 3.0f) * f_log2(volf));              // fp32 seed
     yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
     // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
-    const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * (dir * num) * rp * (yc * yc);
-    const double dh_dt = d_sqrt_fast(d_max(arg, 1e-30));                    // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
+    const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
+    const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
     const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, cur_hi, cur_lo, p, rp, dir, t_at_p);
     const double p_new = d_fma(inv_dh * dh_dt, 10.0, p);                    // dir * dir == 1
 
