@@ -172,8 +172,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
     superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new);
-    if (sp_new > 2380.0) status = kBurst;
-    if (sp_new <= 0.0) status = kZeroPressure;
+    // balloon.py:479-482: burst above 2 380 Pa, zero pressure at <= 0 (the status code is formed after the loop)
+    bool terminal = !(sp_new <= 2380.0) || sp_new <= 0.0;
 
     // ---- step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the
     // mass flow changes rho V - m by ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified
@@ -199,7 +199,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     charge = is_day ? solar_power(sun, att) : 0.0f;
     load = (is_day ? kDayLoad : kNightLoad) + acs_w;
     batt = f_clamp(f_fma(charge - load, kStride / 3600.0f, batt), 0.0f, kBatteryCapacity);
-    if (batt <= 0.0f) status = kOutOfPower;
+    terminal = terminal || batt <= 0.0f;          // balloon.py:541-542
 
     // ---- commit (balloon.py:322-325): every RHS above used the old state
     x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
@@ -223,8 +223,12 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
       t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_cur);
     }
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
-    if (status != kOk) { ++k; break; }     // balloon.py:327-328
+    if (terminal) { ++k; break; }          // balloon.py:327-328
   }
+  // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments)
+  if (sp > 2380.0) status = kBurst;
+  if (k > 0 && sp <= 0.0) status = kZeroPressure;
+  if (k > 0 && batt <= 0.0f) status = kOutOfPower;
 
   s.x = x; s.y = y; s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
   s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;
