@@ -64,7 +64,12 @@ struct ObsShared {
                                          // below the diagonal, d on it.  Rows 120 .. 127 (MFMA tile padding) are
                                          // identity and exist only virtually (zero_row, d = 1)
   union {
-    double el_table[kElevTable];         // phases 0-1: solar elevation at now + 180 s * (k - 240)
+    struct {
+      double el_table[kElevTable];       // phases 0-1: solar elevation at now + 180 s * (k - 240)
+      double pad0;
+      double pb3[kGpMax][2];             // phase 1: wave 3's own (p_k, beta_k) pairs (the two drop waves do not synchronise)
+      double brow[64];                   // phase 1: old factor row 64 (wave 3 overwrites it while wave 2 still reads it)
+    };
     double dinv[kGpRows / 16][136];      // phases 4-5: inverses of the 16 x 16 unit-lower diagonal blocks, packed lower
   };
   union {
@@ -87,7 +92,7 @@ struct ObsShared {
   unsigned long long ballot[2];
   int n_obs;
   int range_ok;
-  float role_t[3];
+  float role_t[4];
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
@@ -115,6 +120,25 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
 }
 
 BLE_FN int tri(int i) { return i * (i + 1) / 2; }
+
+// solar._find_solar_elevation_binary_search (solar.py:295-372) in table-index space: every instant the search
+// touches is min_t + 180 s * integer, i.e. an entry of the elevation table.  mode 0 min, 1 max, 2 |el - target|.
+// Same decisions as find_solar_elevation (ble_reset.h) on the same values.
+__device__ inline int find_in_table(const double* tab, int k_lo, int k_hi, int mode, double target) {
+  int low = 0, high = k_hi - k_lo;
+  auto obj = [&](int idx) {
+    const double el = tab[k_lo + idx];
+    return mode == 0 ? el : (mode == 1 ? -el : __builtin_fabs(el - target));
+  };
+  double ol = obj(low), oh = obj(high);
+#pragma unroll 1
+  while (high > low + 1) {
+    const int span = high - low;                 // midpoint = low + span / 2.0
+    if (ol < oh) { high = low + (span + 1) / 2; oh = obj(high); }   // ceil
+    else { low = low + span / 2; ol = obj(low); }                   // floor
+  }
+  return k_lo + ((ol < oh) ? low : high);
+}
 
 // Sum over the 4 lanes of a quad (lanes 4k .. 4k+3) with DPP quad_perm moves: no LDS traffic,
 // unlike a ds_bpermute-based shuffle.
@@ -198,6 +222,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #define BLE_SUB(i) do {} while (0)
 #endif
   BLE_MARK();
+  // The phases before the sweep are latency-bound chains on few lanes; the sweep of the other resident workgroup
+  // is throughput work.  Priority 1 here, 0 from the sweep on: -3 % per launch (measured).
+  __builtin_amdgcn_s_setprio(1);
   const int64_t env = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: `if (wave == ...)` is a real branch, not an exec mask
@@ -215,7 +242,30 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   if (wave == 1) {           // BalloonState.latlng once per environment (one wave; the others get it through LDS)
     latlng_f64((double)st.center_lat_deg[env], (double)st.center_lng_deg[env], x, y, &site.sin_lat, &site.cos_lat,
                &site.lng_deg);
-    if (lane == 0) { sh.site[0] = site.sin_lat; sh.site[1] = site.cos_lat; sh.site[2] = site.lng_deg; }
+    if (lane == 0) {
+      sh.site[0] = site.sin_lat; sh.site[1] = site.cos_lat; sh.site[2] = site.lng_deg;
+      // -- the ambient features that need only the state (features.py:400-470); this wave would otherwise wait
+      //    for wave 0's ephemeris nodes.  Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
+      //    rounding to float32.
+      const double soc = (double)st.battery_charge[env] * (1.0 / 3058.56);
+      const double d2 = x * x + y * y;
+      const double inv_d = d2 > 0.0 ? d_rsqrt(d2) : 0.0;
+      const double dist_km = d2 * inv_d * 1e-3;
+      const double sp_now = (double)st.superpressure[env];
+      const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) * d_rcp(p);
+      const int cmd = st.last_command[env];
+      const bool paused = st.power_paused[env] != 0 || st.env_fsm[env] != 0 || st.alt_fsm[env] != 0;
+      auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+      out[0] = (float)unit((p - 5000.0) * (1.0 / 9000.0));
+      out[1] = (float)soc;
+      out[5] = (float)(d2 > 0.0 ? -x * inv_d : 0.0);         // sin(atan2(-x, -y))
+      out[6] = (float)(d2 > 0.0 ? -y * inv_d : -1.0);        // cos(atan2(-x, -y)); atan2(-0, -0) = -pi
+      out[7] = (float)(dist_km * d_rcp(dist_km + 250.0));
+      out[8] = cmd == kUp ? 1.0f : 0.0f; out[9] = cmd == kStay ? 1.0f : 0.0f; out[10] = cmd == kDown ? 1.0f : 0.0f;
+      out[11] = paused ? 1.0f : 0.0f; out[12] = paused ? 0.0f : 1.0f;
+      out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) * (1.0 / 200.0));
+      out[15] = (float)ratio;
+    }
   }
 
   // ---- phase 0a: history ring
@@ -235,6 +285,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     chol_pre[i] = (chol_g != nullptr && e2 < kCholTri / 2) ? reinterpret_cast<const double2*>(chol_g)[e2] : make_double2(0.0, 0.0);
   }
   const double p_pre = (chol_g != nullptr && tid < kGpMax) ? chol_g[kCholTri + tid] : 0.0;
+  const double brow_pre = (chol_g != nullptr && tid >= 128 && tid < 192) ? chol_g[tri(64) + tid - 128] : 0.0;
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -409,6 +460,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       if (e2 < chol_pairs) reinterpret_cast<double2*>(sh.L)[e2] = chol_pre[i];
     }
     if (tid < kGpMax) sh.pb[tid][0] = p_pre;
+    if (tid >= 128 && tid < 192) sh.brow[tid - 128] = brow_pre;
   }
   // Rows of the factor the MFMA sweep works on.  Incremental: the window WITHOUT its newest observation
   // (that one becomes a bordering row, folded in after the sweep); refit: the whole window.
@@ -418,6 +470,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   __syncthreads();   // B2
 
   // ---- phase 1: three roles
+  double dnew_keep = 0.0;            // new diagonal entry of the row a drop lane owns (written after B3)
 #ifdef BLE_OBS_TIMING
   const long long role_t0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -425,56 +478,35 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     // -- ambient features (features.py:400-470).  solar.get_next_sunrise_sunset (solar.py:432-483) is two
     //    pairs of independent searches -- (noon, midnight), then (sunrise, sunset): each pair runs on lanes
     //    0 / 1 at once (same code, different bounds), the bounds of the second pair come by shuffle.
-    auto elev = [&](int64_t when) {          // |when - now| < 2 days: 32-bit arithmetic (a 64-bit / and % cost ~300 instructions)
-      const int32_t d = (int32_t)(when - now);
-      const int32_t q = d / 180;
-      const int32_t k = q + 240;
-      return (k >= 0 && k < kElevTable && d - q * 180 == 0) ? el_table[k] : site_elevation(site, when);
-    };
     const bool second = (lane & 1) != 0;
     const bool afternoon = sh.el_next < el_now;
-    const int64_t h12 = 12 * 3600, h24 = 24 * 3600;
-    // stage 1: noon (max elevation; lane 0) and midnight (min; lane 1), each inside its own half day
-    const int64_t lo1 = (second != afternoon) ? now + h12 : now;           // noon: [t, t+12h] in the morning, else [t+12h, t+24h]; midnight the other half
-    const int64_t ext = find_solar_elevation(elev, lo1, lo1 + h12, second ? 0 : 1, 0.0);
-    const int64_t noon = __shfl(ext, 0, 64), midnight = __shfl(ext, 1, 64);
+    // (table index k <-> now + 180 s (k - 240); every range below lies inside [now - 12 h, now + 24 h] = [0, 720])
+    // stage 1: noon (max elevation; lane 0) and midnight (min; lane 1), each inside its own half day:
+    // noon in [t, t + 12 h] in the morning, else [t + 12 h, t + 24 h]; midnight in the other half
+    const int lo1 = (second != afternoon) ? 480 : 240;
+    const int ext = find_in_table(el_table, lo1, lo1 + 240, second ? 0 : 1, 0.0);
+    const int noon = __shfl(ext, 0, 64), midnight = __shfl(ext, 1, 64);
     // stage 2: sunrise (lane 0) between the midnight before noon and noon; sunset (lane 1) between noon and midnight
-    const int64_t lo2 = second ? (afternoon ? noon - h24 : noon) : (afternoon ? midnight : midnight - h24);
-    const int64_t hi2 = second ? midnight : noon;
-    int64_t edge = find_solar_elevation(elev, lo2, hi2, 2, -4.242);
-    if (edge < now) edge += h24;
-    const int64_t sunrise = __shfl(edge, 0, 64), sunset = __shfl(edge, 1, 64);
-   if (lane == 0) {
-    double cycle;
-    if (sunset < sunrise) {   // day
-      const int64_t prev = sunrise - 86400;
-      cycle = kPiD * (double)(now - prev) / (double)(sunset - prev);
-    } else {
-      const int64_t prev = sunset - 86400;
-      cycle = kPiD + kPiD * (double)(now - prev) / (double)(sunrise - prev);
+    const int lo2 = second ? (afternoon ? noon - 480 : noon) : (afternoon ? midnight : midnight - 480);
+    const int hi2 = second ? midnight : noon;
+    int edge = find_in_table(el_table, lo2, hi2, 2, -4.242);
+    if (edge < 240) edge += 480;                           // not before now (solar.py:478-481)
+    const int sunrise = __shfl(edge, 0, 64), sunset = __shfl(edge, 1, 64);
+    if (lane == 0) {
+      // day: pi (now - previous sunrise) / (sunset - previous sunrise); night: pi + the same from the previous
+      // sunset to the sunrise.  In units of 180 s the quotients are those of the reference's seconds.
+      const bool day = sunset < sunrise;
+      const int prev = (day ? sunrise : sunset) - 480;
+      const double frac = (double)(240 - prev) / (double)((day ? sunset : sunrise) - prev);
+      const double cycle = day ? kPiD * frac : kPiD + kPiD * frac;
+      double sc, cc;
+      sincos_f64(cycle, &sc, &cc);
+      const double elc = (el_now + 90.0) * (1.0 / 180.0);
+      out[2] = (float)(elc < 0.0 ? 0.0 : (elc > 1.0 ? 1.0 : elc));
+      out[3] = (float)sc; out[4] = (float)cc;
+      const double soc = (double)st.battery_charge[env] * (1.0 / 3058.56);
+      out[13] = (soc > 0.99 && solar_power_f64(el_now, p) > 120.4) ? 1.0f : 0.0f;     // balloon.py:231-238
     }
-    double sc, cc;
-    sincos_f64(cycle, &sc, &cc);
-    const double batt = (double)st.battery_charge[env], soc = batt / 3058.56;
-    const double dist = sqrt(x * x + y * y);  // (one lane, once)
-    const double sp_now = (double)st.superpressure[env];
-    const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) / p;
-    const int cmd = st.last_command[env];
-    const bool paused = st.power_paused[env] != 0 || st.env_fsm[env] != 0 || st.alt_fsm[env] != 0;
-    auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
-    out[0] = (float)unit((p - 5000.0) / 9000.0);
-    out[1] = (float)soc;
-    out[2] = (float)unit((el_now + 90.0) / 180.0);
-    out[3] = (float)sc; out[4] = (float)cc;
-    out[5] = (float)(dist > 0.0 ? -x / dist : 0.0);        // sin(atan2(-x, -y))
-    out[6] = (float)(dist > 0.0 ? -y / dist : -1.0);       // cos(atan2(-x, -y)); atan2(-0, -0) = -pi
-    out[7] = (float)((dist / 1000.0) / (dist / 1000.0 + 250.0));
-    out[8] = cmd == kUp ? 1.0f : 0.0f; out[9] = cmd == kStay ? 1.0f : 0.0f; out[10] = cmd == kDown ? 1.0f : 0.0f;
-    out[11] = paused ? 1.0f : 0.0f; out[12] = paused ? 0.0f : 1.0f;
-    out[13] = (solar_power_f64(el_now, p) > 120.4 && soc > 0.99) ? 1.0f : 0.0f;     // balloon.py:231-238
-    out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) / 200.0);
-    out[15] = (float)ratio;
-   }
   } else if (wave == 1) {
     if (lane < 22) {
       const double ceiling = pressure_ceiling(sh.lev, sh.pot);
@@ -484,8 +516,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.sp[lane] = s.sp;
       flags |= local;
     }
+    // ---- reachable pressure range (pressure_range_builder.py:249-275), as soon as the 22 superpressures exist
+    wave_sync_lds();
+    if (lane == 0) {
+      int ok = 1;
+      const double ceiling = pressure_ceiling(sh.lev, sh.pot);
+      sh.p_lo = safe_pressure_search(sh.lev, sh.sp, ceiling, sh.sp[20], true, &ok);
+      sh.p_hi = safe_pressure_search(sh.lev, sh.sp, p_floor, sh.sp[21], false, &ok);
+      sh.range_ok = ok;
+    }
   } else if (wave >= 2 && incremental) {
-    if (wave == 2) {
+    if (wave == 2 || n_dropped == 1) {
       // ---- drop the oldest observation: lane owns rows `lane` and `lane + 64` of the new factor
       //   K = [k11 k21^T; k21 K22] = Lt D Lt^T with Lt = [1 0; l21 L22], D = diag(d1, D2)
       //   =>  K22 = L22 D2 L22^T + d1 l21 l21^T : a rank-1 update of the trailing LDL^T factor
@@ -503,53 +544,87 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       if (n_dropped == 1) {
         const int rows = n_chol0 - 1;                                     // == nr
         const bool own0 = lane < rows, own1 = lane + 64 < rows;
-        const double dk0 = own0 ? sh.L[tri(lane + 1) + lane + 1] : 1.0, dk1 = own1 ? sh.L[tri(lane + 65) + lane + 65] : 1.0;
-        const double pk0 = own0 ? sh.pb[lane][0] : 0.0, pk1 = own1 ? sh.pb[lane + 64][0] : 0.0;
-        const double idk0 = d_rcp(dk0), idk1 = d_rcp(dk1);
-        const double t0 = pk0 * pk0 * idk0, t1 = pk1 * pk1 * idk1;
+        const double dk0 = own0 ? sh.L[tri(lane + 1) + lane + 1] : 1.0;
+        const double pk0 = own0 ? sh.pb[lane][0] : 0.0;
+        const double idk0 = d_rcp(dk0);
+        const double t0 = pk0 * pk0 * idk0;
         const double s0 = wave_inclusive_scan(t0, lane);
-        const double s1 = wave_inclusive_scan(t1, lane) + readlane_f64(s0, 63);
         const double gamma_start = d_rcp(sh.L[0]);                         // 1 / d1 of the dropped row
         const double gnew0 = gamma_start + s0, gprev0 = gamma_start + (s0 - t0);
-        const double gnew1 = gamma_start + s1, gprev1 = gamma_start + (s1 - t1);
-        const double rg0 = d_rcp(gnew0), rg1 = d_rcp(gnew1);
-        const double dnew0 = dk0 * gnew0 * d_rcp(gprev0), dnew1 = dk1 * gnew1 * d_rcp(gprev1);
-        const double inv0 = idk0 * gprev0 * rg0, inv1 = idk1 * gprev1 * rg1;  // 1 / d'_k
-        double w0 = own0 ? sh.L[tri(lane + 1)] : 0.0;                      // l21
-        double w1 = own1 ? sh.L[tri(lane + 65)] : 0.0;
-        // old row r + 1 shifted one column (lanes that own no row read in-bounds garbage into private registers)
-        const double* old0 = sh.L + tri(own0 ? lane + 1 : 1) + 1;
-        const double* old1 = sh.L + tri(own1 ? lane + 65 : 1) + 1;
-        double* new0 = sh.L + tri(lane);
-        double* new1 = sh.L + tri(lane + 64);
-        wave_sync_lds();                                                    // every old diagonal / p has been read
-        if (own0) sh.pb[lane][1] = pk0 * rg0 * idk0;                         // beta_k
-        if (own1) sh.pb[lane + 64][1] = pk1 * rg1 * idk1;
-        wave_sync_lds();
-        const double2* pbv = reinterpret_cast<const double2*>(&sh.pb[0][0]);
-        // four columns per round: their (p, beta) pairs and old entries are loaded together (one LDS round
-        // trip per round instead of per column), then the four dependent FMA pairs run from registers
-        const int last_col = rows - 2;                                     // row r has columns 0 .. r - 1
-        for (int k0 = 0; k0 <= last_col; k0 += 4) {
-          double2 pbq[4]; double l0q[4], l1q[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int kk = k0 + j <= last_col ? k0 + j : last_col;
-            pbq[j] = pbv[kk]; l0q[j] = old0[kk]; l1q[j] = old1[kk];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int k = k0 + j;
-            w0 = d_fma(-pbq[j].x, l0q[j], w0);
-            w1 = d_fma(-pbq[j].x, l1q[j], w1);
-            const double n0 = d_fma(pbq[j].y, w0, l0q[j]), n1 = d_fma(pbq[j].y, w1, l1q[j]);
-            *((own0 && lane > k) ? new0 + k : sh.pad + lane) = n0;
-            *((own1 && lane + 64 > k && k <= last_col) ? new1 + k : sh.pad + lane) = n1;
-          }
+        const double rg0 = d_rcp(gnew0);
+        const double2* pbv;
+        const double* old_row;
+        double* new_row;
+        double w, inv_new;
+        bool own;
+        int my_row;
+        if (wave == 2) {
+          // rows 0 .. 63.  Old row 64 -- the source of new row 63 -- is overwritten by wave 3's row 64: lane 63
+          // reads the copy made before the barrier (brow[0] = l21, brow[1 + k] = column k)
+          own = own0; my_row = lane;
+          dnew_keep = dk0 * gnew0 * d_rcp(gprev0);
+          inv_new = idk0 * gprev0 * rg0;                                     // 1 / d'_k
+          const double* src = lane == 63 ? sh.brow : sh.L + tri(own0 ? lane + 1 : 1);
+          w = own0 ? src[0] : 0.0;                                           // l21
+          old_row = src + 1;                                                 // old row r + 1 shifted one column
+          new_row = sh.L + tri(lane);
+          wave_sync_lds();                                                   // every p has been read
+          if (own0) sh.pb[lane][1] = pk0 * rg0 * idk0;                        // beta_k
+          pbv = reinterpret_cast<const double2*>(&sh.pb[0][0]);
+        } else {
+          // rows 64 .. 118, with a private copy of all the (p, beta) pairs (the waves do not synchronise)
+          own = own1; my_row = lane + 64;
+          const double dk1 = own1 ? sh.L[tri(lane + 65) + lane + 65] : 1.0;
+          const double pk1 = own1 ? sh.pb[lane + 64][0] : 0.0;
+          const double idk1 = d_rcp(dk1);
+          const double t1 = pk1 * pk1 * idk1;
+          const double s1 = wave_inclusive_scan(t1, lane) + readlane_f64(s0, 63);
+          const double gnew1 = gamma_start + s1, gprev1 = gamma_start + (s1 - t1);
+          const double rg1 = d_rcp(gnew1);
+          dnew_keep = dk1 * gnew1 * d_rcp(gprev1);
+          inv_new = idk1 * gprev1 * rg1;
+          w = own1 ? sh.L[tri(lane + 65)] : 0.0;
+          old_row = sh.L + tri(own1 ? lane + 65 : 1) + 1;
+          new_row = sh.L + tri(lane + 64);
+          double2* mine = reinterpret_cast<double2*>(sh.pb3);
+          if (own0) mine[lane] = make_double2(pk0, pk0 * rg0 * idk0);
+          if (own1) mine[lane + 64] = make_double2(pk1, pk1 * rg1 * idk1);
+          pbv = mine;
         }
         wave_sync_lds();
-        if (own0) { new0[lane] = dnew0; sh.inv_diag[lane] = inv0; }
-        if (own1) { new1[lane + 64] = dnew1; sh.inv_diag[lane + 64] = inv1; }
+        // (lanes that own no row read in-bounds garbage into private registers)
+        // four columns per round: their (p, beta) pairs and old entries are loaded together (one LDS round
+        // trip per round instead of per column), then the four dependent FMA pairs run from registers
+        const int last_col = (wave == 2 ? (rows < 64 ? rows : 64) : rows) - 2;   // row r has columns 0 .. r - 1
+        if (wave == 2 || rows > 64) {
+          // Rounds of four columns, no clamps inside: constant LDS offsets from three running pointers.  A lane
+          // stores column k only while k < its row index; otherwise the value goes to a per-lane sink (z[2..3]
+          // are idle until the sweep) -- a select between two base addresses, not a branch.
+          const int row_lim = own ? my_row : 0;
+          const double* src = old_row;
+          double* dst = new_row;
+          double* sink = &sh.z[2][0] + 4 * lane;
+          int k0 = 0;
+          for (; k0 + 3 <= last_col; k0 += 4, src += 4, dst += 4, pbv += 4) {
+            double2 pbq[4]; double lq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pbq[j] = pbv[j]; lq[j] = src[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              w = d_fma(-pbq[j].x, lq[j], w);
+              const double nv = d_fma(pbq[j].y, w, lq[j]);
+              (row_lim > k0 + j ? dst : sink)[j] = nv;
+            }
+          }
+          for (; k0 <= last_col; ++k0, ++src, ++dst, ++pbv) {
+            const double2 pbq = pbv[0];
+            const double lq = src[0];
+            w = d_fma(-pbq.x, lq, w);
+            const double nv = d_fma(pbq.y, w, lq);
+            (row_lim > k0 ? dst : sink)[0] = nv;
+          }
+          if (own) sh.inv_diag[my_row] = inv_new;      // (the new diagonal itself is written after the barrier, below)
+        }
       } else {
         if (lane < nr) sh.inv_diag[lane] = d_rcp(sh.L[tri(lane) + lane]);
         if (lane + 64 < nr) sh.inv_diag[lane + 64] = d_rcp(sh.L[tri(lane + 64) + lane + 64]);
@@ -585,19 +660,16 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     for (int i = n_obs + (tid - 128); i < n_pad; i += 128) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
   }
 #ifdef BLE_OBS_TIMING
-  if (tid == 0 || tid == 64 || tid == 128)
+  if ((tid & 63) == 0)
     sh.role_t[tid >> 6] = (float)((long long)__builtin_readcyclecounter() - role_t0);
 #endif
   __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
   BLE_MARK();
-
-  // ---- reachable pressure range (pressure_range_builder.py:249-275)
-  if (tid == 0) {
-    int ok = 1;
-    const double ceiling = pressure_ceiling(sh.lev, sh.pot);
-    sh.p_lo = safe_pressure_search(sh.lev, sh.sp, ceiling, sh.sp[20], true, &ok);
-    sh.p_hi = safe_pressure_search(sh.lev, sh.sp, p_floor, sh.sp[21], false, &ok);
-    sh.range_ok = ok;
+  // the drop's new diagonal: wave 3 read the old diagonals of wave 2's rows, so they are replaced only now
+  // (no reader before the epilogue: the sweep works on 1 / d in inv_diag and on strictly-lower entries)
+  if (wave >= 2 && incremental && n_dropped == 1) {
+    const int r = lane + 64 * (wave - 2);
+    if (r < nr) sh.L[tri(r) + r] = dnew_keep;
   }
 
   // ---- phase 2: Cholesky, left-looking, panels of 8 columns.  Thread (slot, half): slot = row
@@ -932,6 +1004,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   // tile T = 4 t + wave: a wave needs its third tile (t = 2) only if tile 8 + wave exists.  About one
   // environment in five has 125+ reachable levels (9 tiles): there wave 0 sweeps three tiles, the others two
   // (both instantiations run the same three barriers).
+  __builtin_amdgcn_s_setprio(0);
   if (wave + 8 < n_tiles) sweep(std::integral_constant<int, 3>{});
   else sweep(std::integral_constant<int, 2>{});
   // padding above and below the 181 real levels, and the unreachable levels: certain, wrong way, infinitely fast
@@ -948,6 +1021,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   {
     for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
+    out[kObsDim - 13] = sh.role_t[3];
     for (int k = 0; k < 4; ++k) out[kObsDim - 20 + k] = (float)(tsub[k] - tmark[0]);
     out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
   }

@@ -21,10 +21,14 @@ for i in range(125):
 sim.check_errors()
 import os
 if os.environ.get('BLE_HIP_LIB'):
-  t = obs[:, -7:].double().mean(0).cpu().numpy()
-  names = ['phase0 (hist, elev table, column)', 'phase1 (ambient | newton | K)', 'phase2 cholesky', 'phase3 alpha', 'phase4 queries', '', '']
-  for a, b in zip(names, t):
-    print('%-40s %10.0f cycles' % (a, b))
-if os.environ.get('BLE_HIP_LIB'):
-  r = obs[:, -12:-9].double().mean(0).cpu().numpy()
-  print('phase-1 roles: ambient %.0f, newton %.0f, K build %.0f cycles' % tuple(r))
+  # layout written by the -DBLE_OBS_TIMING epilogue of ble_observe_kernel (csrc/ble_observe.h)
+  o = obs.double().mean(0).cpu().numpy()
+  D = 1099
+  marks = o[D - 11:D - 5]
+  names = ['phase 0 (prologue, elevation table, ring) -> B1', 'compaction + phase 1 (ambient | newton | drop) -> B3',
+           'refit cholesky (0 when the factor is carried)', '-', 'diagonal-block inverses', 'sweep + features']
+  for a, b in zip(names, marks):
+    print('%-55s %10.0f cycles' % (a, b))
+  print('phase-1 roles: ambient %.0f, newton + range %.0f, drop rows 0-63 %.0f, drop rows 64+ %.0f cycles' % tuple(o[D - 16:D - 12]))
+  print('phase-0 sub-marks from kernel start: prologue issued %.0f, nodes+site ready %.0f, table filled %.0f' % tuple(o[D - 20:D - 17]))
+  print('tiles %.2f, reachable levels %.1f, share with a 9th tile %.3f' % (o[D - 4], o[D - 3], o[D - 2]))
