@@ -83,6 +83,7 @@ struct ObsShared {
   double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
   double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
   double exp2_frac[32];                  // s^2 2^(j / 32): s^2 exp(x) = 2^k * (s^2 2^(j/32)) * P5(r), |r| <= ln2 / 64
+  double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20], sp[22];
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     sh.column[lane] = acc;
   }
   BLE_SUB(0);        // prologue issued (state, latlng on wave 1, ring + factor loads)
+  if (tid >= 96 && tid < 112) sh.zeros16[tid - 96] = 0.0;
   if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = kGpSigma2 * d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
   if (tid < 6) {
     double jc, frac;
@@ -791,8 +793,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         double t = r == c ? 1.0 : 0.0;
+        const double* lrow = base + r < nr ? sh.L + tri(base + r) + base : sh.zeros16;   // one select per row, not per entry
 #pragma unroll
-        for (int k = 0; k < r; ++k) t = d_fma(-(base + r < nr ? sh.L[tri(base + r) + base + k] : 0.0), xcol[k], t);
+        for (int k = 0; k < r; ++k) t = d_fma(-lrow[k], xcol[k], t);
         xcol[r] = (r < c) ? 0.0 : t;                          // unit diagonal
       }
 #pragma unroll
