@@ -76,13 +76,13 @@ struct ObsShared {
     double zero_row[112];                // phases 4-5: the off-diagonal part of a virtual identity row
     double pb[kGpMax][2];                // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
   };
-  double loc[kGpRows][4];                // x, y, p, t of the observations in the window
+  double loc[kGpRows][4];                // x, y, p / 326 Pa, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
   double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
   double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
   double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
-  double exp2_frac[32];                  // s^2 2^(j / 32): s^2 exp(x) = 2^k * (s^2 2^(j/32)) * P5(r), |r| <= ln2 / 64
+  double exp2_frac[32];                  // s^2 2^(-j / 32): s^2 exp(-r) = 2^-k * (s^2 2^(-j/32)) * P5(rem), |rem| <= ln2 / 64
   double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
@@ -97,17 +97,24 @@ struct ObsShared {
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
-// (scale *) exp(x) for the kernel matrix K* (x = -distance <= 0; the table carries the scale s^2): x = (32 k + j) ln2 / 32 + r, table of 2^(j/32) in LDS,
-// degree-5 Taylor in r (|r| <= ln2 / 64: truncation 2e-15).  15 instructions and 6 constants instead of the
-// 20 + 16 of the table-free d_exp_fast -- the sweep evaluates it 64 times per lane.
-__device__ __forceinline__ double exp_tab(double x, const double* tab) {
-  const double n = d_rint(x * 46.16624130844682903);                 // 32 / ln 2
-  double r = d_fma(n, -2.16608493865351192653e-02, x);               // ln2 / 32 hi (low bits zero)
-  r = d_fma(n, -5.96317165397058656257e-12, r);                      // ln2 / 32 lo
+// s^2 exp(-r), r >= 0, for the kernel matrix K* (the table carries the scale s^2 and the sign: tab[j] = s^2 2^(-j/32)):
+// r = (32 k + j) ln2 / 32 - rem, |rem| <= ln2 / 64, degree-5 Taylor in rem (truncation 2e-15).  One fused reduction
+// step: n ln2/32 is exact inside the FMA and n <= ~1500, so the rounding of the constant costs <= 3e-15 absolute.
+// 11 fp64 instructions (the table-free d_exp_fast: 20 + 16 constants) -- the sweep evaluates it 64 times per lane.
+__device__ __forceinline__ double exp_neg_tab(double r, const double* tab) {
+  const double n = d_rint(r * 46.16624130844682903);                  // 32 / ln 2
+  const double rem = d_fma(n, 2.16608493924982909192e-02, -r);        // ln2 / 32
   const int ni = (int)n;
   const double t = tab[ni & 31];
-  const double pr = d_fma(r, d_fma(r, d_fma(r, d_fma(r, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
-  return d_ldexp(t * d_fma(r, pr, 1.0), ni >> 5);
+  const double pr = d_fma(rem, d_fma(rem, d_fma(rem, d_fma(rem, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  return d_ldexp(d_fma(t * rem, pr, t), -(ni >> 5));
+}
+// sqrt(x), x >= 1e-300: one coupled Newton step on (g, h) = (x y, y / 2) from the 5e-8 seed y = rsq(x): 4e-15 relative,
+// five instructions
+__device__ __forceinline__ double sqrt_coupled(double x) {
+  const double y = d_rsq_seed(x);
+  const double g = x * y, h = 0.5 * y;
+  return d_fma(g, d_fma(-g, h, 0.5), g);
 }
 
 // inclusive prefix sum over the 64 lanes of a wave
@@ -223,6 +230,15 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #define BLE_SUB(i) do {} while (0)
 #endif
   BLE_MARK();
+#ifdef BLE_OBS_PHASE_PROFILE
+  // profiles/obs_phases.py: `append` carries a stop code in bits 8.. -- the launch returns after that phase, so
+  // that per-phase instruction counts are differences of PMC runs (nothing is committed: count and factor stay)
+  const int stop_after = append >> 8;
+  append &= 1;
+#define BLE_STOP(k) do { if (stop_after == (k)) return; } while (0)
+#else
+#define BLE_STOP(k) do {} while (0)
+#endif
   // The phases before the sweep are latency-bound chains on few lanes; the sweep of the other resident workgroup
   // is throughput work.  Priority 1 here, 0 from the sweep on: -3 % per launch (measured).
   __builtin_amdgcn_s_setprio(1);
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   BLE_SUB(0);        // prologue issued (state, latlng on wave 1, ring + factor loads)
   if (tid >= 96 && tid < 112) sh.zeros16[tid - 96] = 0.0;
-  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = kGpSigma2 * d_exp_fast((double)(tid - 64) * (6.93147180559945286227e-01 / 32.0));
+  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = kGpSigma2 * d_exp_fast((double)(tid - 64) * (-6.93147180559945286227e-01 / 32.0));
   if (tid < 6) {
     double jc, frac;
     unix_day_fraction(now - 43200 + 25920 * (int64_t)tid, &jc, &frac);
@@ -419,6 +435,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   __syncthreads();   // B1
   BLE_MARK();
+  BLE_STOP(1);
 
   // ---- phase 0c: compact the window into LDS (chronological)
   int n_obs = sh.wave_count[0] + sh.wave_count[1];
@@ -427,11 +444,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   if (wave < 2 && valid) {
     const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
     if (at >= 0) {
-      sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op; sh.loc[at][3] = (double)ot;
+      sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op * (1.0 / 326.0); sh.loc[at][3] = (double)ot;
       sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
       const double dx = ((double)ox - x) * (1.0 / 357000.0), dy = ((double)oy - y) * (1.0 / 357000.0),
                    dt = ((double)ot - (double)elapsed) * (1.0 / 34560.0);
-      sh.a[at] = dx * dx + dy * dy + dt * dt;
+      sh.a[at] = dx * dx + dy * dy + dt * dt + 1e-300;     // (the guard keeps rsq finite when an observation sits at the query)
     }
   }
   const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       if (i < n_obs) {
         // (a - b) / length_scale as a multiplication by the rounded reciprocal: 1e-16 relative
         const double d0 = (sh.loc[i][0] - sh.loc[j][0]) * (1.0 / 357000.0), d1 = (sh.loc[i][1] - sh.loc[j][1]) * (1.0 / 357000.0),
-                     d2 = (sh.loc[i][2] - sh.loc[j][2]) * (1.0 / 326.0), d3 = (sh.loc[i][3] - sh.loc[j][3]) * (1.0 / 34560.0);
+                     d2 = sh.loc[i][2] - sh.loc[j][2], d3 = (sh.loc[i][3] - sh.loc[j][3]) * (1.0 / 34560.0);
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         const double r = r2 > 0.0 ? r2 * d_rsqrt(r2) : 0.0;
         k_ij = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #endif
   __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
   BLE_MARK();
+  BLE_STOP(2);
   // the drop's new diagonal: wave 3 read the old diagonals of wave 2's rows, so they are replaced only now
   // (no reader before the epilogue: the sweep works on 1 / d in inv_diag and on strictly-lower entries)
   if (wave >= 2 && incremental && n_dropped == 1) {
@@ -807,6 +825,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   __syncthreads();
   BLE_MARK();
+  BLE_STOP(3);
   // (lane 0's pressure-range search above is ordered before these reads by the barrier)
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
@@ -846,6 +865,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       level[t] = 5000.0 + 50.0 * (double)(lo_idx + col[t] - kSpecial);
     }
     if (wave == 0 && jq == 2) level[0] = p;         // column 2: the newest observation's own pressure
+    double level_s[NT];                             // in units of the pressure length scale
+#pragma unroll
+    for (int t = 0; t < NT; ++t) level_s[t] = level[t] * (1.0 / 326.0);
     const double y_last_u = sh.z[0][nr], y_last_v = sh.z[1][nr];   // raw errors of the newest observation (z is overwritten below)
     const int spec_sel = jq == 1 ? 1 : (jq == 3 ? 3 : 0);
     const bool use_spec = jq < kSpecial && jq != 2;
@@ -873,10 +895,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused);
-            // s^2 is folded into the exp table; r = r2 / sqrt(r2) with a denormal-proof guard for r2 == 0
-            const double dp = (level[t] - p_row) * (1.0 / 326.0);
-            const double r2 = a_row + dp * dp;
-            R[t][v] = exp_tab(-(r2 * d_rsqrt(r2 + 1e-300)), sh.exp2_frac);
+            // s^2 is folded into the exp table; a_row carries a 1e-300 guard for r2 == 0
+            const double dp = level_s[t] - p_row;
+            R[t][v] = exp_neg_tab(sqrt_coupled(d_fma(dp, dp, a_row)), sh.exp2_frac);
           }
           if (16 * I + 16 > nr) {                             // scalar: only the last block holds virtual rows
 #pragma unroll
@@ -908,10 +929,15 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
     __syncthreads();                 // wave 0 has read the raw error vectors
     if (wave == 0 && jq < kSpecial) {       // the special columns of tile 0
+      // zeta_u, zeta_v, omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
+      // the new row of the factor), the e_0 solution raw
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) sh.z[jq][16 * I + 4 * v + g] = V[0][I][v];
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + 4 * v + g;
+          sh.z[jq][row] = jq < 3 ? V[0][I][v] * sh.inv_diag[row] : V[0][I][v];
+        }
     }
     __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
@@ -926,7 +952,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
           const double inv_d = sh.inv_diag[row];
-          const double zu = sh.z[0][row] * inv_d, zv = sh.z[1][row] * inv_d, zw = sh.z[2][row] * inv_d;
+          const double zu = sh.z[0][row], zv = sh.z[1][row], zw = sh.z[2][row];      // (already / d)
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const double val = V[t][I][v];                // (Lt^-1 k*)_row
@@ -956,7 +982,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
     // new row of the factor and next call's drop vector, straight from the solved columns
     if (has_last) {
-      for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i] * sh.inv_diag[i];
+      for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i];
     }
     __syncthreads();
     if (has_last && tid == 0) sh.L[tri(nr) + nr] = sh.last[2];
@@ -967,19 +993,26 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const double inv_dn = has_last ? d_rcp(sh.last[2]) : 0.0;
     const double zl_u = has_last ? sh.last[0] * inv_dn : 0.0, zl_v = has_last ? sh.last[1] * inv_dn : 0.0;
     {
-      // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g
+      // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g (ONE instance of
+      // the tail below for all tiles of the wave: the inputs are selected by g)
+      int col_m = col[0];
+      double level_m = level[0], ssq_m = ssq[0], mean_u_m = mean_u[0], mean_v_m = mean_v[0], cross_m = cross[0];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int level_idx = lo_idx + col[t] - kSpecial;
-        if (g != t || col[t] < kSpecial || level_idx > hi_idx) continue;
+      for (int t = 1; t < NT; ++t) {
+        const bool mine = g == t;
+        col_m = mine ? col[t] : col_m; level_m = mine ? level[t] : level_m; ssq_m = mine ? ssq[t] : ssq_m;
+        mean_u_m = mine ? mean_u[t] : mean_u_m; mean_v_m = mine ? mean_v[t] : mean_v_m; cross_m = mine ? cross[t] : cross_m;
+      }
+      const int level_idx = lo_idx + col_m - kSpecial;
+      if (g < NT && col_m >= kSpecial && level_idx <= hi_idx) {
         // the newest observation's row: K*(level, newest) = s^2 exp(-|level - p| / 326) (same x, y, t as the query)
-        const double dpl = (level[t] - p) * (1.0 / 326.0);
-        const double val_last = exp_tab(-__builtin_fabs(dpl), sh.exp2_frac) - cross[t];        // (s^2 is in the table)
-        const double ss = d_fma(val_last * val_last, inv_dn, ssq[t]);
-        const double mu = d_fma(val_last, zl_u, mean_u[t]), mv = d_fma(val_last, zl_v, mean_v[t]);
+        const double dpl = (level_m - p) * (1.0 / 326.0);
+        const double val_last = exp_neg_tab(__builtin_fabs(dpl), sh.exp2_frac) - cross_m;        // (s^2 is in the table)
+        const double ss = d_fma(val_last * val_last, inv_dn, ssq_m);
+        const double mu = d_fma(val_last, zl_u, mean_u_m), mv = d_fma(val_last, zl_v, mean_v_m);
         // forecast at this level from the blended column
         int ip; float wp;
-        wind_axis((float)level[t], 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
+        wind_axis((float)level_m, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
         const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
         const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
         const double u = mu + (double)fu, v = mv + (double)fv;
