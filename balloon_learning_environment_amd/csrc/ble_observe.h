@@ -93,7 +93,7 @@ struct ObsShared {
   unsigned long long ballot[2];
   int n_obs;
   int range_ok;
-  float role_t[4];
+  float role_t[4], sw1[5];
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
@@ -220,14 +220,22 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
                                                                 int append, float* __restrict__ obs,
                                                                 uint32_t* err_flags, int64_t n) {
   __shared__ ObsShared sh;
+#ifdef BLE_OBS_SOLO
+  __shared__ double solo_pad[9000];          // timing experiments: one workgroup per CU
+  if (threadIdx.x == 0 && n < 0) solo_pad[obs != nullptr] = 1.0;
+  if (n < 0) obs[0] = (float)solo_pad[1];
+#endif
 #ifdef BLE_OBS_TIMING
   long long tmark[12]; int nmark = 0;
   long long tsub[5] = {0, 0, 0, 0, 0};
+  long long tsw[6] = {0, 0, 0, 0, 0, 0};
+#define BLE_SW(i) do { tsw[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
 #define BLE_SUB(i) do { tsub[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define BLE_MARK() do {} while (0)
 #define BLE_SUB(i) do {} while (0)
+#define BLE_SW(i) do {} while (0)
 #endif
   BLE_MARK();
 #ifdef BLE_OBS_PHASE_PROFILE
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int nr = has_last ? n_obs - 1 : n_obs;
   __syncthreads();   // B2
 
-  // ---- phase 1: three roles
+  // ---- phase 1: four roles
   double dnew_keep = 0.0;            // new diagonal entry of the row a drop lane owns (written after B3)
 #ifdef BLE_OBS_TIMING
   const long long role_t0 = (long long)__builtin_readcyclecounter();
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   __syncthreads();
   BLE_MARK();
   BLE_STOP(3);
-  // (lane 0's pressure-range search above is ordered before these reads by the barrier)
+  // (the pressure-range search ran on wave 1 in phase 1: two barriers ago)
   const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
@@ -927,6 +935,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         for (int t = 0; t < NT; ++t) V[t][I] = zero4;
       }
     }
+    BLE_SW(0);       // core done (this wave)
     __syncthreads();                 // wave 0 has read the raw error vectors
     if (wave == 0 && jq < kSpecial) {       // the special columns of tile 0
       // zeta_u, zeta_v, omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
@@ -942,6 +951,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
     // the same sum against omega = Lt^-1 k_new
+    BLE_SW(1);       // special columns in LDS
     double ssq[NT], mean_u[NT], mean_v[NT], cross[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { ssq[t] = 0.0; mean_u[t] = 0.0; mean_v[t] = 0.0; cross[t] = 0.0; }
@@ -971,6 +981,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
       cross[t] += __shfl_xor(cross[t], 16, 64); cross[t] += __shfl_xor(cross[t], 32, 64);
     }
+    BLE_SW(2);       // sums accumulated and reduced
     // ---- the bordering row (the newest observation, window entry nr): Lt_full = [Lt 0; r^T 1], r = omega / d,
     //   d_new = k_nn + noise - sum omega^2 / d,   (Lt_full^-1 b)_last = b_last - sum_i r_i (Lt^-1 b)_i
     if (wave == 0 && g == 0 && jq < kSpecial) {
@@ -1043,6 +1054,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   __builtin_amdgcn_s_setprio(0);
   if (wave + 8 < n_tiles) sweep(std::integral_constant<int, 3>{});
   else sweep(std::integral_constant<int, 2>{});
+  BLE_SW(3);         // per-level tail done
   // padding above and below the 181 real levels, and the unreachable levels: certain, wrong way, infinitely fast
   for (int c = tid; c < kObsColumn; c += kObsBlock) {
     if (c < pad_above + lo_idx || c > pad_above + hi_idx) {
@@ -1051,10 +1063,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
   }
 #ifdef BLE_OBS_TIMING
+  BLE_SW(4);         // padding written
+  if (tid == 64) { for (int k = 0; k < 5; ++k) sh.sw1[k] = (float)(tsw[k] - tmark[5]); }
   __syncthreads();
   BLE_MARK();
   if (tid == 0)
   {
+    for (int k = 0; k < 5; ++k) { out[kObsDim - 34 + k] = (float)(tsw[k] - tmark[5]); out[kObsDim - 29 + k] = sh.sw1[k]; }
     for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
     out[kObsDim - 13] = sh.role_t[3];

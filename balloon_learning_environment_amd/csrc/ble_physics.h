@@ -791,8 +791,9 @@ BLE_FN void unix_day_fraction(int64_t unix_s, double* julian_century, double* fr
   int64_t days = unix_s / 86400;
   int64_t sod = unix_s - days * 86400;
   if (sod < 0) { sod += 86400; days -= 1; }
-  *frac = (double)sod / 86400.0;
-  *julian_century = (((2440587.5 + (double)days) + *frac) - 2451545.0) / 36525.0;
+  // (reciprocal multiplications: <= 1 ulp of fp64 from the reference's divisions, i.e. 4e-14 deg of hour angle)
+  *frac = (double)sod * (1.0 / 86400.0);
+  *julian_century = (((2440587.5 + (double)days) + *frac) - 2451545.0) * (1.0 / 36525.0);
 }
 BLE_FN SolarEphemeris solar_ephemeris_f64(double jc) {
   const double d2r = kPiD / 180.0;
@@ -804,13 +805,13 @@ BLE_FN SolarEphemeris solar_ephemeris_f64(double jc) {
   double sm, cm;
   sincos_f64(m0, &sm, &cm);
   const double s2m = 2.0 * sm * cm, s3m = sm * (3.0 - 4.0 * sm * sm);
-  const double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) / 60.0) / 60.0);
+  const double mean_obl = d2r * (23.0 + (26.0 + ((21.448 - jc * (46.815 + jc * (0.00059 - jc * 0.001813)))) * (1.0 / 60.0)) * (1.0 / 60.0));
   double so, co;
   sincos_f64(d2r * (125.04 - 1934.136 * jc), &so, &co);
   const double obl = mean_obl + d2r * (0.00256 * co);
   double sobl, cobl;
   sincos_f64(obl, &sobl, &cobl);
-  const double th = sobl / (1.0 + cobl), var_y = th * th;
+  const double th = sobl * d_rcp(1.0 + cobl), var_y = th * th;          // tan(obl / 2)
   const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
   const double eot = 4.0 * (var_y * s2l - 2.0 * ecc * sm + 4.0 * ecc * var_y * sm * c2l - 0.5 * var_y * var_y * s4l -
                             1.25 * ecc * ecc * s2m);
@@ -819,9 +820,9 @@ BLE_FN SolarEphemeris solar_ephemeris_f64(double jc) {
   sincos_f64(l0 + eoc - d2r * (0.00569 - 0.00478 * so), &sa, &ca);
   SolarEphemeris e;
   e.sin_decl = sobl * sa;
-  e.cos_decl = sqrt(1.0 - e.sin_decl * e.sin_decl);
+  e.cos_decl = d_sqrt_fast(d_fma(-e.sin_decl, e.sin_decl, 1.0));      // |decl| < 24 deg: argument > 0.83
   e.eot_quarter_deg = 0.25 * (eot * (180.0 / kPiD));
-  const double r = (1 + ecc) / (1 - ecc);
+  const double r = (1 + ecc) * d_rcp(1 - ecc);
   e.flux = 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
   return e;
 }
@@ -831,7 +832,7 @@ BLE_FN double solar_flux_f64(double jc) {
   double sm, cm;
   sincos_f64(m0, &sm, &cm);
   const double ecc = 0.016708634 - jc * (0.000042037 + 0.0000001267 * jc);
-  const double r = (1 + ecc) / (1 - ecc);
+  const double r = (1 + ecc) * d_rcp(1 - ecc);
   return 1366.0 * (1 + 0.5 * (r * r - 1) * cm);
 }
 // elevation [deg], refraction corrected, at a site (sin lat, cos lat, lng [deg]) and day fraction
