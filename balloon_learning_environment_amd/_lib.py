@@ -26,7 +26,7 @@ ABI_VERSION = 1
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH = 64, 128
-OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7380
+OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
 
 # every symbol include/ble_abi.h declares
 EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',

@@ -40,7 +40,7 @@ constexpr int kGpCapacity = 128;                    // ring entries per env (BLE
 constexpr int kGpMax = 120;                         // 6 h / 180 s
 constexpr int kGpRows = 128;
 constexpr int kCholTri = kGpMax * (kGpMax + 1) / 2;      // 7260 doubles: the packed factor
-constexpr int kCholStride = kCholTri + kGpMax;           // + the drop vector p (below): 7380 doubles = 59 040 B per environment
+constexpr int kCholStride = kCholTri + 3 * kGpMax;       // + the drop vector p and zeta_u / d, zeta_v / d (below): 7620 doubles = 60 960 B per environment
 constexpr int kCholPrefetch = (kCholTri / 2 + 255) / 256;      // double2 loads per lane (15)
 constexpr int kObsBlock = 256;
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
@@ -117,13 +117,24 @@ __device__ __forceinline__ double sqrt_coupled(double x) {
   return d_fma(g, d_fma(-g, h, 0.5), g);
 }
 
-// inclusive prefix sum over the 64 lanes of a wave
-__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double up = __shfl_up(v, off, 64);
-    v += lane >= off ? up : 0.0;
-  }
+// inclusive prefix sum over the 64 lanes of a wave on DPP moves (no LDS round trips, unlike __shfl_up): Hillis-Steele
+// inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of a row into the next row (row_bcast:15 on rows 1
+// and 3) and lane 31 into the upper half (row_bcast:31 on rows 2 and 3).  Lanes without a source add 0.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_take(double v) {
+  union { double d; int w[2]; } a, b;
+  a.d = v;
+  b.w[0] = __builtin_amdgcn_update_dpp(0, a.w[0], kCtrl, kRowMask, 0xF, false);
+  b.w[1] = __builtin_amdgcn_update_dpp(0, a.w[1], kCtrl, kRowMask, 0xF, false);
+  return b.d;
+}
+__device__ __forceinline__ double wave_inclusive_scan(double v, int /*lane*/) {
+  v += dpp_take<0x111, 0xF>(v);        // row_shr:1
+  v += dpp_take<0x112, 0xF>(v);        // row_shr:2
+  v += dpp_take<0x114, 0xF>(v);        // row_shr:4
+  v += dpp_take<0x118, 0xF>(v);        // row_shr:8
+  v += dpp_take<0x142, 0xA>(v);        // row_bcast:15 -> rows 1, 3
+  v += dpp_take<0x143, 0xC>(v);        // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -311,6 +322,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   const double p_pre = (chol_g != nullptr && tid < kGpMax) ? chol_g[kCholTri + tid] : 0.0;
   const double brow_pre = (chol_g != nullptr && tid >= 128 && tid < 192) ? chol_g[tri(64) + tid - 128] : 0.0;
+  const double zu_pre = (chol_g != nullptr && tid < kGpMax) ? chol_g[kCholTri + kGpMax + tid] : 0.0;          // carried zeta / d
+  const double zv_pre = (chol_g != nullptr && tid < kGpMax) ? chol_g[kCholTri + 2 * kGpMax + tid] : 0.0;
   const float err_u = noise_uv ? noise_uv[env * 2] : 0.0f, err_v = noise_uv ? noise_uv[env * 2 + 1] : 0.0f;
   float* h_xyp = hist.xyp + env * (kGpCapacity * 3);
   int32_t* h_t = hist.elapsed_s + env * kGpCapacity;
@@ -449,19 +462,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   int n_obs = sh.wave_count[0] + sh.wave_count[1];
   int drop = 0;
   if (n_obs > kGpMax) { drop = n_obs - kGpMax; n_obs = kGpMax; flags |= kFlagGpWindow; }
-  if (wave < 2 && valid) {
-    const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
-    if (at >= 0) {
-      sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][2] = (double)op * (1.0 / 326.0); sh.loc[at][3] = (double)ot;
-      sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
-      const double dx = ((double)ox - x) * (1.0 / 357000.0), dy = ((double)oy - y) * (1.0 / 357000.0),
-                   dt = ((double)ot - (double)elapsed) * (1.0 / 34560.0);
-      sh.a[at] = dx * dx + dy * dy + dt * dt + 1e-300;     // (the guard keeps rsq finite when an observation sits at the query)
-    }
-  }
-  const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
-  const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
-  const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   // Can the stored factor be slid to the new window?  The observations inside the 6 h window
   // must be a suffix of the ring (time only moves forward inside an episode), the stored factor
   // must cover a window that ends where this call started, and the new window must start inside it.
@@ -480,6 +480,22 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     incremental = hist.chol != nullptr && drop == 0 && last_invalid < first_valid && n_dropped >= 0 &&
                   n_dropped <= 1 && n_dropped <= n_chol0 && n_chol0 <= kGpMax;
   }
+  if (wave < 2 && valid) {
+    const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
+    if (at >= 0) {
+      sh.loc[at][2] = (double)op * (1.0 / 326.0);
+      if (!incremental) {        // positions, times and raw errors: only the refit builds K and solves for zeta
+        sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][3] = (double)ot;
+        sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
+      }
+      const double dx = ((double)ox - x) * (1.0 / 357000.0), dy = ((double)oy - y) * (1.0 / 357000.0),
+                   dt = ((double)ot - (double)elapsed) * (1.0 / 34560.0);
+      sh.a[at] = dx * dx + dy * dy + dt * dt + 1e-300;     // (the guard keeps rsq finite when an observation sits at the query)
+    }
+  }
+  const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
+  const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
+  const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   if (incremental) {
 #pragma unroll
     for (int i = 0; i < kCholPrefetch; ++i) {
@@ -488,6 +504,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
     if (tid < kGpMax) sh.pb[tid][0] = p_pre;
     if (tid >= 128 && tid < 192) sh.brow[tid - 128] = brow_pre;
+    if (tid < kGpMax) { sh.loc[tid][0] = zu_pre; sh.loc[tid][1] = zv_pre; }      // (x, y slots: unused with a carried factor)
   }
   // Rows of the factor the MFMA sweep works on.  Incremental: the window WITHOUT its newest observation
   // (that one becomes a bordering row, folded in after the sweep); refit: the whole window.
@@ -576,9 +593,20 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         const double idk0 = d_rcp(dk0);
         const double t0 = pk0 * pk0 * idk0;
         const double s0 = wave_inclusive_scan(t0, lane);
-        const double gamma_start = d_rcp(sh.L[0]);                         // 1 / d1 of the dropped row
+        const double d_first = sh.L[0];                                    // d1 of the dropped row
+        const double gamma_start = d_rcp(d_first);
         const double gnew0 = gamma_start + s0, gprev0 = gamma_start + (s0 - t0);
-        const double rg0 = d_rcp(gnew0);
+        const double rg0 = d_rcp(gnew0), rgp0 = d_rcp(gprev0);
+        // zeta = Lt^-1 y slides with the factor (it is carried as zeta / d next to it, so the sweep does not solve
+        // for it): Lt^-1 y = [y_0; L22^-1 (y[1:] - l21 y_0)]  =>  b = L22^-1 y[1:] = zeta[1:] + y_0 p, and with
+        // L22' = L22 T, T[j][k] = p_j beta_k (j > k):  zeta' = T^-1 b,  zeta'_i = b_i - p_i u_i / gamma_{i-1},
+        // u_i = sum_{k<i} p_k b_k / d_k  (the recurrence s_{i+1} = (1 - beta_i p_i) s_i + beta_i b_i telescopes
+        // because 1 - beta_i p_i = gamma_{i-1} / gamma_i): one prefix sum per component.
+        const double y0u = sh.loc[0][0] * d_first, y0v = sh.loc[0][1] * d_first;
+        const double bu0 = own0 ? d_fma(y0u, pk0, sh.loc[lane + 1][0] * dk0) : 0.0;
+        const double bv0 = own0 ? d_fma(y0v, pk0, sh.loc[lane + 1][1] * dk0) : 0.0;
+        const double cu0 = pk0 * idk0 * bu0, cv0 = pk0 * idk0 * bv0;
+        const double su0 = wave_inclusive_scan(cu0, lane), sv0 = wave_inclusive_scan(cv0, lane);
         const double2* pbv;
         const double* old_row;
         double* new_row;
@@ -589,8 +617,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           // rows 0 .. 63.  Old row 64 -- the source of new row 63 -- is overwritten by wave 3's row 64: lane 63
           // reads the copy made before the barrier (brow[0] = l21, brow[1 + k] = column k)
           own = own0; my_row = lane;
-          dnew_keep = dk0 * gnew0 * d_rcp(gprev0);
+          dnew_keep = dk0 * gnew0 * rgp0;
           inv_new = idk0 * gprev0 * rg0;                                     // 1 / d'_k
+          if (own0) {
+            sh.z[0][lane] = d_fma(-pk0 * rgp0, su0 - cu0, bu0) * inv_new;
+            sh.z[1][lane] = d_fma(-pk0 * rgp0, sv0 - cv0, bv0) * inv_new;
+          }
           const double* src = lane == 63 ? sh.brow : sh.L + tri(own0 ? lane + 1 : 1);
           w = own0 ? src[0] : 0.0;                                           // l21
           old_row = src + 1;                                                 // old row r + 1 shifted one column
@@ -607,9 +639,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           const double t1 = pk1 * pk1 * idk1;
           const double s1 = wave_inclusive_scan(t1, lane) + readlane_f64(s0, 63);
           const double gnew1 = gamma_start + s1, gprev1 = gamma_start + (s1 - t1);
-          const double rg1 = d_rcp(gnew1);
-          dnew_keep = dk1 * gnew1 * d_rcp(gprev1);
+          const double rg1 = d_rcp(gnew1), rgp1 = d_rcp(gprev1);
+          dnew_keep = dk1 * gnew1 * rgp1;
           inv_new = idk1 * gprev1 * rg1;
+          const double bu1 = own1 ? d_fma(y0u, pk1, sh.loc[lane + 65][0] * dk1) : 0.0;
+          const double bv1 = own1 ? d_fma(y0v, pk1, sh.loc[lane + 65][1] * dk1) : 0.0;
+          const double cu1 = pk1 * idk1 * bu1, cv1 = pk1 * idk1 * bv1;
+          const double su1 = wave_inclusive_scan(cu1, lane) + readlane_f64(su0, 63);
+          const double sv1 = wave_inclusive_scan(cv1, lane) + readlane_f64(sv0, 63);
+          if (own1) {
+            sh.z[0][lane + 64] = d_fma(-pk1 * rgp1, su1 - cu1, bu1) * inv_new;
+            sh.z[1][lane + 64] = d_fma(-pk1 * rgp1, sv1 - cv1, bv1) * inv_new;
+          }
           w = own1 ? sh.L[tri(lane + 65)] : 0.0;
           old_row = sh.L + tri(own1 ? lane + 65 : 1) + 1;
           new_row = sh.L + tri(lane + 64);
@@ -653,13 +694,16 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           if (own) sh.inv_diag[my_row] = inv_new;      // (the new diagonal itself is written after the barrier, below)
         }
       } else {
-        if (lane < nr) sh.inv_diag[lane] = d_rcp(sh.L[tri(lane) + lane]);
-        if (lane + 64 < nr) sh.inv_diag[lane + 64] = d_rcp(sh.L[tri(lane + 64) + lane + 64]);
+        // nothing left the window: the factor and zeta / d stand
+        for (int r = lane; r < nr; r += 64) {
+          sh.inv_diag[r] = d_rcp(sh.L[tri(r) + r]);
+          sh.z[0][r] = sh.loc[r][0]; sh.z[1][r] = sh.loc[r][1];
+        }
       }
       // rows nr .. of the MFMA tiles are virtual identity rows; they carry no weight in the sums below
       for (int i = nr + lane; i < kGpRows; i += 64) {
-        sh.inv_diag[i] = 0.0;
-        if (i >= n_obs) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
+        sh.inv_diag[i] = 0.0; sh.z[0][i] = 0.0; sh.z[1][i] = 0.0;
+        if (i >= n_obs) { sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
       }
     }
   } else if (wave >= 2) {
@@ -858,27 +902,31 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   while (hi_idx < 180 && 5000.0 + 50.0 * (double)(hi_idx + 1) <= p_hi) ++hi_idx;
   while (hi_idx >= 0 && 5000.0 + 50.0 * (double)hi_idx > p_hi) --hi_idx;
   const int n_reach = hi_idx >= lo_idx ? hi_idx - lo_idx + 1 : 0;
-  constexpr int kSpecial = 4;
+  // special columns: with a carried factor zeta slid with it in phase 1, so only k_new and e_0 ride the sweep
+  const int kSpecial = incremental ? 2 : 4;
+  const int c_new = incremental ? 0 : 2, c_e0 = incremental ? 1 : 3;
   const int n_tiles = (kSpecial + n_reach + 15) >> 4;                                // 1 .. 12
-  // Each wave sweeps its tiles {wave, wave + 4, wave + 8} TOGETHER (independent accumulators keep the
-  // matrix pipe busy); NT = 2 of them when <= 8 tiles are active (the usual case), else 3.
-  auto sweep = [&](auto nt_tag) {
+  // Each wave sweeps its tiles {wave, wave + 4} TOGETHER (independent accumulators keep the matrix pipe busy).  The
+  // rare ninth .. twelfth tile (1 % of the environments once zeta is off the sweep) is a second, barrier-free pass
+  // of the wave that owns it (kFirst = false: no special columns, nothing written to LDS).
+  auto sweep = [&](auto nt_tag, auto first_tag, int tile_base) {
     constexpr int NT = decltype(nt_tag)::value;
+    constexpr bool kFirst = decltype(first_tag)::value;
     d4 V[NT][8];
     int col[NT];
     double level[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      col[t] = 16 * (4 * t + wave) + jq;
+      col[t] = 16 * (tile_base + 4 * t + wave) + jq;
       level[t] = 5000.0 + 50.0 * (double)(lo_idx + col[t] - kSpecial);
     }
-    if (wave == 0 && jq == 2) level[0] = p;         // column 2: the newest observation's own pressure
+    if (kFirst && wave == 0 && jq == c_new) level[0] = p;     // column c_new: the newest observation's own pressure
     double level_s[NT];                             // in units of the pressure length scale
 #pragma unroll
     for (int t = 0; t < NT; ++t) level_s[t] = level[t] * (1.0 / 326.0);
-    const double y_last_u = sh.z[0][nr], y_last_v = sh.z[1][nr];   // raw errors of the newest observation (z is overwritten below)
-    const int spec_sel = jq == 1 ? 1 : (jq == 3 ? 3 : 0);
-    const bool use_spec = jq < kSpecial && jq != 2;
+    const double y_last_u = (double)err_u, y_last_v = (double)err_v;   // raw errors of the newest observation (when has_last)
+    const int spec_sel = jq == c_e0 ? 3 : (jq < 2 ? jq : 0);        // refit: columns 0, 1 = y_u, y_v from z[0], z[1]
+    const bool use_spec = jq < kSpecial && jq != c_new;
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
@@ -911,7 +959,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
             for (int t = 0; t < NT; ++t) R[t][v] = row < nr ? R[t][v] : 0.0;
           }
-          if (wave == 0) {                                    // scalar branch: tile 0 holds the special columns
+          if (kFirst && wave == 0) {                          // scalar branch: tile 0 holds the special columns
             // one unconditional LDS read + selects (a load under a per-lane condition becomes an exec-mask branch);
             // z[3] holds e_0 until the solved column overwrites it
             const double spec = sh.z[spec_sel][row];
@@ -936,19 +984,20 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       }
     }
     BLE_SW(0);       // core done (this wave)
-    __syncthreads();                 // wave 0 has read the raw error vectors
-    if (wave == 0 && jq < kSpecial) {       // the special columns of tile 0
-      // zeta_u, zeta_v, omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
+    // (no barrier here: only wave 0 reads z before this point, and it writes after its own reads)
+    if (kFirst && wave == 0 && jq < kSpecial) {       // the special columns of tile 0
+      // (refit: zeta_u, zeta_v;) omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
       // the new row of the factor), the e_0 solution raw
+      const int dst = jq == c_e0 ? 3 : (jq == c_new ? 2 : jq);
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
-          sh.z[jq][row] = jq < 3 ? V[0][I][v] * sh.inv_diag[row] : V[0][I][v];
+          sh.z[dst][row] = dst < 3 ? V[0][I][v] * sh.inv_diag[row] : V[0][I][v];
         }
     }
-    __syncthreads();
+    if constexpr (kFirst) __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
     // the same sum against omega = Lt^-1 k_new
     BLE_SW(1);       // special columns in LDS
@@ -984,25 +1033,32 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     BLE_SW(2);       // sums accumulated and reduced
     // ---- the bordering row (the newest observation, window entry nr): Lt_full = [Lt 0; r^T 1], r = omega / d,
     //   d_new = k_nn + noise - sum omega^2 / d,   (Lt_full^-1 b)_last = b_last - sum_i r_i (Lt^-1 b)_i
-    if (wave == 0 && g == 0 && jq < kSpecial) {
-      const double last = jq == 0 ? y_last_u - cross[0]                 // zeta_u of the newest observation
-                        : jq == 1 ? y_last_v - cross[0]
-                        : jq == 2 ? (kGpSigma2 + kGpNoise2) - ssq[0]     // d of the new row
-                                  : -cross[0];                          // (Lt_full^-1 e_0)_last
-      sh.last[jq] = last;
+    if (kFirst && wave == 0 && g == 0 && jq < kSpecial) {
+      if (jq == c_new) {              // this lane's column is omega: its sums against zeta / d are r^T zeta
+        sh.last[0] = y_last_u - mean_u[0];                              // zeta_u of the newest observation
+        sh.last[1] = y_last_v - mean_v[0];
+        sh.last[2] = (kGpSigma2 + kGpNoise2) - ssq[0];                  // d of the new row
+      } else if (jq == c_e0) {
+        sh.last[3] = -cross[0];                                         // (Lt_full^-1 e_0)_last
+      }
     }
     // new row of the factor and next call's drop vector, straight from the solved columns
-    if (has_last) {
-      for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i];
-    }
-    __syncthreads();
-    if (has_last && tid == 0) sh.L[tri(nr) + nr] = sh.last[2];
-    if (chol_g != nullptr) {          // p = -(Lt_full^-1 e_0)[1:]
-      for (int i = tid; i + 1 < n_obs; i += kObsBlock)
-        chol_g[kCholTri + i] = (i + 1 < nr) ? -sh.z[3][i + 1] : -sh.last[3];
+    if constexpr (kFirst) {
+      if (has_last) {
+        for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i];
+      }
+      __syncthreads();
+      if (has_last && tid == 0) sh.L[tri(nr) + nr] = sh.last[2];
     }
     const double inv_dn = has_last ? d_rcp(sh.last[2]) : 0.0;
     const double zl_u = has_last ? sh.last[0] * inv_dn : 0.0, zl_v = has_last ? sh.last[1] * inv_dn : 0.0;
+    if (kFirst && chol_g != nullptr) {          // p = -(Lt_full^-1 e_0)[1:], and zeta / d of the whole window
+      for (int i = tid; i < n_obs; i += kObsBlock) {
+        if (i + 1 < n_obs) chol_g[kCholTri + i] = (i + 1 < nr) ? -sh.z[3][i + 1] : -sh.last[3];
+        chol_g[kCholTri + kGpMax + i] = i < nr ? sh.z[0][i] : zl_u;
+        chol_g[kCholTri + 2 * kGpMax + i] = i < nr ? sh.z[1][i] : zl_v;
+      }
+    }
     {
       // after the xor reductions all four lanes of a column hold the totals: lane g finishes tile g (ONE instance of
       // the tail below for all tiles of the wave: the inputs are selected by g)
@@ -1048,12 +1104,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       }
     }
   };
-  // tile T = 4 t + wave: a wave needs its third tile (t = 2) only if tile 8 + wave exists.  About one
-  // environment in five has 125+ reachable levels (9 tiles): there wave 0 sweeps three tiles, the others two
-  // (both instantiations run the same three barriers).
+  // tile T = 4 t + wave for t = 0, 1; a tile 8 + wave exists only with 127+ reachable levels (1 % of the
+  // environments; 125+ while zeta still rode the sweep: 19 %): that wave sweeps it alone afterwards.
   __builtin_amdgcn_s_setprio(0);
-  if (wave + 8 < n_tiles) sweep(std::integral_constant<int, 3>{});
-  else sweep(std::integral_constant<int, 2>{});
+  sweep(std::integral_constant<int, 2>{}, std::true_type{}, 0);
+  if (wave + 8 < n_tiles) sweep(std::integral_constant<int, 1>{}, std::false_type{}, 8);
   BLE_SW(3);         // per-level tail done
   // padding above and below the 181 real levels, and the unreachable levels: certain, wrong way, infinitely fast
   for (int c = tid; c < kObsColumn; c += kObsBlock) {

@@ -126,7 +126,7 @@ class VecSimulator:
               out: Optional[torch.Tensor] = None, carry_factor: bool = True) -> torch.Tensor:
     """PerciatelliFeatureConstructor.observe + get_features for every env: [n, 1099] float32
     device tensor.  `noise_uv` [n, 2]: measured wind minus forecast at the balloons (None = 0).
-    carry_factor (fixed by the first call): keep each env's WindGP Cholesky factor in HBM (58 KB per
+    carry_factor (fixed by the first call): keep each env's WindGP Cholesky factor in HBM (61 KB per
     env) and slide it from step to step instead of refactoring the whole window every call."""
     assert self.grid is not None, 'Must call set_grid (reset) before observe.'
     if self._gp is None:

@@ -242,9 +242,9 @@ def observe_leg(roll, pairs, world):
   # algorithmic work per env-observation: 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles
   # (4 special columns + the ~121 reachable levels) + 32 for the diagonal-block inverses, x 2 048 flop, + ~0.9 MFLOP
   # of fp64 VALU (kernel matrix K*, elevation table, drop recurrences, cold starts); algorithmic bytes: 4 396 out
-  # + 2 x 59 040 factor-and-drop-vector in/out + 152 state + 3 072 ring
+  # + 2 x 60 960 factor, drop vector and zeta in/out + 152 state + 3 072 ring
   flop = (144 * 8 + 32) * 2048 + 0.9e6
-  obs_bytes = 4396 + 2 * 59040 + 152 + 3072
+  obs_bytes = 4396 + 2 * 60960 + 152 + 3072
   traffic = None
   try:
     traffic = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('observe_hbm_bytes_per_launch')

@@ -207,7 +207,7 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
  */
 #define BLE_OBS_DIM 1099
 #define BLE_GP_CAPACITY 128
-#define BLE_GP_CHOL_STRIDE 7380 /* 120 * 121 / 2 doubles (packed factor) + 120 (the drop vector of the next slide) */
+#define BLE_GP_CHOL_STRIDE 7620 /* 120 * 121 / 2 doubles (packed factor) + 120 (the drop vector of the next slide) + 2 * 120 (zeta_u / d, zeta_v / d) */
 typedef struct ble_gp_history_f32 {
   float* xyp;         /* [n][BLE_GP_CAPACITY][3]  x m, y m, pressure Pa */
   int32_t* elapsed_s; /* [n][BLE_GP_CAPACITY]     time_elapsed of the observation */
@@ -215,7 +215,8 @@ typedef struct ble_gp_history_f32 {
   int32_t* count;     /* [n] observations appended this episode; ring slot = count % BLE_GP_CAPACITY */
   double* chol;       /* optional [n][BLE_GP_CHOL_STRIDE]: the current window's K + noise = Lt D Lt^T (unit-lower Lt,
                          d on the diagonal, packed lower triangle, 7260 doubles) followed by the drop vector
-                         p = L22^-1 l21 of the next slide (120 doubles), carried from call to call so that the
+                         p = L22^-1 l21 of the next slide (120 doubles) and zeta / d for the two error components
+                         (zeta = Lt^-1 y, 2 x 120 doubles), carried from call to call so that the
                          per-step refit of the reference (wind_gp.py:186-188) becomes an O(n^2) slide;
                          opaque to the caller; NULL = refit in LDS every call */
   int32_t* n_chol;    /* [n] rows of `chol` in use (required when chol != NULL), zero-initialised */

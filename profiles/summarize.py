@@ -106,7 +106,7 @@ def main(tag):
       # applies to FETCH_SIZE; WRITE_SIZE is uncalibrated (guide) and reported as is
       of, ow = steady['FETCH_SIZE'] * 1024.0, steady['WRITE_SIZE'] * 1024.0
       out['observe_hbm'] = {'fetch_bytes_raw': of, 'write_bytes_raw': ow, 'hbm_bytes_per_launch_fetch_x2': 2 * of + ow,
-                            'algorithmic_bytes_per_launch': 65536 * (4396 + 2 * 59040 + 152 + 3072)}
+                            'algorithmic_bytes_per_launch': 65536 * (4396 + 2 * 60960 + 152 + 3072)}
       try:
         traffic
       except NameError:

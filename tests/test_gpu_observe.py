@@ -321,7 +321,7 @@ def test_carried_factor_equals_fresh_factorisation(vec_state):
     sim.observe(torch.from_numpy((rng.standard_normal((n, 2))).astype(np.float32)).cuda())
   gp = {k: v.cpu().numpy() for k, v in sim._gp.items()}
   ls = np.array([357000.0, 357000.0, 326.0, 34560.0])
-  worst = 0
+  worst = worst_z = 0
   for j in range(n):
     cnt, m = int(gp['count'][j]), int(gp['n_chol'][j])
     idx = [(cnt - m + l) % 128 for l in range(m)]
@@ -335,8 +335,13 @@ def test_carried_factor_equals_fresh_factorisation(vec_state):
       got[r, :r + 1] = packed[k:k + r + 1]; k += r + 1
     want = np.tril(Lt, -1) + np.diag(dd)
     worst = max(worst, np.abs(got - want).max() / np.abs(want).max())
-  print('carried factor vs fresh LDL^T after %d slides: worst relative difference %.3g' % (steps - 120, worst))
-  assert m == 120 and worst < 1e-11
+    # zeta / d (zeta = Lt^-1 y for the two error components) is carried next to the factor and slid with it
+    y = gp['err_uv'][j][idx].astype(np.float64)
+    zeta_d = np.linalg.solve(np.tril(Lt, -1) + np.eye(m), y) / dd[:, None]
+    got_z = np.stack([packed[7260 + 120:7260 + 120 + m], packed[7260 + 240:7260 + 240 + m]], 1)
+    worst_z = max(worst_z, np.abs(got_z - zeta_d).max() / np.abs(zeta_d).max())
+  print('carried factor vs fresh LDL^T after %d slides: worst relative difference %.3g; carried zeta / d: %.3g' % (steps - 120, worst, worst_z))
+  assert m == 120 and worst < 1e-11 and worst_z < 1e-10
 
 
 def _oracle_features_worker(args):
