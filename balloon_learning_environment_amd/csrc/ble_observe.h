@@ -989,13 +989,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       // (refit: zeta_u, zeta_v;) omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
       // the new row of the factor), the e_0 solution raw
       const int dst = jq == c_e0 ? 3 : (jq == c_new ? 2 : jq);
+      double* zdst = &sh.z[dst][g];
+      // (the 32 scale factors are loaded unconditionally and together: a load under `dst < 3` is an exec-mask
+      // branch with its own LDS round trip -- 32 serial ones took 4.7 k cycles of the critical wave)
+      double scale[8][4];
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + 4 * v + g;
-          sh.z[dst][row] = dst < 3 ? V[0][I][v] * sh.inv_diag[row] : V[0][I][v];
-        }
+        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[16 * I + 4 * v + g];
+#pragma unroll
+      for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) zdst[16 * I + 4 * v] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
     }
     if constexpr (kFirst) __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
@@ -1007,18 +1012,23 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
       if (I < nb) {
+        // (the 16 LDS operands of a row block are requested together, then consumed: one round trip per block)
+        double inv_d[4], zu[4], zv[4], zw[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
-          const double inv_d = sh.inv_diag[row];
-          const double zu = sh.z[0][row], zv = sh.z[1][row], zw = sh.z[2][row];      // (already / d)
+          inv_d[v] = sh.inv_diag[row];
+          zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (already / d)
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const double val = V[t][I][v];                // (Lt^-1 k*)_row
-            ssq[t] = d_fma(val * val, inv_d, ssq[t]);
-            mean_u[t] = d_fma(val, zu, mean_u[t]);
-            mean_v[t] = d_fma(val, zv, mean_v[t]);
-            cross[t] = d_fma(val, zw, cross[t]);
+            ssq[t] = d_fma(val * val, inv_d[v], ssq[t]);
+            mean_u[t] = d_fma(val, zu[v], mean_u[t]);
+            mean_v[t] = d_fma(val, zv[v], mean_v[t]);
+            cross[t] = d_fma(val, zw[v], cross[t]);
           }
         }
       }
