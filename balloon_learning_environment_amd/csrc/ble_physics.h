@@ -744,39 +744,26 @@ BLE_FN SunSC sun_refract(SunSC unc) {
 
 // ---------------------------------------------------------------- fp64 asin (fdlibm e_asin.c rational form)
 BLE_FN double d_asin(double x) {
-  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
-               pio4_hi = 7.85398163397448278999e-01;
+  // Branch-free: lanes of one wave sit on both sides of |x| = 0.5 (721 table entries per observation), and a
+  // divergent fdlibm pays for every path.  One evaluation of the rational R serves both halves:
+  //   |x| <  0.5:  asin(x) = x + x R(x^2)
+  //   |x| >= 0.5:  asin(|x|) = pi/2 - 2 (s + s R(t)),  t = (1 - |x|) / 2,  s = sqrt(t)
+  // (without fdlibm's head/tail split of s: 2e-16 absolute instead of the last ulp)
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
   const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
                pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
                qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
                qS4 = 7.70381505559019352791e-02;
-  const double ax = fabs(x);
-  if (ax < 0.5) {
-    const double t = x * x;
-    const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
-    const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-    return x + x * (p * d_rcp(q));                     // q in [0.3, 1]: reciprocal + Newton, 2e-15
-  }
-  const double w = 1.0 - ax;
-  const double t = w * 0.5;
-  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
-  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-  const double s = t > 0.0 ? d_sqrt_fast(t) : 0.0;
-  const double r = p * d_rcp(q);
-  double res;
-  if (ax >= 0.975) {
-    res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
-  } else {
-    // split s into a head with 32 zero low bits (fdlibm) to keep the subtraction exact
-    union { double d; uint64_t u; } cv;
-    cv.d = s; cv.u &= 0xffffffff00000000ULL;
-    const double df = cv.d;
-    const double c = (t - df * df) * d_rcp(s + df);
-    const double pp = 2.0 * s * r - (pio2_lo - 2.0 * c);
-    const double qq = pio4_hi - 2.0 * df;
-    res = pio4_hi - (pp - qq);
-  }
-  return x > 0 ? res : -res;
+  const double ax = __builtin_fabs(x);
+  const bool big = ax >= 0.5;
+  const double t = big ? (1.0 - ax) * 0.5 : x * x;
+  const double rt = d_sqrt_fast(t);                        // (NaN for t == 0: discarded by the select)
+  const double s = big ? (t > 0.0 ? rt : 0.0) : ax;
+  const double p = t * d_fma(t, d_fma(t, d_fma(t, d_fma(t, d_fma(t, pS5, pS4), pS3), pS2), pS1), pS0);
+  const double q = d_fma(t, d_fma(t, d_fma(t, d_fma(t, qS4, qS3), qS2), qS1), 1.0);
+  const double y = d_fma(s, p * d_rcp(q), s);             // q in [0.3, 1]: reciprocal + Newton, 2e-15
+  const double res = big ? pio2_hi - (2.0 * y - pio2_lo) : y;
+  return x < 0.0 ? -res : res;
 }
 
 // ---------------------------------------------------------------- full fp64 solar calculator
