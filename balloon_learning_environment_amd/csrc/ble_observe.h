@@ -934,6 +934,20 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         // the first product of each chain takes a literal-zero accumulator (no register zeroing)
         d4 acc[NT];
         const double* arow = (16 * I + jq < nr ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
+        // right-hand sides of the special columns (tile 0): requested here, consumed after the products below --
+        // read next to their use, each of the 32 loads was a full LDS round trip of the slowest wave
+        double spec[4] = {0.0, 0.0, 0.0, 0.0};
+        if (kFirst && wave == 0) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][16 * I + 4 * v + g];
+        }
+        // (likewise the per-row inputs of the kernel matrix and the packed inverse of the diagonal block)
+        double a_rows[4], p_rows[4], dpk[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          a_rows[v] = sh.a[16 * I + 4 * v + g]; p_rows[v] = sh.loc[16 * I + 4 * v + g][2];
+          dpk[v] = (sh.dinv[I] + tri(jq) + g)[4 * v];               // always inside dinv[I][136]; masked above the diagonal
+        }
 #pragma unroll
         for (int J = 0; J < I; ++J)
 #pragma unroll
@@ -947,7 +961,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
-          const double a_row = sh.a[row], p_row = sh.loc[row][2];
+          const double a_row = a_rows[v], p_row = p_rows[v];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused);
@@ -960,21 +974,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             for (int t = 0; t < NT; ++t) R[t][v] = row < nr ? R[t][v] : 0.0;
           }
           if (kFirst && wave == 0) {                          // scalar branch: tile 0 holds the special columns
-            // one unconditional LDS read + selects (a load under a per-lane condition becomes an exec-mask branch);
+            // unconditional LDS reads + selects (a load under a per-lane condition becomes an exec-mask branch);
             // z[3] holds e_0 until the solved column overwrites it
-            const double spec = sh.z[spec_sel][row];
-            R[0][v] = use_spec ? (row < nr ? spec : 0.0) : R[0][v];
+            R[0][v] = use_spec ? (row < nr ? spec[v] : 0.0) : R[0][v];
           }
           if (I > 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
           }
         }
-        const double* drow = sh.dinv[I] + tri(jq) + g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double packed = drow[4 * c];                        // always inside dinv[I][136]; masked above the diagonal
-          const double a = 4 * c + g <= jq ? packed : 0.0;            // packed lower triangle
+          const double a = 4 * c + g <= jq ? dpk[c] : 0.0;            // packed lower triangle
 #pragma unroll
           for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], c == 0 ? zero4 : V[t][I], 0, 0, 0);
         }
@@ -984,6 +995,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       }
     }
     BLE_SW(0);       // core done (this wave)
+    __builtin_amdgcn_s_setprio(1);      // what follows are short dependent chains again (-1.5 %)
     // (no barrier here: only wave 0 reads z before this point, and it writes after its own reads)
     if (kFirst && wave == 0 && jq < kSpecial) {       // the special columns of tile 0
       // (refit: zeta_u, zeta_v;) omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
