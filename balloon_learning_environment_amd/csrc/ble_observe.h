@@ -86,7 +86,7 @@ struct ObsShared {
   double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
-  double lev[20], pot[20], sp[22];
+  double lev[20], pot[20];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
   int wave_count[2];
@@ -188,40 +188,54 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The pressure-range searches run on ONE wave whose lane k < 20 holds search level k (pressure, p / T and, after the
+// cold starts, superpressure): the reference's loops over the 20 levels become ballots and lane reads instead of
+// 60 dependent LDS round trips on one lane.  `idx` arguments of lane_read must be wave-uniform.
+__device__ __forceinline__ double lane_read(double v, int idx) { return readlane_f64(v, __builtin_amdgcn_readfirstlane(idx)); }
+
 // interp1d(p/T -> p, linear, extrapolating) at the float ceiling (pressure_range_builder.py:236-247)
-__device__ inline double pressure_ceiling(const double* lev, const double* pot) {
+__device__ inline double pressure_ceiling_wave(double lev_l, double pot_l, int lane) {
   const double target = (92.5 + 68.5 + 6830.0 * kHeMolarMassD) * kGasConstantD / (kAirMolarMassD * 1804.0);
-  int i = 0;
-  while (i < 20 && pot[i] < target) ++i;      // searchsorted(side='left')
+  const unsigned long long stop = __ballot(lane < 20 && !(pot_l < target));      // searchsorted(side='left'): first level not below
+  int i = stop ? __ffsll((long long)stop) - 1 : 20;
   i = i < 1 ? 1 : (i > 19 ? 19 : i);
-  const double slope = (lev[i] - lev[i - 1]) / (pot[i] - pot[i - 1]);
-  return slope * (target - pot[i - 1]) + lev[i - 1];
+  const double l1 = lane_read(lev_l, i), l0 = lane_read(lev_l, i - 1), q1 = lane_read(pot_l, i), q0 = lane_read(pot_l, i - 1);
+  const double slope = (l1 - l0) / (q1 - q0);
+  return slope * (target - q0) + l0;
 }
 
-// _search_for_safe_pressure (:111-182) over superpressures that are already solved.
-__device__ inline double safe_pressure_search(const double* lev, const double* sp, double significant, double sp_sig,
-                                              bool upward, int* ok) {
+// _search_for_safe_pressure (:111-182) over superpressures that are already solved (sp_l: lane k < 20 = level k).
+__device__ inline double safe_pressure_search_wave(double lev_l, double sp_l, int lane, double significant, double sp_sig,
+                                                   bool upward, int* ok) {
   const double lo = 250.0, hi = 2380.0 - 250.0;
   if (sp_sig >= lo && sp_sig <= hi) return significant;
-  double last_p = significant, last_sp = sp_sig;
-  for (int n = 0; n < 20; ++n) {
-    const int k = upward ? n : 19 - n;
-    const double p = lev[k];
-    if (upward ? (p < significant) : (p > significant)) continue;
-    const double s = sp[k];
-    if (s > hi || s < lo) { last_p = p; last_sp = s; continue; }
-    // _compute_safe_pressure (:73-108): p1 < p2
-    const double p1 = upward ? last_p : p, s1 = upward ? last_sp : s;
-    const double p2 = upward ? p : last_p, s2 = upward ? s : last_sp;
-    double target;
-    if ((s1 < lo) != (s2 < lo)) target = lo;
-    else if ((s1 > hi) != (s2 > hi)) target = hi;
-    else { *ok = 0; return significant; }
-    if (!(p1 < p2) || s1 == s2) { *ok = 0; return significant; }
-    return fabs((target - s1) / (s2 - s1)) * (p2 - p1) + p1;
+  // levels on the far side of `significant`, in scan order (upward: 0 -> 19, else 19 -> 0); the first one whose
+  // superpressure is inside [lo, hi] ends the scan, `last` is the level scanned just before it
+  const bool valid = lane < 20 && !(upward ? (lev_l < significant) : (lev_l > significant));
+  const unsigned long long bv = __ballot(valid), bi = __ballot(valid && !(sp_l > hi || sp_l < lo));
+  if (bi == 0) { *ok = 0; return significant; }
+  int first, last;
+  if (upward) {
+    first = __ffsll((long long)bi) - 1;
+    const unsigned long long before = bv & ((1ull << first) - 1ull);
+    last = before ? 63 - __clzll((long long)before) : -1;
+  } else {
+    first = 63 - __clzll((long long)bi);
+    const unsigned long long before = bv & ~((2ull << first) - 1ull);
+    last = before ? __ffsll((long long)before) - 1 : -1;
   }
-  *ok = 0;
-  return significant;
+  const double p = lane_read(lev_l, first), sfirst = lane_read(sp_l, first);
+  const double last_p = last >= 0 ? lane_read(lev_l, last >= 0 ? last : 0) : significant;
+  const double last_sp = last >= 0 ? lane_read(sp_l, last >= 0 ? last : 0) : sp_sig;
+  // _compute_safe_pressure (:73-108): p1 < p2
+  const double p1 = upward ? last_p : p, s1 = upward ? last_sp : sfirst;
+  const double p2 = upward ? p : last_p, s2 = upward ? sfirst : last_sp;
+  double target;
+  if ((s1 < lo) != (s2 < lo)) target = lo;
+  else if ((s1 > hi) != (s2 > hi)) target = hi;
+  else { *ok = 0; return significant; }
+  if (!(p1 < p2) || s1 == s2) { *ok = 0; return significant; }
+  return fabs((target - s1) / (s2 - s1)) * (p2 - p1) + p1;
 }
 
 __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32 st, const float* __restrict__ wind_grid,
@@ -552,23 +566,22 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       out[13] = (soc > 0.99 && solar_power_f64(el_now, p) > 120.4) ? 1.0f : 0.0f;     // balloon.py:231-238
     }
   } else if (wave == 1) {
+    // lane k < 20: search level k; lane 20: the float ceiling; lane 21: the floor
+    const double lev_l = lane < 20 ? sh.lev[lane] : 0.0, pot_l = lane < 20 ? sh.pot[lane] : 0.0;
+    const double ceiling = pressure_ceiling_wave(lev_l, pot_l, lane);
+    double sp_l = 0.0;
     if (lane < 22) {
-      const double ceiling = pressure_ceiling(sh.lev, sh.pot);
-      const double level = lane < 20 ? sh.lev[lane] : (lane == 20 ? ceiling : p_floor);
+      const double level = lane < 20 ? lev_l : (lane == 20 ? ceiling : p_floor);
       uint32_t local = 0;
       const StableParams s = stable_params(alpha, level, el_now, flux_now, (double)st.upwelling_infrared[env], &local);
-      sh.sp[lane] = s.sp;
+      sp_l = s.sp;
       flags |= local;
     }
     // ---- reachable pressure range (pressure_range_builder.py:249-275), as soon as the 22 superpressures exist
-    wave_sync_lds();
-    if (lane == 0) {
-      int ok = 1;
-      const double ceiling = pressure_ceiling(sh.lev, sh.pot);
-      sh.p_lo = safe_pressure_search(sh.lev, sh.sp, ceiling, sh.sp[20], true, &ok);
-      sh.p_hi = safe_pressure_search(sh.lev, sh.sp, p_floor, sh.sp[21], false, &ok);
-      sh.range_ok = ok;
-    }
+    int ok = 1;
+    const double p_lo_w = safe_pressure_search_wave(lev_l, sp_l, lane, ceiling, lane_read(sp_l, 20), true, &ok);
+    const double p_hi_w = safe_pressure_search_wave(lev_l, sp_l, lane, p_floor, lane_read(sp_l, 21), false, &ok);
+    if (lane == 0) { sh.p_lo = p_lo_w; sh.p_hi = p_hi_w; sh.range_ok = ok; }
   } else if (wave >= 2 && incremental) {
     if (wave == 2 || n_dropped == 1) {
       // ---- drop the oldest observation: lane owns rows `lane` and `lane + 64` of the new factor
