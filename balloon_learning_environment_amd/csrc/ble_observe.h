@@ -286,26 +286,31 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int32_t elapsed = st.time_elapsed_s[env];
   const int64_t now = st.start_unix[env] + (int64_t)elapsed;
   const double alpha = (double)st.alpha[env];
+  // (every per-environment input of every role is requested here, in one memory round trip: read where they are used,
+  // the roles of wave 1 paid three dependent ones)
+  const float lat0_f = st.center_lat_deg[env], lng0_f = st.center_lng_deg[env];
+  const float batt_f = st.battery_charge[env], sp_f = st.superpressure[env], ir_f = st.upwelling_infrared[env];
+  const int cmd = st.last_command[env];
+  const int paused_bits = (int)st.power_paused[env] | (int)st.env_fsm[env] | (int)st.alt_fsm[env];
   const double x = (double)xf, y = (double)yf, p = (double)pf;
   float* out = obs + env * kObsDim;
 
   SunSite site;
   if (wave == 1) {           // BalloonState.latlng once per environment (one wave; the others get it through LDS)
-    latlng_f64((double)st.center_lat_deg[env], (double)st.center_lng_deg[env], x, y, &site.sin_lat, &site.cos_lat,
+    latlng_f64((double)lat0_f, (double)lng0_f, x, y, &site.sin_lat, &site.cos_lat,
                &site.lng_deg);
     if (lane == 0) {
       sh.site[0] = site.sin_lat; sh.site[1] = site.cos_lat; sh.site[2] = site.lng_deg;
       // -- the ambient features that need only the state (features.py:400-470); this wave would otherwise wait
       //    for wave 0's ephemeris nodes.  Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
       //    rounding to float32.
-      const double soc = (double)st.battery_charge[env] * (1.0 / 3058.56);
+      const double soc = (double)batt_f * (1.0 / 3058.56);
       const double d2 = x * x + y * y;
       const double inv_d = d2 > 0.0 ? d_rsqrt(d2) : 0.0;
       const double dist_km = d2 * inv_d * 1e-3;
-      const double sp_now = (double)st.superpressure[env];
+      const double sp_now = (double)sp_f;
       const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) * d_rcp(p);
-      const int cmd = st.last_command[env];
-      const bool paused = st.power_paused[env] != 0 || st.env_fsm[env] != 0 || st.alt_fsm[env] != 0;
+      const bool paused = paused_bits != 0;
       auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
       out[0] = (float)unit((p - 5000.0) * (1.0 / 9000.0));
       out[1] = (float)soc;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       const double elc = (el_now + 90.0) * (1.0 / 180.0);
       out[2] = (float)(elc < 0.0 ? 0.0 : (elc > 1.0 ? 1.0 : elc));
       out[3] = (float)sc; out[4] = (float)cc;
-      const double soc = (double)st.battery_charge[env] * (1.0 / 3058.56);
+      const double soc = (double)batt_f * (1.0 / 3058.56);
       out[13] = (soc > 0.99 && solar_power_f64(el_now, p) > 120.4) ? 1.0f : 0.0f;     // balloon.py:231-238
     }
   } else if (wave == 1) {
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     if (lane < 22) {
       const double level = lane < 20 ? lev_l : (lane == 20 ? ceiling : p_floor);
       uint32_t local = 0;
-      const StableParams s = stable_params(alpha, level, el_now, flux_now, (double)st.upwelling_infrared[env], &local);
+      const StableParams s = stable_params(alpha, level, el_now, flux_now, (double)ir_f, &local);
       sp_l = s.sp;
       flags |= local;
     }
