@@ -90,8 +90,6 @@ struct ObsShared {
   double lev[20], pot[20];
   double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
   float column[20];
-  int wave_count[2];
-  unsigned long long ballot[2];
   int n_obs;
   int range_ok;
   float role_t[4], sw1[5];
@@ -370,6 +368,14 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       ot = h_t[slot]; oeu = h_err[slot * 2]; oev = h_err[slot * 2 + 1];
     }
   }
+  // Every wave also reads the TIMES of ring entries lane and lane + 64: each forms both validity ballots itself, so the
+  // window's size and shape need no exchange through LDS (one barrier less before the roles of phase 1).
+  int32_t ta = elapsed, tb = elapsed;
+  {
+    const int ea = lane, eb = lane + 64;
+    if (ea < m && !(append && ea == m - 1)) ta = h_t[(count - m + ea) % kGpCapacity];
+    if (eb < m && !(append && eb == m - 1)) tb = h_t[(count - m + eb) % kGpCapacity];
+  }
   // (the ring entries are consumed after the elevation table below: their HBM round trips -- count, then the
   // slots -- hide behind that computation instead of stalling all four waves here)
 
@@ -464,22 +470,21 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   BLE_SUB(2);        // elevation table filled
   BLE_SUB(3);        // search levels / pressure column done
-  if (tid < kGpCapacity && tid < m) {
-    const int32_t age = ot > elapsed ? ot - elapsed : elapsed - ot;
-    valid = age < kGpHorizonS;             // strict, wind_gp.py:183
+  unsigned long long b0, b1;
+  {
+    const int32_t age_a = ta > elapsed ? ta - elapsed : elapsed - ta, age_b = tb > elapsed ? tb - elapsed : elapsed - tb;
+    b0 = __ballot(lane < m && age_a < kGpHorizonS);              // strict, wind_gp.py:183
+    b1 = __ballot(lane + 64 < m && age_b < kGpHorizonS);
   }
-  int pos = 0;
-  if (wave < 2) {
-    const unsigned long long ballot = __ballot(valid);
-    pos = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) { sh.wave_count[wave] = __popcll(ballot); sh.ballot[wave] = ballot; }
-  }
-  __syncthreads();   // B1
+  const unsigned long long b_mine = wave == 0 ? b0 : b1;
+  valid = wave < 2 && ((b_mine >> lane) & 1ull) != 0;
+  const int pos = __popcll(b_mine & ((1ull << lane) - 1ull));
+  const int count_w0 = __popcll(b0);
   BLE_MARK();
   BLE_STOP(1);
 
   // ---- phase 0c: compact the window into LDS (chronological)
-  int n_obs = sh.wave_count[0] + sh.wave_count[1];
+  int n_obs = count_w0 + __popcll(b1);
   int drop = 0;
   if (n_obs > kGpMax) { drop = n_obs - kGpMax; n_obs = kGpMax; flags |= kFlagGpWindow; }
   // Can the stored factor be slid to the new window?  The observations inside the 6 h window
@@ -488,7 +493,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   bool incremental = false;
   int n_dropped = 0;
   {
-    const unsigned long long b0 = sh.ballot[0], b1 = sh.ballot[1];
     const int m0 = m < 64 ? m : 64, m1 = m - m0;
     const unsigned long long inv0 = ~b0 & (m0 >= 64 ? ~0ull : ((1ull << m0) - 1ull));
     const unsigned long long inv1 = ~b1 & (m1 >= 64 ? ~0ull : ((1ull << m1) - 1ull));
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
                   n_dropped <= 1 && n_dropped <= n_chol0 && n_chol0 <= kGpMax;
   }
   if (wave < 2 && valid) {
-    const int at = pos + (wave == 1 ? sh.wave_count[0] : 0) - drop;
+    const int at = pos + (wave == 1 ? count_w0 : 0) - drop;
     if (at >= 0) {
       sh.loc[at][2] = (double)op * (1.0 / 326.0);
       if (!incremental) {        // positions, times and raw errors: only the refit builds K and solves for zeta
@@ -513,7 +517,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.a[at] = dx * dx + dy * dy + dt * dt + 1e-300;     // (the guard keeps rsq finite when an observation sits at the query)
     }
   }
-  const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
   const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
   if (incremental) {
@@ -531,7 +534,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const bool appended = count != count0;
   const bool has_last = incremental && appended;
   const int nr = has_last ? n_obs - 1 : n_obs;
-  __syncthreads();   // B2
+  __syncthreads();   // B2: the elevation table, the compacted window and the landed factor are in LDS
+  const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
 
   // ---- phase 1: four roles
   double dnew_keep = 0.0;            // new diagonal entry of the row a drop lane owns (written after B3)
