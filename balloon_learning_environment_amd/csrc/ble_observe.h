@@ -2,29 +2,32 @@
 // environments on the device -- one workgroup (4 waves) per environment.
 //
 //   history    ring of the last 128 (x, y, p, t; err_u, err_v) observations per env in HBM
-//   phase 0    append the new observation, compact the <= 120 observations of the 6 h window
-//              (wind_gp.py:179-185) into LDS; 721-entry solar-elevation table (fp64) filled by
-//              all lanes; T(p) at the 20 search levels; the (x, y, t)-blended pressure column
-//   phase 1    lane 0: sunrise/sunset searches on the table -> 16 ambient features
-//              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) for the
+//   phase 0    every per-env input requested at entry; append the new observation; roles: wave 0 the time-only
+//              half of the solar calculator at 6 nodes, wave 1 latlng + the state-only ambient features, wave 2
+//              the (x, y, t)-blended pressure column, wave 3 T(p) at the 20 search levels; then the 721-entry
+//              solar-elevation table (fp64) filled by all lanes; the <= 120 observations of the 6 h window
+//              (wind_gp.py:179-185) compacted into LDS (every wave forms the validity ballots itself)
+//   phase 1    wave 0: sunrise/sunset searches on the table -> the remaining ambient features
+//              wave 1: 22 cold-start Newton solves (20 levels + ceiling + floor) and the searches for the
 //                      reachable pressure range (pressure_range_builder.py:203-275)
-//              wave 2 (or waves 2-3 when refitting): the Cholesky factor of K = s^2 exp(-|d/ls|) + 0.05 I
-//                      (sklearn GaussianProcessRegressor.fit refits it every step):
-//              * incremental (hist.chol given): the factor of the previous window lives in HBM
-//                (58 KB per env, prefetched with 16-byte loads at kernel entry); the window slides
-//                by dropping the oldest observation -- a stable rank-1 UPDATE of the trailing
-//                factor -- and appending the newest -- one forward substitution -- O(n^2) instead
-//                of O(n^3), one fused wave-synchronous sweep
+//              waves 2-3: the factor of K = s^2 exp(-|d/ls|) + 0.05 I (sklearn GaussianProcessRegressor.fit
+//                      refits it every step):
+//              * incremental (hist.chol given): the factor of the previous window lives in HBM as Lt D Lt^T
+//                (61 KB per env with the drop vector and zeta / d, prefetched with 16-byte loads at kernel
+//                entry); the window slides by dropping the oldest observation -- a rank-1 UPDATE of the trailing
+//                factor whose only cross-row dependency, p = L22^-1 l21, was solved by the previous call's
+//                sweep -- and zeta = Lt^-1 y slides with it (one prefix sum); the newest observation becomes
+//                a bordering row after the sweep: O(n^2) instead of O(n^3)
 //              * refit (no hist.chol, first call, or an inconsistent history): K built in LDS, then
-//                (phase 2) a left-looking blocked Cholesky in panels of 8 columns
-//   phase 4    V = L^-1 [K*^T | y] for the 181 query levels and the two error vectors: blocked forward
-//              substitution on v_mfma_f64_16x16x4_f64, 48 columns per wave, V resident in registers,
-//              inverted 16 x 16 diagonal blocks; mean = v . z + forecast (= K* K^-1 y),
-//              deviation = (s^2 - |v|^2) / s^2
+//                (phase 2) a left-looking blocked Cholesky in panels of 8 columns; zeta from the sweep
+//   phase 4    V = Lt^-1 [k_new | e_0 | K*^T] for the bordering row, the next drop vector and the reachable
+//              query levels: blocked forward substitution on v_mfma_f64_16x16x4_f64, two 16-column tiles per
+//              wave, V resident in registers, inverted 16 x 16 diagonal blocks; mean = v . zeta / d + forecast
+//              (= K* K^-1 y), deviation = (s^2 - v^2 / d) / s^2
 //   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
 //
 // All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (factor) + 8.7 KB (block
-// inverses, aliased with the solar table) + 10 KB = 76.5 KB and <= 256 registers: two workgroups per CU,
+// inverses, aliased with the solar table) + 12 KB = 79 KB and <= 256 registers: two workgroups per CU,
 // which is what hides the latency-bound single-wave phases.  DESIGN.md 3b has the cycle budget.
 #pragma once
 #include <type_traits>
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   int n_chol0 = hist.chol != nullptr ? hist.n_chol[env] : 0;
   if (reset_mask != nullptr && reset_mask[env] != 0) { count = 0; n_chol0 = 0; }
   const int count0 = count;
-  // The stored factor (58 KB) is requested now, 16 B per lane and 15 loads in flight, and lands in
+  // The stored factor (58 KB of the 61 KB slab) is requested now, 16 B per lane and 15 loads in flight, and lands in
   // LDS after the solar table has been computed: its HBM latency hides behind phase 0b.
   double* chol_g = hist.chol != nullptr ? hist.chol + env * kCholStride : nullptr;
   const int chol_pairs = (tri(n_chol0 <= kGpMax ? n_chol0 : 0) + 1) >> 1;
