@@ -95,7 +95,7 @@ struct ObsShared {
   float column[20];
   int n_obs;
   int range_ok;
-  float role_t[4], sw1[5];
+  float role_t[4], sw1[5], role_t0[4];
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
@@ -302,26 +302,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
                &site.lng_deg);
     if (lane == 0) {
       sh.site[0] = site.sin_lat; sh.site[1] = site.cos_lat; sh.site[2] = site.lng_deg;
-      // -- the ambient features that need only the state (features.py:400-470); this wave would otherwise wait
-      //    for wave 0's ephemeris nodes.  Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
-      //    rounding to float32.
-      const double soc = (double)batt_f * (1.0 / 3058.56);
-      const double d2 = x * x + y * y;
-      const double inv_d = d2 > 0.0 ? d_rsqrt(d2) : 0.0;
-      const double dist_km = d2 * inv_d * 1e-3;
-      const double sp_now = (double)sp_f;
-      const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) * d_rcp(p);
-      const bool paused = paused_bits != 0;
-      auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
-      out[0] = (float)unit((p - 5000.0) * (1.0 / 9000.0));
-      out[1] = (float)soc;
-      out[5] = (float)(d2 > 0.0 ? -x * inv_d : 0.0);         // sin(atan2(-x, -y))
-      out[6] = (float)(d2 > 0.0 ? -y * inv_d : -1.0);        // cos(atan2(-x, -y)); atan2(-0, -0) = -pi
-      out[7] = (float)(dist_km * d_rcp(dist_km + 250.0));
-      out[8] = cmd == kUp ? 1.0f : 0.0f; out[9] = cmd == kStay ? 1.0f : 0.0f; out[10] = cmd == kDown ? 1.0f : 0.0f;
-      out[11] = paused ? 1.0f : 0.0f; out[12] = paused ? 0.0f : 1.0f;
-      out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) * (1.0 / 200.0));
-      out[15] = (float)ratio;
     }
   }
 
@@ -390,8 +370,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   double* el_table = sh.el_table;
   // (independent of the site and of the ephemeris nodes: before the first barrier, next to wave 0's nodes and
   // wave 1's latlng, instead of after the table where waves 2 / 3 made the others wait at B1)
-  const double l0 = atm_lapse_f64(0, alpha);
-  const double p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
+  double p_floor = 0.0;            // (waves 3 and 1 only: the search levels now, the cold starts in phase 1)
+  if (wave == 1 || wave == 3) {
+    const double l0 = atm_lapse_f64(0, alpha);
+    p_floor = 108870.8213 * d_pow_fast((300.0 + l0 * (15240.0 - -610.0)) / 300.0, -9.80665 / (kAirSpecificGasD * l0));
+  }
   if (wave == 3 && lane < 20) {
     // np.linspace(1000, p_floor, 20); p / T(p) at each level (pressure_range_builder.py:222-235)
     const double level = lane == 19 ? p_floor : 1000.0 + (double)lane * ((p_floor - 1000.0) / 19.0);
@@ -417,9 +400,33 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         }
     sh.column[lane] = acc;
   }
+  if (wave == 2) {
+    // (this wave has the shortest role: it also fills the exp table and writes the state-only ambient features)
+    if (lane >= 32) sh.exp2_frac[lane - 32] = kGpSigma2 * d_exp_fast((double)(lane - 32) * (-6.93147180559945286227e-01 / 32.0));
+    else if (lane >= 16) sh.zeros16[lane - 16] = 0.0;
+    if (lane == 63) {
+      // -- the ambient features that need only the state (features.py:400-470);   Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
+      //    rounding to float32.
+      const double soc = (double)batt_f * (1.0 / 3058.56);
+      const double d2 = x * x + y * y;
+      const double inv_d = d2 > 0.0 ? d_rsqrt(d2) : 0.0;
+      const double dist_km = d2 * inv_d * 1e-3;
+      const double sp_now = (double)sp_f;
+      const double ratio = (p + (sp_now > 0.0 ? sp_now : 0.0)) * d_rcp(p);
+      const bool paused = paused_bits != 0;
+      auto unit = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+      out[0] = (float)unit((p - 5000.0) * (1.0 / 9000.0));
+      out[1] = (float)soc;
+      out[5] = (float)(d2 > 0.0 ? -x * inv_d : 0.0);         // sin(atan2(-x, -y))
+      out[6] = (float)(d2 > 0.0 ? -y * inv_d : -1.0);        // cos(atan2(-x, -y)); atan2(-0, -0) = -pi
+      out[7] = (float)(dist_km * d_rcp(dist_km + 250.0));
+      out[8] = cmd == kUp ? 1.0f : 0.0f; out[9] = cmd == kStay ? 1.0f : 0.0f; out[10] = cmd == kDown ? 1.0f : 0.0f;
+      out[11] = paused ? 1.0f : 0.0f; out[12] = paused ? 0.0f : 1.0f;
+      out[14] = (float)unit(((double)power_table_lookup_f64(ratio, soc, &flags) - 100.0) * (1.0 / 200.0));
+      out[15] = (float)ratio;
+    }
+  }
   BLE_SUB(0);        // prologue issued (state, latlng on wave 1, ring + factor loads)
-  if (tid >= 96 && tid < 112) sh.zeros16[tid - 96] = 0.0;
-  if (tid >= 64 && tid < 96) sh.exp2_frac[tid - 64] = kGpSigma2 * d_exp_fast((double)(tid - 64) * (-6.93147180559945286227e-01 / 32.0));
   if (tid < 6) {
     double jc, frac;
     unix_day_fraction(now - 43200 + 25920 * (int64_t)tid, &jc, &frac);
@@ -430,6 +437,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     unix_day_fraction(now, &jc, &frac);
     sh.flux_now = solar_flux_f64(jc);
   }
+#ifdef BLE_OBS_TIMING
+  if ((tid & 63) == 0) sh.role_t0[tid >> 6] = (float)((long long)__builtin_readcyclecounter() - tmark[0]);
+#endif
   __syncthreads();
   BLE_SUB(1);        // ephemeris nodes + site ready
   site.sin_lat = sh.site[0]; site.cos_lat = sh.site[1]; site.lng_deg = sh.site[2];
@@ -1221,6 +1231,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
     out[kObsDim - 13] = sh.role_t[3];
+    for (int k = 0; k < 4; ++k) out[kObsDim - 38 + k] = sh.role_t0[k];
     for (int k = 0; k < 4; ++k) out[kObsDim - 20 + k] = (float)(tsub[k] - tmark[0]);
     out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
   }

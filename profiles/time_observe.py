@@ -32,4 +32,5 @@ if os.environ.get('BLE_HIP_LIB'):
   print('phase-1 roles: ambient %.0f, newton + range %.0f, drop rows 0-63 %.0f, drop rows 64+ %.0f cycles' % tuple(o[D - 16:D - 12]))
   print('phase-0 sub-marks from kernel start: prologue issued %.0f, nodes+site ready %.0f, table filled %.0f' % tuple(o[D - 20:D - 17]))
   print('sweep sub-marks from its start (core done | specials in LDS | sums reduced | per-level tail | padding): wave 0 %s ; wave 1 %s' % (' '.join('%.0f' % v for v in o[D - 34:D - 29]), ' '.join('%.0f' % v for v in o[D - 29:D - 24])))
+  print('arrival at the first barrier, waves 0-3: %.0f %.0f %.0f %.0f' % tuple(o[D - 38:D - 34]))
   print('tiles %.2f, reachable levels %.1f, share with a 9th tile %.3f' % (o[D - 4], o[D - 3], o[D - 2]))
