@@ -64,9 +64,10 @@ struct GpHistory {
 };
 
 struct ObsShared {
+  double l_guard[16];                    // zeros in front of L: the sweep pads the factor at the TOP (virtual identity rows
+                                         // 0 .. pad - 1 of the MFMA tiles), so "columns" -pad .. -1 of the first rows are read
   double L[kCholTri];                    // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
-                                         // below the diagonal, d on it.  Rows 120 .. 127 (MFMA tile padding) are
-                                         // identity and exist only virtually (zero_row, d = 1)
+                                         // below the diagonal, d on it
   union {
     struct {
       double el_table[kElevTable];       // phases 0-1: solar elevation at now + 180 s * (k - 240)
@@ -76,10 +77,7 @@ struct ObsShared {
     };
     double dinv[kGpRows / 16][136];      // phases 4-5: inverses of the 16 x 16 unit-lower diagonal blocks, packed lower
   };
-  union {
-    double zero_row[112];                // phases 4-5: the off-diagonal part of a virtual identity row
-    double pb[kGpMax][2];                // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
-  };
+  double pb[kGpMax][2];                  // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
   double loc[kGpRows][4];                // x, y, p / 326 Pa, t of the observations in the window
   double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
   double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
@@ -404,6 +402,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     // (this wave has the shortest role: it also fills the exp table and writes the state-only ambient features)
     if (lane >= 32) sh.exp2_frac[lane - 32] = kGpSigma2 * d_exp_fast((double)(lane - 32) * (-6.93147180559945286227e-01 / 32.0));
     else if (lane >= 16) sh.zeros16[lane - 16] = 0.0;
+    else sh.l_guard[lane] = 0.0;
     if (lane == 63) {
       // -- the ambient features that need only the state (features.py:400-470);   Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
       //    rounding to float32.
@@ -809,6 +808,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.L[e] = k_ij;
     }
     for (int i = n_obs + (tid - 128); i < n_pad; i += 128) { sh.z[0][i] = 0.0; sh.z[1][i] = 0.0; sh.loc[i][2] = 0.0; sh.a[i] = 0.0; }
+    if (tid == 128) {        // slot 127 of the row vectors: what the sweep reads for its virtual rows
+      sh.z[0][kGpRows - 1] = 0.0; sh.z[1][kGpRows - 1] = 0.0; sh.loc[kGpRows - 1][2] = 0.0; sh.a[kGpRows - 1] = 0.0; sh.inv_diag[kGpRows - 1] = 0.0;
+    }
   }
 #ifdef BLE_OBS_TIMING
   if ((tid & 63) == 0)
@@ -824,6 +826,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     if (r < nr) sh.L[tri(r) + r] = dnew_keep;
     if (wave == 2 && kSlideBack + 1 + lane < nr) sh.L[tri(kSlideBack + 1 + lane) + kSlideBack] = l_back_keep;
   }
+  // (with the factor padded at the top the diagonal blocks start at factor rows 16 b - pad_top: column kSlideBack can lie
+  // inside one, so the block inverses below must not start before the deferred entries are in place)
+  if (incremental && n_dropped == 1) __syncthreads();
 
   // ---- phase 2: Cholesky, left-looking, panels of 8 columns.  Thread (slot, half): slot = row
   // of the trailing matrix, half = which half of the j range.
@@ -934,27 +939,38 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const double dist = dist2 > 0.0 ? dist2 * d_rsqrt(dist2) : 0.0;
   const double inv_dist = d_rcp(dist + 1e-5);
   const double to_station_x = -x * inv_dist, to_station_y = -y * inv_dist;
-  const int n_pad_s = (nr + 15) & ~15;           // rows of the sweep, padded with virtual identity rows to the MFMA tile
+  // Rows of the sweep: nr padded to the 16-row MFMA tile with virtual identity rows AT THE TOP (MFMA row m = factor row
+  // m - pad_top).  A partial block costs its K-steps only where it is a K dimension: at the top, block column 0 has
+  // 4 - pad_top / 4 of them per row block instead of 4 (119 rows: 128 MFMAs per tile instead of 144); at the bottom it would
+  // save nothing.
+  const int n_pad_s = (nr + 15) & ~15;
+  const int pad_top = n_pad_s - nr;
   // -- inverses of the 16 x 16 (unit lower) diagonal blocks of Lt (thread = (block, column): forward substitution)
   if (tid < 128) {
     sh.z[3][tid] = (tid == 0 && nr > 0) ? 1.0 : 0.0;            // right-hand side e_0 of the drop-vector column
     const int blk = tid >> 4, c = tid & 15, base = blk * 16;
     if (base < n_pad_s) {
       double xcol[16];
+      const int shift = base - pad_top;                         // factor column of the block's column 0 (block 0: -pad_top)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         double t = r == c ? 1.0 : 0.0;
-        const double* lrow = base + r < nr ? sh.L + tri(base + r) + base : sh.zeros16;   // one select per row, not per entry
+        const int ir = base + r - pad_top;                      // factor row; virtual above the window
+        // one select per row, not per entry; a real row's virtual columns (block 0) read the zero guard or finite
+        // entries of earlier rows against x[k] = 0
+        const double* lrow = ir >= 0 ? sh.L + tri(ir >= 0 ? ir : 0) + shift : sh.zeros16;
 #pragma unroll
         for (int k = 0; k < r; ++k) t = d_fma(-lrow[k], xcol[k], t);
         xcol[r] = (r < c) ? 0.0 : t;                          // unit diagonal
+      }
+      if (base + c < pad_top) {                                 // a virtual column is an identity column
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xcol[r] = r == c ? 1.0 : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (r >= c) sh.dinv[blk][tri(r) + c] = xcol[r];
     }
-  } else if (tid < 128 + 112) {
-    sh.zero_row[tid - 128] = 0.0;                 // (aliases the (p, beta) pairs of phase 1, dead since B3)
   }
   __syncthreads();
   BLE_MARK();
@@ -1009,34 +1025,58 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const int spec_sel = jq == c_e0 ? 3 : (jq < 2 ? jq : 0);        // refit: columns 0, 1 = y_u, y_v from z[0], z[1]
     const bool use_spec = jq < kSpecial && jq != c_new;
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const int c0 = pad_top >> 2;          // K-steps 0 .. c0 - 1 of block column 0 hold only virtual rows: skipped
+    // factor row of MFMA row m is m - pad_top; virtual rows (block 0 only) read the all-zero slot 127 of the row vectors
+    auto row_slot = [&](int m) { const int i = m - pad_top; return (m < 16 && i < 0) ? kGpRows - 1 : i; };      // (m >= 16: never virtual)
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
       if (I < nb) {
         // the first product of each chain takes a literal-zero accumulator (no register zeroing)
         d4 acc[NT];
-        const double* arow = (16 * I + jq < nr ? sh.L + tri(16 * I + jq) : sh.zero_row) + g;
+        // (row blocks I >= 1 hold real rows only; their virtual columns -pad_top .. -1 read the guard in front of L or
+        // finite entries of the row above, against the zero rows of V)
+        const double* arow = sh.L + (I > 0 ? tri(16 * I + jq - pad_top) - pad_top : 0) + g;
         // right-hand sides of the special columns (tile 0): requested here, consumed after the products below --
         // read next to their use, each of the 32 loads was a full LDS round trip of the slowest wave
         double spec[4] = {0.0, 0.0, 0.0, 0.0};
         if (kFirst && wave == 0) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][16 * I + 4 * v + g];
+          for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][row_slot(16 * I + 4 * v + g)];
         }
         // (likewise the per-row inputs of the kernel matrix and the packed inverse of the diagonal block)
         double a_rows[4], p_rows[4], dpk[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          a_rows[v] = sh.a[16 * I + 4 * v + g]; p_rows[v] = sh.loc[16 * I + 4 * v + g][2];
+          a_rows[v] = sh.a[row_slot(16 * I + 4 * v + g)]; p_rows[v] = sh.loc[row_slot(16 * I + 4 * v + g)][2];
           dpk[v] = (sh.dinv[I] + tri(jq) + g)[4 * v];               // always inside dinv[I][136]; masked above the diagonal
         }
+        // one K-step of the block row: acc (+)= L[I][J](:, 4c .. 4c+3) V[J](4c .. 4c+3, :)
+        auto kstep = [&](auto j_tag, auto c_tag, auto first_tag) {
+          constexpr int J = decltype(j_tag)::value, c = decltype(c_tag)::value;
+          const double a = arow[16 * J + 4 * c];
 #pragma unroll
-        for (int J = 0; J < I; ++J)
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], decltype(first_tag)::value ? zero4 : acc[t], 0, 0, 0);
+        };
+        using std::integral_constant;
+        if (I > 0) {
+          // block column 0: K-steps c0 .. 3, the first one with the literal-zero accumulator
+          typedef integral_constant<int, 0> J0; typedef std::true_type T; typedef std::false_type F;
+          typedef integral_constant<int, 0> C0; typedef integral_constant<int, 1> C1;
+          typedef integral_constant<int, 2> C2; typedef integral_constant<int, 3> C3;
+          if (c0 == 0) { kstep(J0{}, C0{}, T{}); kstep(J0{}, C1{}, F{}); kstep(J0{}, C2{}, F{}); kstep(J0{}, C3{}, F{}); }
+          else if (c0 == 1) { kstep(J0{}, C1{}, T{}); kstep(J0{}, C2{}, F{}); kstep(J0{}, C3{}, F{}); }
+          else if (c0 == 2) { kstep(J0{}, C2{}, T{}); kstep(J0{}, C3{}, F{}); }
+          else { kstep(J0{}, C3{}, T{}); }
+        }
+#pragma unroll
+        for (int J = 1; J < I; ++J)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const double a = arow[16 * J + 4 * c];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], (J == 0 && c == 0) ? zero4 : acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
           }
         d4 R[NT];
 #pragma unroll
@@ -1050,14 +1090,15 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             const double dp = level_s[t] - p_row;
             R[t][v] = exp_neg_tab(sqrt_coupled(d_fma(dp, dp, a_row)), sh.exp2_frac);
           }
-          if (16 * I + 16 > nr) {                             // scalar: only the last block holds virtual rows
+          const bool real_row = I > 0 || row >= pad_top;
+          if (I == 0 && pad_top > 0) {                        // scalar: only the first block holds virtual rows
 #pragma unroll
-            for (int t = 0; t < NT; ++t) R[t][v] = row < nr ? R[t][v] : 0.0;
+            for (int t = 0; t < NT; ++t) R[t][v] = real_row ? R[t][v] : 0.0;
           }
           if (kFirst && wave == 0) {                          // scalar branch: tile 0 holds the special columns
             // unconditional LDS reads + selects (a load under a per-lane condition becomes an exec-mask branch);
             // z[3] holds e_0 until the solved column overwrites it
-            R[0][v] = use_spec ? (row < nr ? spec[v] : 0.0) : R[0][v];
+            R[0][v] = use_spec ? (real_row ? spec[v] : 0.0) : R[0][v];
           }
           if (I > 0) {
 #pragma unroll
@@ -1082,18 +1123,19 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       // (refit: zeta_u, zeta_v;) omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
       // the new row of the factor), the e_0 solution raw
       const int dst = jq == c_e0 ? 3 : (jq == c_new ? 2 : jq);
-      double* zdst = &sh.z[dst][g];
+      double* zdst = &sh.z[dst][0];
       // (the 32 scale factors are loaded unconditionally and together: a load under `dst < 3` is an exec-mask
       // branch with its own LDS round trip -- 32 serial ones took 4.7 k cycles of the critical wave)
       double scale[8][4];
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[16 * I + 4 * v + g];
+        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(16 * I + 4 * v + g)];
+      // (virtual rows hold zeros and go to the all-zero slot 127)
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) zdst[16 * I + 4 * v] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
+        for (int v = 0; v < 4; ++v) zdst[row_slot(16 * I + 4 * v + g)] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
     }
     if constexpr (kFirst) __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
@@ -1109,7 +1151,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         double inv_d[4], zu[4], zv[4], zw[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int row = 16 * I + 4 * v + g;
+          const int row = row_slot(16 * I + 4 * v + g);
           inv_d[v] = sh.inv_diag[row];
           zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (already / d)
         }
