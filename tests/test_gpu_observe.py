@@ -376,7 +376,7 @@ def test_observe_full_size_65536_envs(vec_state):
   want_steps = (0, 60, steps - 1, steps)
   gen = torch.Generator(device='cuda')
 
-  def fly(record):
+  def fly(record, carry=True):
     sim = vec_state.VecSimulator(n)
     sim.set_grid(torch.from_numpy(field).cuda())
     sim.reset_device(seed=31)
@@ -387,7 +387,7 @@ def test_observe_full_size_65536_envs(vec_state):
       if i > 0:
         sim.step(torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda', generator=gen))
       noise = torch.randn((n, 2), dtype=torch.float32, device='cuda', generator=gen) * 1.5
-      sim.observe(noise, out=obs)
+      sim.observe(noise, out=obs, carry_factor=carry)
       if record:
         st = {k: t[idx_t].cpu().numpy() for k, t in sim.state.items()}
         rows.append(st); noises.append(noise[idx_t].cpu().numpy().astype(np.float64))
@@ -399,6 +399,7 @@ def test_observe_full_size_65536_envs(vec_state):
   final_a, rows, noises, kept, sim = fly(True)
   assert int(sim._gp['count'].min()) == steps + 1 and sim._gp['chol'].numel() * 8 > 3.5e9
   alive = rows[-1]['status'] == 0
+  alive_all = (sim.state['status'] == 0).cpu().numpy()
   jobs = []
   for j in range(len(idx)):
     env_rows = []
@@ -426,3 +427,12 @@ def test_observe_full_size_65536_envs(vec_state):
   torch.cuda.empty_cache()
   final_b, *_ = fly(False)
   assert torch.equal(final_a, final_b)
+  # EVERY environment against the other algorithm: the same flight with the WindGP refitted from scratch at every
+  # call (blocked Cholesky in LDS instead of the carried, slid factor).  Races between the waves of the slide show up
+  # only at full occupancy and in a fraction of a percent of the environments per step: 128 samples can miss them.
+  final_c, *_ = fly(False, carry=False)
+  live = torch.from_numpy(alive_all).cuda()
+  diff = (final_a.double() - final_c.double()).abs()[live]
+  frac_loose = float((diff.amax(dim=1) > 1e-5).double().mean())
+  print(f'carried vs refitted at 65536 envs: max |diff| {float(diff.max()):.3g}, envs beyond 1e-5: {frac_loose:.2e}')
+  assert float(diff.max()) <= 2e-4 and frac_loose <= 1e-3
