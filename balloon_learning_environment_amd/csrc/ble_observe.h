@@ -93,7 +93,7 @@ struct ObsShared {
   float column[20];
   int n_obs;
   int range_ok;
-  float role_t[4], sw1[5], role_t0[4];
+  float role_t[4], sw1[5], role_t0[4], blk1[8];
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   long long tmark[12]; int nmark = 0;
   long long tsub[5] = {0, 0, 0, 0, 0};
   long long tsw[6] = {0, 0, 0, 0, 0, 0};
+  long long tblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BLE_SW(i) do { tsw[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
 #define BLE_SUB(i) do { tsub[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1027,7 +1028,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int c0 = pad_top >> 2;          // K-steps 0 .. c0 - 1 of block column 0 hold only virtual rows: skipped
     // factor row of MFMA row m is m - pad_top; virtual rows (block 0 only) read the all-zero slot 127 of the row vectors
-    auto row_slot = [&](int m) { const int i = m - pad_top; return (m < 16 && i < 0) ? kGpRows - 1 : i; };      // (m >= 16: never virtual)
+    // (as one per-lane offset computed once: slot of MFMA row 4 v + g of block 0, and g - pad_top for the blocks below,
+    // whose rows are all real -- their indices are then compile-time offsets from it)
+    const int off_rest = g - pad_top;
+    auto row_slot = [&](int I, int v) { return I > 0 ? off_rest + (16 * I + 4 * v) : (4 * v + off_rest < 0 ? kGpRows - 1 : 4 * v + off_rest); };
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
       if (I < nb) {
@@ -1041,13 +1045,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         double spec[4] = {0.0, 0.0, 0.0, 0.0};
         if (kFirst && wave == 0) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][row_slot(16 * I + 4 * v + g)];
+          for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][row_slot(I, v)];
         }
         // (likewise the per-row inputs of the kernel matrix and the packed inverse of the diagonal block)
         double a_rows[4], p_rows[4], dpk[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          a_rows[v] = sh.a[row_slot(16 * I + 4 * v + g)]; p_rows[v] = sh.loc[row_slot(16 * I + 4 * v + g)][2];
+          a_rows[v] = sh.a[row_slot(I, v)]; p_rows[v] = sh.loc[row_slot(I, v)][2];
           dpk[v] = (sh.dinv[I] + tri(jq) + g)[4 * v];               // always inside dinv[I][136]; masked above the diagonal
         }
         // one K-step of the block row: acc (+)= L[I][J](:, 4c .. 4c+3) V[J](4c .. 4c+3, :)
@@ -1115,6 +1119,9 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
         for (int t = 0; t < NT; ++t) V[t][I] = zero4;
       }
+#ifdef BLE_OBS_TIMING
+      if (kFirst) tblk[I] = (long long)__builtin_readcyclecounter();
+#endif
     }
     BLE_SW(0);       // core done (this wave)
     __builtin_amdgcn_s_setprio(1);      // what follows are short dependent chains again (-1.5 %)
@@ -1130,12 +1137,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(16 * I + 4 * v + g)];
+        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(I, v)];
       // (virtual rows hold zeros and go to the all-zero slot 127)
 #pragma unroll
       for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) zdst[row_slot(16 * I + 4 * v + g)] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
+        for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
     }
     if constexpr (kFirst) __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
@@ -1151,7 +1158,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         double inv_d[4], zu[4], zv[4], zw[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int row = row_slot(16 * I + 4 * v + g);
+          const int row = row_slot(I, v);
           inv_d[v] = sh.inv_diag[row];
           zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (already / d)
         }
@@ -1264,7 +1271,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
 #ifdef BLE_OBS_TIMING
   BLE_SW(4);         // padding written
-  if (tid == 64) { for (int k = 0; k < 5; ++k) sh.sw1[k] = (float)(tsw[k] - tmark[5]); }
+  if (tid == 64) { for (int k = 0; k < 5; ++k) sh.sw1[k] = (float)(tsw[k] - tmark[5]); for (int k = 0; k < 8; ++k) sh.blk1[k] = (float)(tblk[k] - tmark[5]); }
   __syncthreads();
   BLE_MARK();
   if (tid == 0)
@@ -1274,6 +1281,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
     out[kObsDim - 13] = sh.role_t[3];
     for (int k = 0; k < 4; ++k) out[kObsDim - 38 + k] = sh.role_t0[k];
+    for (int k = 0; k < 8; ++k) out[kObsDim - 46 + k] = sh.blk1[k];
     for (int k = 0; k < 4; ++k) out[kObsDim - 20 + k] = (float)(tsub[k] - tmark[0]);
     out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
   }

@@ -33,4 +33,5 @@ if os.environ.get('BLE_HIP_LIB'):
   print('phase-0 sub-marks from kernel start: prologue issued %.0f, nodes+site ready %.0f, table filled %.0f' % tuple(o[D - 20:D - 17]))
   print('sweep sub-marks from its start (core done | specials in LDS | sums reduced | per-level tail | padding): wave 0 %s ; wave 1 %s' % (' '.join('%.0f' % v for v in o[D - 34:D - 29]), ' '.join('%.0f' % v for v in o[D - 29:D - 24])))
   print('arrival at the first barrier, waves 0-3: %.0f %.0f %.0f %.0f' % tuple(o[D - 38:D - 34]))
+  print('sweep core of wave 1, end of row block 0..7 from the sweep start: ' + ' '.join('%.0f' % v for v in o[D - 46:D - 38]))
   print('tiles %.2f, reachable levels %.1f, share with a 9th tile %.3f' % (o[D - 4], o[D - 3], o[D - 2]))
