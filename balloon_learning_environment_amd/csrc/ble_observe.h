@@ -89,7 +89,8 @@ struct ObsShared {
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
   double lev[20], pot[20];
-  double el_now, flux_now, el_next, p_floor, p_lo, p_hi;
+  double el_now, flux_now, el_next, p_floor;
+  int lo_idx, hi_idx;                    // first / last reachable level of the 181
   float column[20];
   int n_obs;
   int range_ok;
@@ -605,7 +606,16 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     int ok = 1;
     const double p_lo_w = safe_pressure_search_wave(lev_l, sp_l, lane, ceiling, lane_read(sp_l, 20), true, &ok);
     const double p_hi_w = safe_pressure_search_wave(lev_l, sp_l, lane, p_floor, lane_read(sp_l, 21), false, &ok);
-    if (lane == 0) { sh.p_lo = p_lo_w; sh.p_hi = p_hi_w; sh.range_ok = ok; }
+    // first and last reachable level of the 181 (features.py:530-536: level >= p_lo && level <= p_hi), here and not
+    // in front of the sweep where all four waves would walk these loops
+    int lo_i = (int)((p_lo_w - 5000.0) * (1.0 / 50.0)), hi_i = (int)((p_hi_w - 5000.0) * (1.0 / 50.0));
+    lo_i = lo_i < 0 ? 0 : (lo_i > 181 ? 181 : lo_i);
+    hi_i = hi_i < -1 ? -1 : (hi_i > 180 ? 180 : hi_i);
+    while (lo_i > 0 && 5000.0 + 50.0 * (double)(lo_i - 1) >= p_lo_w) --lo_i;     // exactly the reference's comparisons
+    while (lo_i <= 180 && 5000.0 + 50.0 * (double)lo_i < p_lo_w) ++lo_i;
+    while (hi_i < 180 && 5000.0 + 50.0 * (double)(hi_i + 1) <= p_hi_w) ++hi_i;
+    while (hi_i >= 0 && 5000.0 + 50.0 * (double)hi_i > p_hi_w) --hi_i;
+    if (lane == 0) { sh.lo_idx = lo_i; sh.hi_idx = hi_i; sh.range_ok = ok; }
   } else if (wave >= 2 && incremental) {
     if (wave == 2 || n_dropped == 1) {
       // ---- drop the oldest observation: lane owns rows `lane` and `lane + 64` of the new factor
@@ -977,7 +987,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   BLE_MARK();
   BLE_STOP(3);
   // (the pressure-range search ran on wave 1 in phase 1: two barriers ago)
-  const double p_lo = sh.p_lo, p_hi = sh.p_hi;
   if (sh.range_ok == 0 && tid == 0) flags |= kFlagPressureSearch;
 
   // -- V = Lt^-1 [y | k_new | e_0 | K*^T] with v_mfma_f64_16x16x4 (K + noise = Lt D Lt^T, Lt unit lower, nr rows).
@@ -992,13 +1001,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   typedef double d4 __attribute__((ext_vector_type(4)));
   const int g = lane >> 4, jq = lane & 15;
   const int nb = n_pad_s >> 4;
-  int lo_idx = (int)((p_lo - 5000.0) * (1.0 / 50.0)), hi_idx = (int)((p_hi - 5000.0) * (1.0 / 50.0));
-  lo_idx = lo_idx < 0 ? 0 : (lo_idx > 181 ? 181 : lo_idx);
-  hi_idx = hi_idx < -1 ? -1 : (hi_idx > 180 ? 180 : hi_idx);
-  while (lo_idx > 0 && 5000.0 + 50.0 * (double)(lo_idx - 1) >= p_lo) --lo_idx;     // exactly the reference's
-  while (lo_idx <= 180 && 5000.0 + 50.0 * (double)lo_idx < p_lo) ++lo_idx;          // level >= p_lo && level <= p_hi
-  while (hi_idx < 180 && 5000.0 + 50.0 * (double)(hi_idx + 1) <= p_hi) ++hi_idx;
-  while (hi_idx >= 0 && 5000.0 + 50.0 * (double)hi_idx > p_hi) --hi_idx;
+  const int lo_idx = sh.lo_idx, hi_idx = sh.hi_idx;                                // (wave 1, phase 1)
   const int n_reach = hi_idx >= lo_idx ? hi_idx - lo_idx + 1 : 0;
   // special columns: with a carried factor zeta slid with it in phase 1, so only k_new and e_0 ride the sweep
   const int kSpecial = incremental ? 2 : 4;
