@@ -189,6 +189,38 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// stable_params (ble_reset.h; stable_init.py:40-129) for the superpressure alone, with the TWO evaluations of each
+// finite-difference Newton step on a PAIR of lanes (half = 0: T - delta / 2, half = 1: T + delta / 2; exchanged with one
+// DPP quad swap): the same arithmetic, half the dependent chain.  Both lanes of a pair return the same value.
+__device__ inline double stable_superpressure_paired(double alpha, double p, double el_deg, double flux, double ir, int half,
+                                                     uint32_t* flags) {
+  const AtmWindow w = atm_window(alpha, p, flags);
+  double h, t_amb;
+  atm_at_pressure_f64(w, alpha, p, &h, &t_amb);
+  const double ma = ((p * kAirMolarMassD * 1804.0 / (kGasConstantD * t_amb) - 68.5 - 92.5 - kHeMolarMassD * 6830.0) /
+                     kAirMolarMassD);
+  const double mols_air = ma > 0.0 ? ma : 0.0;
+  const double att = solar_attenuation_f64(el_deg, p);
+  double ti = 206.0;
+  const double delta = 0.01;
+  constexpr double kInvCbrt1804 = 0.08214626507693945;     // 1804^(-1/3)
+  uint32_t ignored = 0;
+  const double q_earth = earth_heat_per_area_f64(ir, &ignored);
+#pragma unroll 1
+  for (int k = 0; k < 10; ++k) {
+    const double mine = thermal_dtdt_f64(1804.0, kInvCbrt1804, half ? ti + delta / 2 : ti - delta / 2, t_amb, p, att, flux, q_earth);
+    const double other = quad_swap(mine, 1);
+    const double d1 = half ? other : mine, d2 = half ? mine : other;
+    const double d2t = (d2 - d1) / delta;
+    const double mean = (d1 + d2) / 2.0;
+    if (fabs(d2t) > 0.0) ti -= mean / d2t;
+    if (fabs(mean) < 1e-5) break;
+  }
+  double volume, sp;
+  superpressure_volume_f64(mols_air, ti, p, 1.0 / p, &volume, &sp);
+  return sp;
+}
+
 // The pressure-range searches run on ONE wave whose lane k < 20 holds search level k (pressure, p / T and, after the
 // cold starts, superpressure): the reference's loops over the 20 levels become ballots and lane reads instead of
 // 60 dependent LDS round trips on one lane.  `idx` arguments of lane_read must be wave-uniform.
@@ -594,14 +626,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     // lane k < 20: search level k; lane 20: the float ceiling; lane 21: the floor
     const double lev_l = lane < 20 ? sh.lev[lane] : 0.0, pot_l = lane < 20 ? sh.pot[lane] : 0.0;
     const double ceiling = pressure_ceiling_wave(lev_l, pot_l, lane);
-    double sp_l = 0.0;
-    if (lane < 22) {
-      const double level = lane < 20 ? lev_l : (lane == 20 ? ceiling : p_floor);
+    // cold starts: level lane / 2 on the lane pair (lane & ~1, lane | 1) -- 44 lanes; then back to one level per lane
+    double sp_pair = 0.0;
+    const int lvl = lane >> 1;
+    const double lev_p = __shfl(lev_l, lvl < 20 ? lvl : 0, 64);
+    if (lane < 44) {
+      const double level = lvl < 20 ? lev_p : (lvl == 20 ? ceiling : p_floor);
       uint32_t local = 0;
-      const StableParams s = stable_params(alpha, level, el_now, flux_now, (double)ir_f, &local);
-      sp_l = s.sp;
+      sp_pair = stable_superpressure_paired(alpha, level, el_now, flux_now, (double)ir_f, lane & 1, &local);
       flags |= local;
     }
+    const double sp_l = __shfl(sp_pair, lane < 22 ? 2 * lane : 0, 64);
     // ---- reachable pressure range (pressure_range_builder.py:249-275), as soon as the 22 superpressures exist
     int ok = 1;
     const double p_lo_w = safe_pressure_search_wave(lev_l, sp_l, lane, ceiling, lane_read(sp_l, 20), true, &ok);
