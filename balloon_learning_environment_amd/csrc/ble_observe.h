@@ -1165,22 +1165,29 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     __builtin_amdgcn_s_setprio(1);      // what follows are short dependent chains again (-1.5 %)
     // (no barrier here: only wave 0 reads z before this point, and it writes after its own reads)
     if (kFirst && wave == 0 && jq < kSpecial) {       // the special columns of tile 0
-      // (refit: zeta_u, zeta_v;) omega leave scaled by 1 / d (that is how every reader below wants them; omega / d is
-      // the new row of the factor), the e_0 solution raw
+      // omega and the e_0 solution leave raw: every other wave waits for this store, so it carries no loads (the
+      // readers fold 1 / d in); only the refit's zeta_u, zeta_v leave divided by d, the form they are carried in
       const int dst = jq == c_e0 ? 3 : (jq == c_new ? 2 : jq);
       double* zdst = &sh.z[dst][0];
-      // (the 32 scale factors are loaded unconditionally and together: a load under `dst < 3` is an exec-mask
-      // branch with its own LDS round trip -- 32 serial ones took 4.7 k cycles of the critical wave)
-      double scale[8][4];
+      if (dst < 2) {
+        // (the 32 scale factors are loaded unconditionally and together: a load under a per-lane condition is an
+        // exec-mask branch with its own LDS round trip -- 32 serial ones took 4.7 k cycles of the critical wave)
+        double scale[8][4];
 #pragma unroll
-      for (int I = 0; I < 8; ++I)
+        for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(I, v)];
-      // (virtual rows hold zeros and go to the all-zero slot 127)
+          for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(I, v)];
 #pragma unroll
-      for (int I = 0; I < 8; ++I)
+        for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v] * (dst < 3 ? scale[I][v] : 1.0);
+          for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v] * scale[I][v];
+      } else {
+        // (virtual rows hold zeros and go to the all-zero slot 127)
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v];
+      }
     }
     if constexpr (kFirst) __syncthreads();
     // k* K^-1 k* = sum w^2 / d,  k* K^-1 y = sum w zeta / d  (zeta = Lt^-1 y),  and -- for the bordering row --
@@ -1198,17 +1205,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         for (int v = 0; v < 4; ++v) {
           const int row = row_slot(I, v);
           inv_d[v] = sh.inv_diag[row];
-          zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (already / d)
+          zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (zeta / d; omega raw)
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const double val = V[t][I][v];                // (Lt^-1 k*)_row
-            ssq[t] = d_fma(val * val, inv_d[v], ssq[t]);
+            const double vd = val * inv_d[v];
+            ssq[t] = d_fma(val, vd, ssq[t]);
             mean_u[t] = d_fma(val, zu[v], mean_u[t]);
             mean_v[t] = d_fma(val, zv[v], mean_v[t]);
-            cross[t] = d_fma(val, zw[v], cross[t]);
+            cross[t] = d_fma(vd, zw[v], cross[t]);
           }
         }
       }
@@ -1235,7 +1243,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     // new row of the factor and next call's drop vector, straight from the solved columns
     if constexpr (kFirst) {
       if (has_last) {
-        for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i];
+        for (int i = tid; i < nr; i += kObsBlock) sh.L[tri(nr) + i] = sh.z[2][i] * sh.inv_diag[i];
       }
       __syncthreads();
       if (has_last && tid == 0) sh.L[tri(nr) + nr] = sh.last[2];
