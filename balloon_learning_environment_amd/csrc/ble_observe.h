@@ -175,6 +175,22 @@ __device__ __forceinline__ double quad_swap(double v, int xor1) {
   return b.d;
 }
 
+// Sum over the four lanes jq, jq + 16, jq + 32, jq + 48 of a wave, the total in all of them: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of a wave in the VALU (measured:
+// swap(x, x) returns the lower part's values in every lane and the upper part's), no LDS crossbar round trip.
+__device__ __forceinline__ double column_sum(double v) {
+  union { double d; int w[2]; } a, lo, hi;
+  a.d = v;
+  auto r0 = __builtin_amdgcn_permlane32_swap(a.w[0], a.w[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(a.w[1], a.w[1], false, false);
+  lo.w[0] = r0[0]; lo.w[1] = r1[0]; hi.w[0] = r0[1]; hi.w[1] = r1[1];
+  a.d = lo.d + hi.d;
+  auto q0 = __builtin_amdgcn_permlane16_swap(a.w[0], a.w[0], false, false);
+  auto q1 = __builtin_amdgcn_permlane16_swap(a.w[1], a.w[1], false, false);
+  lo.w[0] = q0[0]; lo.w[1] = q1[0]; hi.w[0] = q0[1]; hi.w[1] = q1[1];
+  return lo.d + hi.d;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane must be wave-uniform
   union { double d; int w[2]; } a, b;
   a.d = v;
@@ -1223,10 +1239,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {     // the four lanes g = 0..3 of a column hold disjoint rows
-      ssq[t] += __shfl_xor(ssq[t], 16, 64); ssq[t] += __shfl_xor(ssq[t], 32, 64);
-      mean_u[t] += __shfl_xor(mean_u[t], 16, 64); mean_u[t] += __shfl_xor(mean_u[t], 32, 64);
-      mean_v[t] += __shfl_xor(mean_v[t], 16, 64); mean_v[t] += __shfl_xor(mean_v[t], 32, 64);
-      cross[t] += __shfl_xor(cross[t], 16, 64); cross[t] += __shfl_xor(cross[t], 32, 64);
+      ssq[t] = column_sum(ssq[t]); mean_u[t] = column_sum(mean_u[t]);
+      mean_v[t] = column_sum(mean_v[t]); cross[t] = column_sum(cross[t]);
     }
     BLE_SW(2);       // sums accumulated and reduced
     // ---- the bordering row (the newest observation, window entry nr): Lt_full = [Lt 0; r^T 1], r = omega / d,
