@@ -991,8 +991,14 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
   const double ra14 = (ra * y4) * (y4 * y4);
   // (the cold-start Newton of the reset / observation kernels converges on differences of this function:
   // there the twelfth root is fp64 too)
-  const double tw = kExactTwelfthRoot ? d_pow_fast(d_fma(2.69e-8, ra, 1.0), 1.0 / 12.0)
-                                      : (double)f_pow((float)d_fma(2.69e-8, ra, 1.0), 1.0f / 12.0f);
+  // kExactTwelfthRoot: the fp32 root (1e-7 relative) refined by one Newton step on y^12 = x in fp64 -- 5e-14, a quarter
+  // of the instructions of exp(log(x) / 12)
+  const double tw_arg = d_fma(2.69e-8, ra, 1.0);
+  double tw = (double)f_pow((float)tw_arg, 1.0f / 12.0f);
+  if (kExactTwelfthRoot) {
+    const double y2 = tw * tw, y4r = y2 * y2, y8 = y4r * y4r;
+    tw = d_fma(-tw * (1.0 / 12.0), d_fma(y8 * y4r, d_rcp(tw_arg), -1.0), tw);       // y - y (y^12 / x - 1) / 12
+  }
   const double nusselt = d_fma(0.457, ra14, 2.0 + tw);
   constexpr double kCond = 0.0241 * 0.006415624181362592;   // 0.0241 / 273.15^0.9
   const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb)) * yc)) * dt;
