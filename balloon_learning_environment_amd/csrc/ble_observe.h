@@ -46,7 +46,6 @@ constexpr int kCholTri = kGpMax * (kGpMax + 1) / 2;      // 7260 doubles: the pa
 constexpr int kCholStride = kCholTri + 3 * kGpMax;       // + the drop vector p and zeta_u / d, zeta_v / d (below): 7620 doubles = 60 960 B per environment
 constexpr int kCholPrefetch = (kCholTri / 2 + 255) / 256;      // double2 loads per lane (15)
 constexpr int kObsBlock = 256;
-constexpr int kSlideBack = 95;                      // columns >= 95 of rows 96+ are slid backwards from the diagonal by the other wave
 constexpr int kElevTable = 721;                     // t + 180 s * m, m in [-240, 480]
 constexpr double kGpSigma2 = 3.6 * 3.6;             // wind_gp.py:36
 constexpr double kGpNoise2 = 0.05;                  // wind_gp.py:37
@@ -601,7 +600,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 
   // ---- phase 1: four roles
   double dnew_keep = 0.0;            // new diagonal entry of the row a drop lane owns (written after B3)
-  double l_back_keep = 0.0;          // column kSlideBack of row kSlideBack + 1 + lane (wave 2's backward pass; written after B3)
 #ifdef BLE_OBS_TIMING
   const long long role_t0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -708,13 +706,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         const double2* pbv;
         const double* old_row;
         double* new_row;
-        double w, inv_new;
+        double w, inv_new, p_mine = 0.0;
         bool own;
         int my_row;
         if (wave == 2) {
           // rows 0 .. 63.  Old row 64 -- the source of new row 63 -- is overwritten by wave 3's row 64: lane 63
           // reads the copy made before the barrier (brow[0] = l21, brow[1 + k] = column k)
-          own = own0; my_row = lane;
+          own = own0; my_row = lane; p_mine = pk0;
           dnew_keep = dk0 * gnew0 * rgp0;
           inv_new = idk0 * gprev0 * rg0;                                     // 1 / d'_k
           if (own0) {
@@ -727,13 +725,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           new_row = sh.L + tri(lane);
           wave_sync_lds();                                                   // every p has been read
           if (own0) sh.pb[lane][1] = pk0 * rg0 * idk0;                        // beta_k
-          if (rows > kSlideBack + 1) {       // (p, beta) of columns 64 .. for the backward pass below
-            const double dk1 = own1 ? sh.L[tri(lane + 65) + lane + 65] : 1.0;
-            const double pk1 = own1 ? sh.pb[lane + 64][0] : 0.0;
-            const double idk1 = d_rcp(dk1);
-            const double s1 = wave_inclusive_scan(pk1 * pk1 * idk1, lane) + readlane_f64(s0, 63);
-            if (own1) sh.pb[lane + 64][1] = pk1 * d_rcp(gamma_start + s1) * idk1;
-          }
           pbv = reinterpret_cast<const double2*>(&sh.pb[0][0]);
         } else {
           // rows 64 .. 118, with a private copy of all the (p, beta) pairs (the waves do not synchronise)
@@ -745,7 +736,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           const double s1 = wave_inclusive_scan(t1, lane) + readlane_f64(s0, 63);
           const double gnew1 = gamma_start + s1, gprev1 = gamma_start + (s1 - t1);
           const double rg1 = d_rcp(gnew1), rgp1 = d_rcp(gprev1);
-          dnew_keep = dk1 * gnew1 * rgp1;
+          dnew_keep = dk1 * gnew1 * rgp1; p_mine = pk1;
           inv_new = idk1 * gprev1 * rg1;
           const double bu1 = own1 ? d_fma(y0u, pk1, sh.loc[lane + 65][0] * dk1) : 0.0;
           const double bv1 = own1 ? d_fma(y0v, pk1, sh.loc[lane + 65][1] * dk1) : 0.0;
@@ -765,74 +756,47 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           pbv = mine;
         }
         wave_sync_lds();
-        // (lanes that own no row read in-bounds garbage into private registers)
-        // four columns per round: their (p, beta) pairs and old entries are loaded together (one LDS round
-        // trip per round instead of per column), then the four dependent FMA pairs run from registers
-        // row r has columns 0 .. r - 1; wave 3 stops at column kSlideBack - 1, wave 2 finishes rows kSlideBack + 1 .. backwards
-        const int last_col = (wave == 2 ? (rows < 64 ? rows : 64) : (rows < kSlideBack + 1 ? rows : kSlideBack + 1)) - 2;
+        // Every row is slid from BOTH ends at once (lane = row r, columns 0 .. r - 1): columns 0 .. m - 1 forwards from
+        // w^(0) = l21_r, columns r - 1 .. m backwards from the diagonal, m = (r + 1) / 2 -- w^(k+1) = sum_{k<j<r} p_j L22[r][j]
+        // + p_r because l21 = L22 p, so w^(r) = p_r, L22'[r][k] = L22[r][k] + beta_k w^(k+1), w^(k) = w^(k+1) + p_k L22[r][k].
+        // Two independent recurrences per lane, half the steps (59 for row 118): the loop is bound by the latency of its
+        // dependent FMAs and LDS round trips, not by their number.  Step j of lane r - 1 reads (backwards) the storage entry
+        // that lane r overwrites in the same step, and never one written in an earlier step: the loads of a round precede
+        // its stores.  Forward: the (p, beta) pair is the same for all lanes; backward: per lane.
         if (wave == 2 || rows > 64) {
-          // Rounds of four columns, no clamps inside: constant LDS offsets from three running pointers.  A lane
-          // stores column k only while k < its row index; otherwise the value goes to a per-lane sink (z[2..3]
-          // are idle until the sweep) -- a select between two base addresses, not a branch.
-          const int row_lim = own ? my_row : 0;
-          const double* src = old_row;
-          double* dst = new_row;
-          double* sink = &sh.z[2][0] + 4 * lane;
-          int k0 = 0;
-          for (; k0 + 3 <= last_col; k0 += 4, src += 4, dst += 4, pbv += 4) {
-            double2 pbq[4]; double lq[4];
+          // (lanes that own no row: r = 0, nothing stored; their loads stay inside the factor or the guard in front of it)
+          const int r = own ? my_row : 0;
+          const int m = (r + 1) >> 1;
+          const int r_max = (wave == 2 ? (rows < 64 ? rows : 64) : rows) - 1;
+          const int steps = (r_max + 1) >> 1;
+          double wf = w, wb = p_mine;
+          const double* fsrc = old_row;
+          double* fdst = new_row;
+          const double2* fpb = pbv;
+          const double* bsrc = old_row + (r - 4);          // columns k_hi - 3 .. k_hi, k_hi = r - 1 - j
+          const double2* bpb = pbv + (r - 4);
+          double* bdst = new_row + (r - 4);
+          double* sink = &sh.z[2][0] + 4 * lane;           // (z[2..3] are idle until the sweep)
+          for (int j0 = 0; j0 < steps; j0 += 4) {
+            double2 fp[4], bp[4]; double fl[4], bl[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pbq[j] = pbv[j]; lq[j] = src[j]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              w = d_fma(-pbq[j].x, lq[j], w);
-              const double nv = d_fma(pbq[j].y, w, lq[j]);
-              (row_lim > k0 + j ? dst : sink)[j] = nv;
-            }
-          }
-          for (; k0 <= last_col; ++k0, ++src, ++dst, ++pbv) {
-            const double2 pbq = pbv[0];
-            const double lq = src[0];
-            w = d_fma(-pbq.x, lq, w);
-            const double nv = d_fma(pbq.y, w, lq);
-            (row_lim > k0 ? dst : sink)[0] = nv;
-          }
-          if (own) sh.inv_diag[my_row] = inv_new;      // (the new diagonal itself is written after the barrier, below)
-        }
-        if (wave == 2 && rows > kSlideBack + 1) {
-          // Rows 96 .. of the new factor, columns kSlideBack .. r - 1, BACKWARDS from the diagonal (wave 3 would need 118
-          // forward steps for them; this wave has 63):  w^(k+1) = sum_{k<j<r} p_j L22[r][j] + p_r  (because l21 = L22 p),
-          // so  w^(r) = p_r,  L22'[r][k] = L22[r][k] + beta_k w^(k+1),  w^(k) = w^(k+1) + p_k L22[r][k].
-          // Lane = row, so the column index differs per lane.  Step j of lane r - 1 reads the storage entry that lane r
-          // overwrites in the same step: the loads of a step precede its stores.  Column kSlideBack's storage is still
-          // read by wave 3 (as the old column kSlideBack - 1 of the row above): it is written after the barrier.
-          wave_sync_lds();                               // this wave's betas are in LDS
-          const int rb = kSlideBack + 1 + lane;
-          const bool ownb = rb < rows;
-          double wb = ownb ? sh.pb[rb][0] : 0.0;
-          const double* oldb = sh.L + tri(ownb ? rb + 1 : 1) + 1;
-          double* newb = sh.L + tri(ownb ? rb : 0);
-          double* sinkb = &sh.z[2][0] + 4 * lane;
-          const double2* pq = reinterpret_cast<const double2*>(&sh.pb[0][0]);
-          const int steps = rows - 1 - kSlideBack;       // of the last row (<= 23)
-          // four steps per round from two running pointers with constant offsets; no clamps: a lane past its last column
-          // reads in-bounds entries of its own storage row (column >= kSlideBack - 25) and stores to the sink
-          const double* ob = oldb + (rb - 4);            // columns k_hi - 3 .. k_hi, k_hi = rb - 1 - j
-          const double2* pp = pq + (rb - 4);
-          double* nb = newb + (rb - 4);
-          for (int j = 0; j < steps; j += 4, ob -= 4, pp -= 4, nb -= 4) {
-            double2 pbq[4]; double lq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { pbq[i] = pp[3 - i]; lq[i] = ob[3 - i]; }
+            for (int i = 0; i < 4; ++i) { fp[i] = fpb[i]; fl[i] = fsrc[i]; bp[i] = bpb[3 - i]; bl[i] = bsrc[3 - i]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int k = rb - 1 - j - i;
-              const double nv = d_fma(pbq[i].y, wb, lq[i]);
-              wb = d_fma(pbq[i].x, lq[i], wb);
-              (ownb && k > kSlideBack ? nb : sinkb)[3 - i] = nv;
-              l_back_keep = (ownb && k == kSlideBack) ? nv : l_back_keep;
+              const int kf = j0 + i, kb = r - 1 - j0 - i;
+              wf = d_fma(-fp[i].x, fl[i], wf);
+              const double nf = d_fma(fp[i].y, wf, fl[i]);
+              const double nb = d_fma(bp[i].y, wb, bl[i]);
+              wb = d_fma(bp[i].x, bl[i], wb);
+              (kf < m ? fdst : sink)[i] = nf;
+              (kb >= m ? bdst : sink)[3 - i] = nb;
             }
+            fsrc += 4; fdst += 4; fpb += 4;
+            // (a lane whose backward half is finished stops moving left: its reads stay inside its own storage row)
+            const int back = r - 8 - j0 >= 0 ? 4 : 0;
+            bsrc -= back; bpb -= back; bdst -= back;
           }
+          if (own) sh.inv_diag[my_row] = inv_new;      // (the new diagonal itself is written after the barrier, below)
         }
       } else {
         // nothing left the window: the factor and zeta / d stand
@@ -886,11 +850,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   if (wave >= 2 && incremental && n_dropped == 1) {
     const int r = lane + 64 * (wave - 2);
     if (r < nr) sh.L[tri(r) + r] = dnew_keep;
-    if (wave == 2 && kSlideBack + 1 + lane < nr) sh.L[tri(kSlideBack + 1 + lane) + kSlideBack] = l_back_keep;
   }
-  // (with the factor padded at the top the diagonal blocks start at factor rows 16 b - pad_top: column kSlideBack can lie
-  // inside one, so the block inverses below must not start before the deferred entries are in place)
-  if (incremental && n_dropped == 1) __syncthreads();
 
   // ---- phase 2: Cholesky, left-looking, panels of 8 columns.  Thread (slot, half): slot = row
   // of the trailing matrix, half = which half of the j range.
