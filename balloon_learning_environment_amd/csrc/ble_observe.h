@@ -109,6 +109,21 @@ __device__ __forceinline__ double exp_neg_tab(double r, const double* tab) {
   const double pr = d_fma(rem, d_fma(rem, d_fma(rem, d_fma(rem, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
   return d_ldexp(d_fma(t * rem, pr, t), -(ni >> 5));
 }
+// The same in two stages, so that the table read of stage A can fly under other work (the sweep puts a row block's
+// MFMAs between them): A = reduction + table request, B = polynomial, scale, exponent.
+struct ExpStage { double rem, t; int ni; };
+__device__ __forceinline__ ExpStage exp_neg_stage_a(double r, const double* tab) {
+  ExpStage e;
+  const double n = d_rint(r * 46.16624130844682903);
+  e.rem = d_fma(n, 2.16608493924982909192e-02, -r);
+  e.ni = (int)n;
+  e.t = tab[e.ni & 31];
+  return e;
+}
+__device__ __forceinline__ double exp_neg_stage_b(const ExpStage& e) {
+  const double pr = d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  return d_ldexp(d_fma(e.t * e.rem, pr, e.t), -(e.ni >> 5));
+}
 // sqrt(x), x >= 1e-300: one coupled Newton step on (g, h) = (x y, y / 2) from the 5e-8 seed y = rsq(x): 4e-15 relative,
 // five instructions
 __device__ __forceinline__ double sqrt_coupled(double x) {
@@ -1070,6 +1085,16 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           a_rows[v] = sh.a[row_slot(I, v)]; p_rows[v] = sh.loc[row_slot(I, v)][2];
           dpk[v] = (sh.dinv[I] + tri(jq) + g)[4 * v];               // always inside dinv[I][136]; masked above the diagonal
         }
+        // kernel matrix of the block, stage A (distance, square root, exp reduction, table request) BEFORE the block's
+        // products: the table reads land under the MFMAs; stage B (polynomial) after them
+        ExpStage kst[NT][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const double dp = level_s[t] - p_rows[v];
+            kst[t][v] = exp_neg_stage_a(sqrt_coupled(d_fma(dp, dp, a_rows[v])), sh.exp2_frac);
+          }
         // one K-step of the block row: acc (+)= L[I][J](:, 4c .. 4c+3) V[J](4c .. 4c+3, :)
         auto kstep = [&](auto j_tag, auto c_tag, auto first_tag) {
           constexpr int J = decltype(j_tag)::value, c = decltype(c_tag)::value;
@@ -1102,13 +1127,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * I + 4 * v + g;
-          const double a_row = a_rows[v], p_row = p_rows[v];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused);
             // s^2 is folded into the exp table; a_row carries a 1e-300 guard for r2 == 0
-            const double dp = level_s[t] - p_row;
-            R[t][v] = exp_neg_tab(sqrt_coupled(d_fma(dp, dp, a_row)), sh.exp2_frac);
+            R[t][v] = exp_neg_stage_b(kst[t][v]);
           }
           const bool real_row = I > 0 || row >= pad_top;
           if (I == 0 && pad_top > 0) {                        // scalar: only the first block holds virtual rows
