@@ -239,11 +239,17 @@ def observe_leg(roll, pairs, world):
   sim.check_errors()
   live = float((sim.state['status'] == 0).sum().item())
   ms_obs, ms_pair = statistics.median(t_obs), statistics.median(t_pair)
-  # algorithmic work per env-observation: 144 v_mfma_f64_16x16x4 per 16-column tile x 8 tiles
-  # (4 special columns + the ~121 reachable levels) + 32 for the diagonal-block inverses, x 2 048 flop, + ~0.9 MFLOP
-  # of fp64 VALU (kernel matrix K*, elevation table, drop recurrences, cold starts); algorithmic bytes: 4 396 out
-  # + 2 x 60 960 factor, drop vector and zeta in/out + 152 state + 3 072 ring
-  flop = (144 * 8 + 32) * 2048 + 0.9e6
+  # ALGORITHMIC work per env-observation, independent of how the kernel tiles it: the forward substitution
+  # V = Lt^-1 [k_new | e_0 | K*^T] on 119 rows x (2 + 121 reachable levels) columns = n (n - 1) m flop; the kernel matrix
+  # (119 x 123 entries x ~40 flop: distance, square root, exp); the four sums per level (119 x 123 x 8); the window slide
+  # (7 021 entries x 4); the 721-entry elevation table (~200 flop per entry); the 22 cold starts; all fp64.
+  # (The kernel EXECUTES more: 16-row MFMA tiles pad 119 rows to 128 and 123 columns to 128 -- 1 042 MFMAs x 2 048 flop
+  # = 2.13 MFLOP for the 1.73 MFLOP substitution -- and the block inverses; `executed_mfma_tflops` reports that rate.)
+  # Algorithmic bytes: 4 396 out + 2 x 60 960 factor, drop vector and zeta in/out + 152 state + 3 072 ring
+  n_rows, n_cols = 119, 2 + 121
+  flop = (n_rows * (n_rows - 1) * n_cols + n_rows * n_cols * 40 + n_rows * n_cols * 8 + 7021 * 4 + 721 * 200
+          + 22 * 6 * 2 * 150)
+  mfma_flop_executed = 1042 * 2048
   obs_bytes = 4396 + 2 * 60960 + 152 + 3072
   traffic = None
   try:
@@ -259,6 +265,7 @@ def observe_leg(roll, pairs, world):
           'kernel': 'ble_observe_kernel (fp64 WindGP: factor carried in HBM and slid with a stored drop vector, MFMA forward substitution)',
           'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS, 'achieved': tf, 'frac': tf / FP64_PEAK_TFLOPS,
                        'traffic': traffic, 'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': obs_bytes,
+                       'executed_mfma_tflops': n * mfma_flop_executed / (ms_obs * 1e-3) / 1e12,
                        'hbm_gbs_algorithmic': n * obs_bytes / (ms_obs * 1e-3) / 1e9, 'hbm_gbs_measured': (traffic / (ms_obs * 1e-3) / 1e9) if traffic else None}}
 
 
