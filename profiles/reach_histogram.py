@@ -1,4 +1,5 @@
-"""Histogram of reachable levels per environment after 125 steps (needs a -DBLE_OBS_TIMING build: BLE_HIP_LIB=...).\n   python profiles/reach_histogram.py"""
+"""Histogram of reachable levels per environment after 125 steps (needs a -DBLE_OBS_TIMING build: BLE_HIP_LIB=...).
+   python profiles/reach_histogram.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from balloon_learning_environment_amd import vec_state

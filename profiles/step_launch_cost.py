@@ -1,4 +1,5 @@
-"""Per-launch fixed cost of ble_step_kernel: launches of K = 1 .. 32 agent steps (4 back to back per event pair).\n   python profiles/step_launch_cost.py"""
+"""Per-launch fixed cost of ble_step_kernel: launches of K = 1 .. 32 agent steps (4 back to back per event pair).
+   python profiles/step_launch_cost.py"""
 import sys, statistics, numpy as np, torch
 sys.path.insert(0, '.')
 from balloon_learning_environment_amd import vec_state, reset_host
