@@ -436,3 +436,54 @@ def test_observe_full_size_65536_envs(vec_state):
   frac_loose = float((diff.amax(dim=1) > 1e-5).double().mean())
   print(f'carried vs refitted at 65536 envs: max |diff| {float(diff.max()):.3g}, envs beyond 1e-5: {frac_loose:.2e}')
   assert float(diff.max()) <= 2e-4 and frac_loose <= 1e-3
+
+
+def test_irregular_history_carried_equals_refit_at_occupancy(vec_state):
+  """Irregular use of the history (skipped observations, get_features without observe, episode resets of a third of
+  the environments) on 16 384 environments -- enough to fill every CU with two workgroups, where races between the
+  waves of the slide would show -- flown twice, with the carried, slid factor and with a refit at every call: every
+  environment of every compared step must agree."""
+  n, steps = 16384, 330
+  rng = np.random.default_rng(23)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  plan = []
+  skipping = 0
+  for i in range(steps):
+    reset = i in (70, 231)
+    if skipping > 0:
+      skipping -= 1
+      plan.append((reset, None)); continue
+    if rng.random() < 0.025:            # (long stretches of regular steps in between: the window fills and slides)
+      skipping = int(rng.integers(1, 30))
+    plan.append((reset, bool(rng.random() > 0.1)))
+
+  def fly(carry):
+    sim = vec_state.VecSimulator(n)
+    sim.set_grid(torch.from_numpy(field).cuda())
+    sim.reset_device(seed=77)
+    gen = torch.Generator(device='cuda'); gen.manual_seed(3)
+    outs = []
+    obs = torch.empty(n, 1099, dtype=torch.float32, device='cuda')
+    for i, (reset, append) in enumerate(plan):
+      sim.step(torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda', generator=gen))
+      noise = torch.randn((n, 2), dtype=torch.float32, device='cuda', generator=gen)
+      if reset:
+        mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[::3] = 1
+        sim.reset_device(seed=1000 + i, mask=mask)
+      if append is None:
+        continue
+      sim.observe(noise, append=append, out=obs, carry_factor=carry)
+      if i % 9 == 0 or i > steps - 4 or not append:
+        outs.append((i, obs.clone(), (sim.state['status'] == 0).clone()))
+    sim.check_errors()
+    return outs
+
+  a, b = fly(True), fly(False)
+  assert len(a) == len(b) and len(a) >= 10
+  worst = 0.0
+  for (i, oa, la), (_, ob, lb) in zip(a, b):
+    assert torch.equal(la, lb)
+    d = (oa.double() - ob.double()).abs()[la]
+    worst = max(worst, float(d.max()))
+    assert float(d.max()) <= 2e-4 and float((d.amax(dim=1) > 1e-5).double().mean()) <= 1e-3, (i, float(d.max()))
+  print(f'irregular history at 16384 envs, carried vs refitted: {len(a)} compared steps, worst |diff| {worst:.3g}')
