@@ -49,8 +49,6 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   __shared__ double acs_poly[kAcsPolyDoubles];
-  if (threadIdx.x < 12) acs_build_poly(kAcsEfficiency, (int)threadIdx.x, acs_poly + 6 * threadIdx.x);
-  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
   const bool in_range = i < n && (int)threadIdx.x < lanes;
   uint32_t flags = 0;
@@ -70,6 +68,9 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     c.ir = st.upwelling_infrared[i]; c.alpha = st.alpha[i]; c.start_unix = st.start_unix[i];
     live = s.status == kOk;
   }
+  // (the ACS table's piecewise cubics are built while the state loads above are in flight)
+  if (threadIdx.x < 12) acs_build_poly(kAcsEfficiency, (int)threadIdx.x, acs_poly + 6 * threadIdx.x);
+  __syncthreads();
   const bool was_live = live;
   int last_act = 0;
   EnvHoisted hc;
