@@ -232,8 +232,14 @@ class BalloonArena(BalloonArenaInterface):
     self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
     self._bind_wind_field()
     self.feature_constructor = self._feature_constructor_factory(self._wind_field, self._vec.get_atmosphere())
-    self.feature_constructor.observe(self.get_measurements())
+    if hasattr(self.feature_constructor, 'bind_state'):       # the device constructor reads this arena's state in place
+      self.feature_constructor.bind_state(self._vec.sim)
+    self._observe()
     return self.feature_constructor.get_features()
+
+  def _observe(self) -> None:
+    fc = self.feature_constructor
+    (fc.observe_bound if getattr(fc, '_bound', False) else fc.observe)(self.get_measurements())
 
   def step(self, action: control.AltitudeControlCommand) -> np.ndarray:
     # balloon.py:288-290: stepping a terminal balloon is an error in the single-env API
@@ -245,7 +251,7 @@ class BalloonArena(BalloonArenaInterface):
     self._row = None
     self._vec.sim.check_errors()
     self.last_reward = float(reward[0].item())
-    self.feature_constructor.observe(self.get_measurements())
+    self._observe()
     return self.feature_constructor.get_features()
 
   def get_simulator_state(self) -> simulator_data.SimulatorState:

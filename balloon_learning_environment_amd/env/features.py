@@ -287,12 +287,32 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     self._features = None
     self.num_features = 1099
 
+  def bind_state(self, sim) -> None:
+    """The arena that owns this constructor flies its balloon in `sim` (a one-environment VecSimulator on the same
+    device).  The private simulator then ALIASES that state: `observe_bound` reads it where it already is instead of
+    copying 26 fields host -> device per step (0.36 ms of the single-env facade's 1.03 ms)."""
+    from balloon_learning_environment_amd import device as dev
+    assert sim.n == 1 and sim.device == self._sim.device
+    self._sim.state = sim.state
+    self._sim._struct = dev.state_struct(sim.state)
+    self._bound = True
+
+  def observe_bound(self, observation: simulator_data.SimulatorObservation) -> None:
+    """observe() for the owning arena: `observation` describes the bound simulator's current state."""
+    assert getattr(self, '_bound', False)
+    self._observe(observation, copy_state=False)
+
   def observe(self, observation: simulator_data.SimulatorObservation) -> None:
+    self._observe(observation, copy_state=True)
+
+  def _observe(self, observation: simulator_data.SimulatorObservation, copy_state: bool) -> None:
     import torch
     from balloon_learning_environment_amd.env.balloon import balloon as balloon_lib
     b = observation.balloon_observation
-    row = balloon_lib.row_from_state(b, self._alpha)
-    self._sim.set_state({k: np.array([v]) for k, v in row.items()})
+    if copy_state:
+      assert not getattr(self, '_bound', False), 'a bound constructor observes its arena (observe_bound)'
+      row = balloon_lib.row_from_state(b, self._alpha)
+      self._sim.set_state({k: np.array([v]) for k, v in row.items()})
     fc = self._forecast.get_forecast(b.x, b.y, b.pressure, b.time_elapsed)
     w = observation.wind_at_balloon
     noise = torch.tensor([[w.u.mps - fc.u.mps, w.v.mps - fc.v.mps]], dtype=torch.float32, device=self._sim.device)
