@@ -74,7 +74,7 @@ struct ObsShared {
       double pb3[kGpMax][2];             // phase 1: wave 3's own (p_k, beta_k) pairs (the two drop waves do not synchronise)
       double brow[64];                   // phase 1: old factor row 64 (wave 3 overwrites it while wave 2 still reads it)
     };
-    double dinv[kGpRows / 16][136];      // phases 4-5: inverses of the 16 x 16 unit-lower diagonal blocks, packed lower
+    double dinv[kGpRows / 16][138];      // [136]: a zero, read by the lanes above the diagonal of the packed triangle
   };
   double pb[kGpMax][2];                  // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
   double loc[kGpRows][4];                // x, y, p / 326 Pa, t of the observations in the window
@@ -83,7 +83,7 @@ struct ObsShared {
   double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
   double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
   double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
-  double exp2_frac[32];                  // s^2 2^(-j / 32): s^2 exp(-r) = 2^-k * (s^2 2^(-j/32)) * P5(rem), |rem| <= ln2 / 64
+  double exp2_frac[64];                  // s^2 2^(-j / 64): s^2 exp(-r) = 2^-k * (s^2 2^(-j/64)) * P4(rem), |rem| <= ln2 / 128
   double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
   double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
   double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
@@ -97,32 +97,34 @@ struct ObsShared {
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
-// s^2 exp(-r), r >= 0, for the kernel matrix K* (the table carries the scale s^2 and the sign: tab[j] = s^2 2^(-j/32)):
-// r = (32 k + j) ln2 / 32 - rem, |rem| <= ln2 / 64, degree-5 Taylor in rem (truncation 2e-15).  One fused reduction
-// step: n ln2/32 is exact inside the FMA and n <= ~1500, so the rounding of the constant costs <= 3e-15 absolute.
-// 11 fp64 instructions (the table-free d_exp_fast: 20 + 16 constants) -- the sweep evaluates it 64 times per lane.
+// s^2 exp(-r), r >= 0, for the kernel matrix K* (the table carries the scale s^2 and the sign: tab[j] = s^2 2^(-j/64)):
+// r = (64 k + j) ln2 / 64 - rem, |rem| <= ln2 / 128, degree-4 Taylor in rem (truncation 4e-14 relative: with
+// cond(K) ~ 3e4 that is 1e-9 on the posterior, four orders below the parity bar; the 32-entry / degree-5 form it
+// replaces was 2e-15 and one FMA longer).  One fused reduction step: n ln2/64 is exact inside the FMA and n <= ~3000,
+// so the rounding of the constant costs <= 3e-15 absolute.
+// 10 fp64 instructions (the table-free d_exp_fast: 20 + 16 constants) -- the sweep evaluates it 64 times per lane.
 __device__ __forceinline__ double exp_neg_tab(double r, const double* tab) {
-  const double n = d_rint(r * 46.16624130844682903);                  // 32 / ln 2
-  const double rem = d_fma(n, 2.16608493924982909192e-02, -r);        // ln2 / 32
+  const double n = d_rint(r * 92.33248261689365806);                  // 64 / ln 2
+  const double rem = d_fma(n, 1.08304246962491454596e-02, -r);        // ln2 / 64
   const int ni = (int)n;
-  const double t = tab[ni & 31];
-  const double pr = d_fma(rem, d_fma(rem, d_fma(rem, d_fma(rem, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
-  return d_ldexp(d_fma(t * rem, pr, t), -(ni >> 5));
+  const double t = tab[ni & 63];
+  const double pr = d_fma(rem, d_fma(rem, d_fma(rem, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+  return d_ldexp(d_fma(t * rem, pr, t), -(ni >> 6));
 }
 // The same in two stages, so that the table read of stage A can fly under other work (the sweep puts a row block's
 // MFMAs between them): A = reduction + table request, B = polynomial, scale, exponent.
 struct ExpStage { double rem, t; int ni; };
 __device__ __forceinline__ ExpStage exp_neg_stage_a(double r, const double* tab) {
   ExpStage e;
-  const double n = d_rint(r * 46.16624130844682903);
-  e.rem = d_fma(n, 2.16608493924982909192e-02, -r);
+  const double n = d_rint(r * 92.33248261689365806);
+  e.rem = d_fma(n, 1.08304246962491454596e-02, -r);
   e.ni = (int)n;
-  e.t = tab[e.ni & 31];
+  e.t = tab[e.ni & 63];
   return e;
 }
 __device__ __forceinline__ double exp_neg_stage_b(const ExpStage& e) {
-  const double pr = d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
-  return d_ldexp(d_fma(e.t * e.rem, pr, e.t), -(e.ni >> 5));
+  const double pr = d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+  return d_ldexp(d_fma(e.t * e.rem, pr, e.t), -(e.ni >> 6));
 }
 // sqrt(x), x >= 1e-300: one coupled Newton step on (g, h) = (x y, y / 2) from the 5e-8 seed y = rsq(x): 4e-15 relative,
 // five instructions
@@ -466,9 +468,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   if (wave == 2) {
     // (this wave has the shortest role: it also fills the exp table and writes the state-only ambient features)
-    if (lane >= 32) sh.exp2_frac[lane - 32] = kGpSigma2 * d_exp_fast((double)(lane - 32) * (-6.93147180559945286227e-01 / 32.0));
-    else if (lane >= 16) sh.zeros16[lane - 16] = 0.0;
-    else sh.l_guard[lane] = 0.0;
+    sh.exp2_frac[lane] = kGpSigma2 * d_exp_fast((double)lane * (-6.93147180559945286227e-01 / 64.0));
+    if (lane < 16) { sh.zeros16[lane] = 0.0; sh.l_guard[lane] = 0.0; }
     if (lane == 63) {
       // -- the ambient features that need only the state (features.py:400-470);   Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
       //    rounding to float32.
@@ -1011,6 +1012,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         if (r >= c) sh.dinv[blk][tri(r) + c] = xcol[r];
     }
   }
+  else if (tid < 136) sh.dinv[tid - 128][136] = 0.0;
   __syncthreads();
   BLE_MARK();
   BLE_STOP(3);
@@ -1041,7 +1043,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   auto sweep = [&](auto nt_tag, auto first_tag, int tile_base) {
     constexpr int NT = decltype(nt_tag)::value;
     constexpr bool kFirst = decltype(first_tag)::value;
-    d4 V[NT][8];
+    d4 V[NT][8];                                    // (row blocks I >= nb are never formed and never read)
     int col[NT];
     double level[NT];
 #pragma unroll
@@ -1062,6 +1064,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     // (as one per-lane offset computed once: slot of MFMA row 4 v + g of block 0, and g - pad_top for the blocks below,
     // whose rows are all real -- their indices are then compile-time offsets from it)
     const int off_rest = g - pad_top;
+    // packed lower triangle of a block inverse: the lanes above the diagonal read the zero at [136] (an offset chosen
+    // once per lane, not a compare + select per load)
+    int doff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) doff[c] = 4 * c + g <= jq ? tri(jq) + g + 4 * c : 136;
     auto row_slot = [&](int I, int v) { return I > 0 ? off_rest + (16 * I + 4 * v) : (4 * v + off_rest < 0 ? kGpRows - 1 : 4 * v + off_rest); };
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           a_rows[v] = sh.a[row_slot(I, v)]; p_rows[v] = sh.loc[row_slot(I, v)][2];
-          dpk[v] = (sh.dinv[I] + tri(jq) + g)[4 * v];               // always inside dinv[I][136]; masked above the diagonal
+          dpk[v] = sh.dinv[I][doff[v]];
         }
         // kernel matrix of the block, stage A (distance, square root, exp reduction, table request) BEFORE the block's
         // products: the table reads land under the MFMAs; stage B (polynomial) after them
@@ -1150,13 +1157,10 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double a = 4 * c + g <= jq ? dpk[c] : 0.0;            // packed lower triangle
+          const double a = dpk[c];
 #pragma unroll
           for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], c == 0 ? zero4 : V[t][I], 0, 0, 0);
         }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) V[t][I] = zero4;
       }
 #ifdef BLE_OBS_TIMING
       if (kFirst) tblk[I] = (long long)__builtin_readcyclecounter();
@@ -1180,14 +1184,18 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           for (int v = 0; v < 4; ++v) scale[I][v] = sh.inv_diag[row_slot(I, v)];
 #pragma unroll
         for (int I = 0; I < 8; ++I)
+          if (I < nb) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v] * scale[I][v];
+            for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v] * scale[I][v];
+          }
       } else {
         // (virtual rows hold zeros and go to the all-zero slot 127)
 #pragma unroll
         for (int I = 0; I < 8; ++I)
+          if (I < nb) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v];
+            for (int v = 0; v < 4; ++v) zdst[row_slot(I, v)] = V[0][I][v];
+          }
       }
     }
     if constexpr (kFirst) __syncthreads();
