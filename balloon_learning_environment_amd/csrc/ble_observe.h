@@ -1155,11 +1155,22 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
             for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
           }
         }
+        // V[I] = Dinv[I] R.  Block 0: the K-steps that hold only virtual rows (zero rows of R against identity columns)
+        // are skipped like those of block column 0 above
+        auto dstep = [&](auto c_tag, auto first_tag) {
+          constexpr int c = decltype(c_tag)::value;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double a = dpk[c];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[t][c], c == 0 ? zero4 : V[t][I], 0, 0, 0);
+          for (int t = 0; t < NT; ++t)
+            V[t][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(dpk[c], R[t][c], decltype(first_tag)::value ? zero4 : V[t][I], 0, 0, 0);
+        };
+        {
+          typedef std::true_type T; typedef std::false_type F;
+          typedef integral_constant<int, 0> C0; typedef integral_constant<int, 1> C1;
+          typedef integral_constant<int, 2> C2; typedef integral_constant<int, 3> C3;
+          if (I > 0 || c0 == 0) { dstep(C0{}, T{}); dstep(C1{}, F{}); dstep(C2{}, F{}); dstep(C3{}, F{}); }
+          else if (c0 == 1) { dstep(C1{}, T{}); dstep(C2{}, F{}); dstep(C3{}, F{}); }
+          else if (c0 == 2) { dstep(C2{}, T{}); dstep(C3{}, F{}); }
+          else { dstep(C3{}, T{}); }
         }
       }
 #ifdef BLE_OBS_TIMING
