@@ -113,15 +113,17 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   }
   // Sun at stride k of this step: quadratic through the three fp64 nodes, fp32; the reference's
   // own fp64 chain on the (rare) strides where a solar threshold is within the fp32 floor.
-  // (everything the exact path reads -- s.x, s.y, u, v, s.t_elapsed, c -- is live across the loop anyway)
+  // (position and time at the START of the step, by value: the reward below calls this after s has been advanced)
+  const float x_start = s.x, y_start = s.y;
+  const int32_t t_start = s.t_elapsed;
   auto sun_at = [&](int kk) -> SunState {
     const float fkk = (float)kk;
     bool near;
     SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
     if (__builtin_expect(near, 0)) {
       const double dk = 10.0 * (double)kk;
-      r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)s.x), d_fma(dk, (double)v, (double)s.y),
-                    c.start_unix + (int64_t)(s.t_elapsed + 10 * kk));
+      r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
+                    c.start_unix + (int64_t)(t_start + 10 * kk));
     }
     return r;
   };
