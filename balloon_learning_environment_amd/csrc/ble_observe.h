@@ -1094,13 +1094,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         }
         // kernel matrix of the block, stage A (distance, square root, exp reduction, table request) BEFORE the block's
         // products: the table reads land under the MFMAs; stage B (polynomial) after them
+        // (block 0: the rows 4 v + g of a register v < c0 are all virtual -- their K-steps of the block inverse are skipped
+        // below, so the entries are neither evaluated nor read)
         ExpStage kst[NT][4];
 #pragma unroll
         for (int v = 0; v < 4; ++v)
+          if (I > 0 || v >= c0) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const double dp = level_s[t] - p_rows[v];
-            kst[t][v] = exp_neg_stage_a(sqrt_coupled(d_fma(dp, dp, a_rows[v])), sh.exp2_frac);
+            for (int t = 0; t < NT; ++t) {
+              const double dp = level_s[t] - p_rows[v];
+              kst[t][v] = exp_neg_stage_a(sqrt_coupled(d_fma(dp, dp, a_rows[v])), sh.exp2_frac);
+            }
           }
         // one K-step of the block row: acc (+)= L[I][J](:, 4c .. 4c+3) V[J](4c .. 4c+3, :)
         auto kstep = [&](auto j_tag, auto c_tag, auto first_tag) {
@@ -1132,7 +1136,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           }
         d4 R[NT];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 4; ++v) if (I > 0 || v >= c0) {
           const int row = 16 * I + 4 * v + g;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
@@ -1222,13 +1226,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         // (the 16 LDS operands of a row block are requested together, then consumed: one round trip per block)
         double inv_d[4], zu[4], zv[4], zw[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 4; ++v) if (I > 0 || v >= c0) {          // (all-virtual registers of block 0 hold zeros)
           const int row = row_slot(I, v);
           inv_d[v] = sh.inv_diag[row];
           zu[v] = sh.z[0][row]; zv[v] = sh.z[1][row]; zw[v] = sh.z[2][row];          // (zeta / d; omega raw)
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < 4; ++v) if (I > 0 || v >= c0) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const double val = V[t][I][v];                // (Lt^-1 k*)_row
