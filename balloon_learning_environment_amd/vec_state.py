@@ -217,6 +217,35 @@ class VecSimulator:
                                    dev.stream_ptr(self.device))
     _lib.check(code, 'ble_step_n_f32')
 
+  def prepare_step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
+                     active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):
+    """step_n with everything but the launch done NOW: the checks run once and the arguments are marshalled once;
+    the returned callable enqueues the K agent steps on the stream that is current when IT is called (~3 us of host
+    time instead of ~10).  For loops that launch the same buffers again and again (rollouts, the benchmark); the
+    caller keeps the tensors, the grid and the simulator alive and unchanged in shape."""
+    k = actions.shape[0]
+    assert actions.dtype == torch.uint8 and actions.is_contiguous() and tuple(actions.shape) == (k, self.n)
+    assert rewards.dtype == torch.float32 and tuple(rewards.shape) == (k, self.n) and rewards.is_contiguous()
+    assert terminals.dtype == torch.uint8 and tuple(terminals.shape) == (k, self.n) and terminals.is_contiguous()
+    if active_counts is not None:
+      assert active_counts.dtype == torch.int64 and tuple(active_counts.shape) == (k, COUNT_SLOTS)
+      assert active_counts.is_contiguous()
+    assert self.grid is not None, 'Must call set_grid (reset) before step.'
+    fn, struct = self.lib.ble_step_n_f32, ctypes.byref(self._struct)
+    args = (struct, actions.data_ptr(), self.grid.data_ptr(), self.grid_env_stride, rewards.data_ptr(),
+            terminals.data_ptr(), self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k)
+    device, index = self.device, self.device.index
+
+    def launch():
+      if torch.cuda.current_device() != index:
+        with torch.cuda.device(device):
+          code = fn(*args, dev.stream_ptr(device))
+      else:
+        code = fn(*args, dev.stream_ptr(device))
+      if code != 0:
+        _lib.check(code, 'ble_step_n_f32')
+    return launch
+
   @property
   def active_count(self) -> torch.Tensor:
     """Total number of envs stepped so far (sum of the counter slots), a 0-d device tensor."""

@@ -607,6 +607,17 @@ def test_fused_rollout_equals_single_steps(ble):
   live_per_step = cnt.sum(dim=1).cpu().numpy()
   expect = np.concatenate([[n], n - torch.stack(tb).cpu().numpy()[:-1].sum(axis=1)])
   np.testing.assert_array_equal(live_per_step, expect)
+  # the prepared launch (checks and argument marshalling done once) enqueues the same work
+  c = ble.VecSimulator(n); c.set_state(init); c.set_grid(field)
+  rew_c = torch.zeros_like(rew); term_c = torch.zeros_like(term)
+  launch = c.prepare_step_n(acts, rew_c, term_c)
+  launch()
+  torch.cuda.synchronize()
+  sc = c.get_state()
+  for name in sa:
+    np.testing.assert_array_equal(sa[name], sc[name], err_msg=name)
+  np.testing.assert_array_equal(rew.cpu().numpy(), rew_c.cpu().numpy())
+  np.testing.assert_array_equal(term.cpu().numpy(), term_c.cpu().numpy())
 
 
 # ---------------------------------------------------------------- device reset
