@@ -487,3 +487,18 @@ def test_irregular_history_carried_equals_refit_at_occupancy(vec_state):
     worst = max(worst, float(d.max()))
     assert float(d.max()) <= 2e-4 and float((d.amax(dim=1) > 1e-5).double().mean()) <= 1e-3, (i, float(d.max()))
   print(f'irregular history at 16384 envs, carried vs refitted: {len(a)} compared steps, worst |diff| {worst:.3g}')
+
+
+def test_long_flight_at_full_size_carried_equals_refit(vec_state):
+  """profiles/soak_observe.py as a test: 1 200 agent steps (60 h of flight: five window lengths, the 48 h boomerang of the
+  wind field's time axis) of 65 536 environments with skipped observations, feature reads without an append and new
+  episodes for terminated environments, carried factor against a refit at every call -- every live environment of every
+  25th step within the parity bar, no error flag."""
+  import subprocess, sys, os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, 'profiles', 'soak_observe.py'), '65536', '1200', '25'],
+                     cwd=root, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+  line = [l for l in r.stdout.splitlines() if l.startswith('soak:')][-1]
+  print(line)
+  assert 'beyond 1e-5: 0 ' in line
