@@ -3,7 +3,9 @@ vs a refit at every call -- over `steps` agent steps of `n` environments with ra
 observations, feature reads without an append, and immediate new episodes for the terminated environments.  Every `every`
 steps ALL environments are compared; error flags are checked at the end.
 
-  python profiles/soak_observe.py [n=65536] [steps=1500] [every=25]
+  python profiles/soak_observe.py [n=65536] [steps=1500] [every=25] [drain=0]
+`drain` > 0: every 37th step the batteries of that fraction of the environments are emptied (they run out of power and
+start new episodes: the reset path of the history ring and of the carried factor under load).
 """
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
@@ -13,6 +15,7 @@ def main():
   n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
   steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
   every = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+  drain = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
   rng = np.random.default_rng(5)
   field = torch.from_numpy((rng.standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)).cuda()
   sims = []
@@ -26,6 +29,9 @@ def main():
   for i in range(steps):
     act = torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda', generator=gen)
     noise = torch.randn((n, 2), dtype=torch.float32, device='cuda', generator=gen)
+    if drain > 0 and i % 37 == 36:
+      sel = torch.rand(n, device='cuda', generator=gen) < drain
+      for s in sims: s.state['battery_charge'][sel] = 0.01
     for s in sims: s.step(act)
     # a terminated environment starts a new episode at once (same seeds on both sides): left frozen, its repeated
     # observations at one time stamp would overflow the 6 h window -- the kernel reports that, rightly
