@@ -44,4 +44,5 @@ class BleGpHistoryF32(ctypes.Structure):
   """struct ble_gp_history_f32."""
   _fields_ = [('xyp', ctypes.POINTER(ctypes.c_float)), ('elapsed_s', ctypes.POINTER(ctypes.c_int32)),
               ('err_uv', ctypes.POINTER(ctypes.c_float)), ('count', ctypes.POINTER(ctypes.c_int32)),
-              ('chol', ctypes.POINTER(ctypes.c_double)), ('n_chol', ctypes.POINTER(ctypes.c_int32))]
+              ('chol', ctypes.POINTER(ctypes.c_double)), ('n_chol', ctypes.POINTER(ctypes.c_int32)),
+              ('chol_stride', ctypes.c_int64)]

@@ -22,7 +22,7 @@ _SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_
                                                           'ble_observe.h', 'ble_noise.h', 'ble_decode.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH = 64, 128

@@ -18,6 +18,18 @@
 
 using namespace ble;
 
+// Instrumentation hooks of ble_step_kernel: empty in the product build.  A profiling build
+// (profiles/build_variant.sh ... -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
+// marks from that header, which is not part of the package.
+#ifdef BLE_STEP_INSTR_HEADER
+#include BLE_STEP_INSTR_HEADER
+#else
+#define BLE_STEP_INSTR_BEGIN() do {} while (0)
+#define BLE_STEP_MARK(i) do {} while (0)
+#define BLE_STEP_INSTR_END() do {} while (0)
+#define BLE_STEP_COUNTS_LIVE 1
+#endif
+
 namespace {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
@@ -55,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   EnvRegs s;
   EnvConst c;
   bool live = false;
+  BLE_STEP_INSTR_BEGIN();
   if (in_range) {
     // every load is issued up front, unconditionally (one memory round trip)
     s.status = st.status[i];
@@ -69,12 +82,15 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     live = s.status == kOk;
   }
   // (the ACS table's piecewise cubics are built while the state loads above are in flight)
+  BLE_STEP_MARK(1);
   if (threadIdx.x < 12) acs_build_poly(kAcsEfficiency, (int)threadIdx.x, acs_poly + 6 * threadIdx.x);
   __syncthreads();
+  BLE_STEP_MARK(2);
   const bool was_live = live;
   int last_act = 0;
   EnvHoisted hc;
   if (live) hc = hoist_constants(c);
+  BLE_STEP_MARK(3);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
     const int64_t o = (int64_t)k * n + i;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     }
     // live-environment count: one atomic per wave, spread over BLE_COUNT_SLOTS addresses and
     // issued after the step so that no load of this wave queues behind it
-    if (active_count) {
+    if (BLE_STEP_COUNTS_LIVE && active_count) {
       const unsigned long long m = __ballot(live);
       if ((threadIdx.x & 63) == 0 && m)
         atomicAdd(active_count + (int64_t)k * BLE_COUNT_SLOTS + (blockIdx.x & (BLE_COUNT_SLOTS - 1)),
@@ -109,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     }
     live = live && s.status == kOk;
   }
+  BLE_STEP_MARK(4);
   if (was_live) {
     st.x[i] = s.x; st.y[i] = s.y; st.pressure[i] = s.p; st.ambient_temperature[i] = s.t_amb;
     st.internal_temperature[i] = s.t_int; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp;
@@ -119,6 +136,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     st.status[i] = s.status; st.last_command[i] = (uint8_t)last_act;
     st.alt_fsm[i] = s.alt_fsm; st.env_fsm[i] = s.env_fsm; st.power_paused[i] = s.paused;
   }
+  BLE_STEP_INSTR_END();
   report_flags(flags, err_flags);
 }
 
@@ -130,10 +148,11 @@ __global__ __launch_bounds__(256) void ble_forecast_kernel(const float* __restri
                                                            float* __restrict__ v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const WindQuery wq = wind_query(x[i], y[i], pressure[i], elapsed[i]);
-  float uu, vv;
-  wind_blend(wind_grid + i * grid_env_stride, wq, &uu, &vv);
-  u[i] = uu; v[i] = vv;
+  // float32 query, fp64 interpolation like scipy's interpn; the float32 result is the correctly rounded reference value
+  // (the transition's own, fused lookup blends in fp32: wind_blend_corners)
+  double uu, vv;
+  wind_forecast_f64(wind_grid + i * grid_env_stride, x[i], y[i], pressure[i], elapsed[i], &uu, &vv);
+  u[i] = (float)uu; v[i] = (float)vv;
 }
 
 // get_forecast_column (grid_based_wind_field.py:96-132): one wave per column.  The wave
@@ -144,35 +163,36 @@ __global__ __launch_bounds__(kBlock) void ble_forecast_column_kernel(
     const float* __restrict__ wind_grid, int64_t grid_env_stride, const float* __restrict__ x,
     const float* __restrict__ y, const int32_t* __restrict__ elapsed, const float* __restrict__ levels,
     int n_levels, float* __restrict__ out_uv, int64_t n) {
-  __shared__ float column[BLE_GRID_NP * 2];
+  __shared__ double column[BLE_GRID_NP * 2];
   const int64_t env = blockIdx.x;
   if (env >= n) return;
   const int lane = threadIdx.x;
-  const WindQuery wq = wind_query(x[env], y[env], 5000.0f, elapsed[env]);
+  const WindQueryD wq = wind_query_xyt_f64(x[env], y[env], elapsed[env]);
   const float* grid = wind_grid + env * grid_env_stride;
   if (lane < BLE_GRID_NP * 2) {
     const int ip = lane >> 1, comp = lane & 1;
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
-          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
+          const double w = ((a ? wq.wx : 1.0 - wq.wx) * (b ? wq.wy : 1.0 - wq.wy)) * (d ? wq.wt : 1.0 - wq.wt);
+          acc = d_fma((double)grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
         }
     column[lane] = acc;
   }
   __syncthreads();
   for (int l = lane; l < n_levels; l += kBlock) {
     const float p = f_clamp(levels[l], 5000.0f, 14000.0f);
-    int ip; float wp;
-    wind_axis(p, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
-    const float u = f_fma(wp, column[(ip + 1) * 2] - column[ip * 2], column[ip * 2]);
-    const float v = f_fma(wp, column[(ip + 1) * 2 + 1] - column[ip * 2 + 1], column[ip * 2 + 1]);
-    out_uv[(env * n_levels + l) * 2] = u;
-    out_uv[(env * n_levels + l) * 2 + 1] = v;
+    int ip = (int)((p - 5000.0f) * (1.0f / 1000.0f));
+    ip = ip > 8 ? 8 : ip;
+    const double wp = ((double)p - (5000.0 + 1000.0 * (double)ip)) * 1e-3;
+    const double u = d_fma(wp, column[(ip + 1) * 2] - column[ip * 2], column[ip * 2]);
+    const double v = d_fma(wp, column[(ip + 1) * 2 + 1] - column[ip * 2 + 1], column[ip * 2 + 1]);
+    out_uv[(env * n_levels + l) * 2] = (float)u;
+    out_uv[(env * n_levels + l) * 2 + 1] = (float)v;
   }
 }
 
@@ -503,8 +523,10 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
   if (n == 0) return BLE_OK;
   GpHistory h;
   h.xyp = hist->xyp; h.elapsed_s = hist->elapsed_s; h.err_uv = hist->err_uv; h.count = hist->count;
-  h.chol = hist->chol; h.n_chol = hist->n_chol;
-  if (h.chol != nullptr && h.n_chol == nullptr) return BLE_E_INVALID_ARG;
+  h.chol = hist->chol; h.n_chol = hist->n_chol; h.chol_stride = hist->chol_stride;
+  // a slab shorter than the kernel's layout would be overrun (and overlap the next environment's)
+  if (h.chol != nullptr && (h.n_chol == nullptr || h.chol_stride < (int64_t)kCholStride || (h.chol_stride & 1) != 0))
+    return BLE_E_INVALID_ARG;
   BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, *st, wind_grid,
              grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
   return launch_status();

@@ -34,6 +34,26 @@
 
 #include "ble_reset.h"
 
+// Instrumentation hooks.  The product build defines them empty; profiling builds (profiles/build_variant.sh:
+// -DBLE_OBS_INSTR_HEADER='"../../profiles/instr/ble_observe_instr.h"' plus -DBLE_OBS_TIMING / -DBLE_OBS_SOLO /
+// -DBLE_OBS_PHASE_PROFILE) take their definitions -- in-kernel cycle marks, one-workgroup-per-CU padding, early
+// returns after a phase -- from that header, which is not part of the package.
+#ifdef BLE_OBS_INSTR_HEADER
+#include BLE_OBS_INSTR_HEADER
+#else
+#define BLE_OBS_INSTR_SHARED
+#define BLE_OBS_INSTR_BEGIN() do {} while (0)
+#define BLE_OBS_INSTR_END() do {} while (0)
+#define BLE_MARK() do {} while (0)
+#define BLE_SUB(i) do {} while (0)
+#define BLE_SW(i) do {} while (0)
+#define BLE_BLK(i) do {} while (0)
+#define BLE_STOP(k) do {} while (0)
+#define BLE_ROLE_ENTRY_DONE() do {} while (0)
+#define BLE_ROLE_BEGIN() do {} while (0)
+#define BLE_ROLE_END() do {} while (0)
+#endif
+
 namespace ble {
 
 constexpr int kObsLevels = 181;
@@ -60,6 +80,7 @@ struct GpHistory {
   int32_t* count;      // [n]
   double* chol;        // [n][kCholStride] packed Cholesky factor of the current window, or nullptr
   int32_t* n_chol;     // [n] rows of `chol` that are valid (the window it was computed for ends at `count`)
+  int64_t chol_stride; // doubles between consecutive environments' slabs (>= kCholStride, checked by the host entry point)
 };
 
 struct ObsShared {
@@ -90,10 +111,10 @@ struct ObsShared {
   double lev[20], pot[20];
   double el_now, flux_now, el_next, p_floor;
   int lo_idx, hi_idx;                    // first / last reachable level of the 181
-  float column[20];
+  double column[20];                     // the (x, y, t)-blended forecast at the 10 pressure nodes, (u, v) interleaved
   int n_obs;
   int range_ok;
-  float role_t[4], sw1[5], role_t0[4], blk1[8];
+  BLE_OBS_INSTR_SHARED
 };
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
@@ -312,34 +333,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
                                                                 int append, float* __restrict__ obs,
                                                                 uint32_t* err_flags, int64_t n) {
   __shared__ ObsShared sh;
-#ifdef BLE_OBS_SOLO
-  __shared__ double solo_pad[9000];          // timing experiments: one workgroup per CU
-  if (threadIdx.x == 0 && n < 0) solo_pad[obs != nullptr] = 1.0;
-  if (n < 0) obs[0] = (float)solo_pad[1];
-#endif
-#ifdef BLE_OBS_TIMING
-  long long tmark[12]; int nmark = 0;
-  long long tsub[5] = {0, 0, 0, 0, 0};
-  long long tsw[6] = {0, 0, 0, 0, 0, 0};
-  long long tblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define BLE_SW(i) do { tsw[i] = (long long)__builtin_readcyclecounter(); } while (0)
-#define BLE_MARK() do { tmark[nmark++] = (long long)__builtin_readcyclecounter(); } while (0)
-#define BLE_SUB(i) do { tsub[i] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define BLE_MARK() do {} while (0)
-#define BLE_SUB(i) do {} while (0)
-#define BLE_SW(i) do {} while (0)
-#endif
+  BLE_OBS_INSTR_BEGIN();        // (profiling builds only; nothing in the product build)
   BLE_MARK();
-#ifdef BLE_OBS_PHASE_PROFILE
-  // profiles/obs_phases.py: `append` carries a stop code in bits 8.. -- the launch returns after that phase, so
-  // that per-phase instruction counts are differences of PMC runs (nothing is committed: count and factor stay)
-  const int stop_after = append >> 8;
-  append &= 1;
-#define BLE_STOP(k) do { if (stop_after == (k)) return; } while (0)
-#else
-#define BLE_STOP(k) do {} while (0)
-#endif
   // The phases before the sweep are latency-bound chains on few lanes; the sweep of the other resident workgroup
   // is throughput work.  Priority 1 here, 0 from the sweep on: -3 % per launch (measured).
   __builtin_amdgcn_s_setprio(1);
@@ -378,7 +373,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   const int count0 = count;
   // The stored factor (58 KB of the 61 KB slab) is requested now, 16 B per lane and 15 loads in flight, and lands in
   // LDS after the solar table has been computed: its HBM latency hides behind phase 0b.
-  double* chol_g = hist.chol != nullptr ? hist.chol + env * kCholStride : nullptr;
+  double* chol_g = hist.chol != nullptr ? hist.chol + env * hist.chol_stride : nullptr;
   const int chol_pairs = (tri(n_chol0 <= kGpMax ? n_chol0 : 0) + 1) >> 1;
   double2 chol_pre[kCholPrefetch];
 #pragma unroll
@@ -450,19 +445,21 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     sh.lev[lane] = level; sh.pot[lane] = level / t;
   }
   if (wave == 2 && lane < 20) {
-    // get_forecast_column: blend (x, y, t) first, pressure afterwards (grid_based_wind_field.py:96-132)
-    const WindQuery wq = wind_query(xf, yf, 5000.0f, elapsed);
+    // get_forecast_column: blend (x, y, t) first, pressure afterwards (grid_based_wind_field.py:96-132), in fp64 from
+    // the float32-packed query like scipy's interpn (the bearing feature is an arccos of this wind: an fp32 blend,
+    // 1e-6 m/s off, moved it by up to 2e-4 where the wind points at or away from the station)
+    const WindQueryD wq = wind_query_xyt_f64(xf, yf, elapsed);
     const float* grid = wind_grid + env * grid_env_stride;
     const int ip = lane >> 1, comp = lane & 1;
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const float w = (a ? wq.wx : 1.0f - wq.wx) * (b ? wq.wy : 1.0f - wq.wy) * (d ? wq.wt : 1.0f - wq.wt);
-          acc = f_fma(grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
+          const double w = ((a ? wq.wx : 1.0 - wq.wx) * (b ? wq.wy : 1.0 - wq.wy)) * (d ? wq.wt : 1.0 - wq.wt);
+          acc = d_fma((double)grid[((((wq.ix + a) * 21 + (wq.iy + b)) * 10 + ip) * 9 + (wq.it + d)) * 2 + comp], w, acc);
         }
     sh.column[lane] = acc;
   }
@@ -503,9 +500,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     unix_day_fraction(now, &jc, &frac);
     sh.flux_now = solar_flux_f64(jc);
   }
-#ifdef BLE_OBS_TIMING
-  if ((tid & 63) == 0) sh.role_t0[tid >> 6] = (float)((long long)__builtin_readcyclecounter() - tmark[0]);
-#endif
+  BLE_ROLE_ENTRY_DONE();
   __syncthreads();
   BLE_SUB(1);        // ephemeris nodes + site ready
   site.sin_lat = sh.site[0]; site.cos_lat = sh.site[1]; site.lng_deg = sh.site[2];
@@ -618,9 +613,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 
   // ---- phase 1: four roles
   double dnew_keep = 0.0;            // new diagonal entry of the row a drop lane owns (written after B3)
-#ifdef BLE_OBS_TIMING
-  const long long role_t0 = (long long)__builtin_readcyclecounter();
-#endif
+  BLE_ROLE_BEGIN();
   if (wave == 0) {
     // -- ambient features (features.py:400-470).  solar.get_next_sunrise_sunset (solar.py:432-483) is two
     //    pairs of independent searches -- (noon, midnight), then (sunrise, sunset): each pair runs on lanes
@@ -856,10 +849,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       sh.z[0][kGpRows - 1] = 0.0; sh.z[1][kGpRows - 1] = 0.0; sh.loc[kGpRows - 1][2] = 0.0; sh.a[kGpRows - 1] = 0.0; sh.inv_diag[kGpRows - 1] = 0.0;
     }
   }
-#ifdef BLE_OBS_TIMING
-  if ((tid & 63) == 0)
-    sh.role_t[tid >> 6] = (float)((long long)__builtin_readcyclecounter() - role_t0);
-#endif
+  BLE_ROLE_END();
   __syncthreads();   // B3  (el_table is dead from here on: V may be overwritten)
   BLE_MARK();
   BLE_STOP(2);
@@ -1177,9 +1167,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           else { dstep(C3{}, T{}); }
         }
       }
-#ifdef BLE_OBS_TIMING
-      if (kFirst) tblk[I] = (long long)__builtin_readcyclecounter();
-#endif
+      BLE_BLK(I);
     }
     BLE_SW(0);       // core done (this wave)
     __builtin_amdgcn_s_setprio(1);      // what follows are short dependent chains again (-1.5 %)
@@ -1298,11 +1286,12 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         const double ss = d_fma(val_last * val_last, inv_dn, ssq_m);
         const double mu = d_fma(val_last, zl_u, mean_u_m), mv = d_fma(val_last, zl_v, mean_v_m);
         // forecast at this level from the blended column
-        int ip; float wp;
-        wind_axis((float)level_m, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &ip, &wp);
-        const float fu = f_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
-        const float fv = f_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
-        const double u = mu + (double)fu, v = mv + (double)fv;
+        int ip = (int)((level_m - 5000.0) * 1e-3);
+        ip = ip > 8 ? 8 : ip;
+        const double wp = (level_m - (5000.0 + 1000.0 * (double)ip)) * 1e-3;
+        const double fu = d_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
+        const double fv = d_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
+        const double u = mu + fu, v = mv + fv;
         double var = kGpSigma2 - ss;
         var = var < 0.0 ? 0.0 : var;
         // (reciprocal + Newton instead of the ~30-instruction fp64 division / sqrt sequences: 2e-15 relative)
@@ -1337,23 +1326,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       o[0] = 0.0f; o[1] = 1.0f; o[2] = 1.0f;
     }
   }
-#ifdef BLE_OBS_TIMING
   BLE_SW(4);         // padding written
-  if (tid == 64) { for (int k = 0; k < 5; ++k) sh.sw1[k] = (float)(tsw[k] - tmark[5]); for (int k = 0; k < 8; ++k) sh.blk1[k] = (float)(tblk[k] - tmark[5]); }
-  __syncthreads();
-  BLE_MARK();
-  if (tid == 0)
-  {
-    for (int k = 0; k < 5; ++k) { out[kObsDim - 34 + k] = (float)(tsw[k] - tmark[5]); out[kObsDim - 29 + k] = sh.sw1[k]; }
-    for (int k = 1; k < nmark; ++k) out[kObsDim - 12 + k] = (float)(tmark[k] - tmark[k - 1]);
-    for (int k = 0; k < 3; ++k) out[kObsDim - 16 + k] = sh.role_t[k];
-    out[kObsDim - 13] = sh.role_t[3];
-    for (int k = 0; k < 4; ++k) out[kObsDim - 38 + k] = sh.role_t0[k];
-    for (int k = 0; k < 8; ++k) out[kObsDim - 46 + k] = sh.blk1[k];
-    for (int k = 0; k < 4; ++k) out[kObsDim - 20 + k] = (float)(tsub[k] - tmark[0]);
-    out[kObsDim - 4] = (float)n_tiles; out[kObsDim - 3] = (float)n_reach; out[kObsDim - 2] = (float)(n_tiles > 8);
-  }
-#endif
+  BLE_OBS_INSTR_END();
   // the factor of this window goes back to HBM for the next call
   __syncthreads();                                 // the bordering row is in LDS
   if (chol_g != nullptr) {

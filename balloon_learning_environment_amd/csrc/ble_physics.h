@@ -525,28 +525,70 @@ BLE_FN void wind_axis(float q, float g0, float inv_step, float step, int n, int*
   *idx = i;
   *w = (q - f_fma((float)i, step, g0)) * inv_step;
 }
+// float32 time coordinate of a query [h] (grid_based_wind_field.py:164-181: boomerang beyond 48 h, then float32)
+BLE_FN float wind_time_coord(int32_t elapsed_s) {
+  if (elapsed_s < 48 * 3600) return (float)elapsed_s / 3600.0f;
+  // _boomerang(t, 48): fp64 like the reference, then float32
+  double t = (double)elapsed_s / 3600.0;
+  long long cyc = (long long)(t / 48.0);
+  double rem = t - 48.0 * (double)cyc;   // exact for these magnitudes
+  if (rem < 0.0) rem += 48.0;
+  if (rem >= 48.0) rem -= 48.0;
+  return (float)((cyc & 1) ? 48.0 - rem : rem);
+}
 BLE_FN WindQuery wind_query(float x_m, float y_m, float pressure, int32_t elapsed_s) {
   WindQuery wq;
   // x.kilometers -> clip -> float32 (correctly rounded fp32 division == fp64 division then cast)
   float x_km = f_clamp(x_m / 1000.0f, -500.0f, 500.0f);
   float y_km = f_clamp(y_m / 1000.0f, -500.0f, 500.0f);
   float p = f_clamp(pressure, 5000.0f, 14000.0f);
-  float t_h;
-  if (elapsed_s < 48 * 3600) {
-    t_h = (float)elapsed_s / 3600.0f;
-  } else {  // _boomerang(t, 48): fp64 like the reference, then float32
-    double t = (double)elapsed_s / 3600.0;
-    long long cyc = (long long)(t / 48.0);
-    double rem = t - 48.0 * (double)cyc;   // exact for these magnitudes
-    if (rem < 0.0) rem += 48.0;
-    if (rem >= 48.0) rem -= 48.0;
-    t_h = (float)((cyc & 1) ? 48.0 - rem : rem);
-  }
+  const float t_h = wind_time_coord(elapsed_s);
   wind_axis(x_km, -500.0f, 1.0f / 50.0f, 50.0f, 21, &wq.ix, &wq.wx);
   wind_axis(y_km, -500.0f, 1.0f / 50.0f, 50.0f, 21, &wq.iy, &wq.wy);
   wind_axis(p, 5000.0f, 1.0f / 1000.0f, 1000.0f, 10, &wq.ip, &wq.wp);
   wind_axis(t_h, 0.0f, 1.0f / 6.0f, 6.0f, 9, &wq.it, &wq.wt);
   return wq;
+}
+// The same query with fp64 interpolation weights, as scipy's interpn forms them: the query point is packed as
+// float32 (grid_based_wind_field.py:181) and everything after it -- (q - grid[i]) / (grid[i+1] - grid[i]), the weight
+// products, the accumulation -- is fp64.  Used by the observation's forecast column, whose bearing feature puts the
+// blended wind through an arccos (the transition's own lookup stays fp32: it feeds a 180 s displacement).
+struct WindQueryD { int ix, iy, it; double wx, wy, wt; };
+BLE_FN WindQueryD wind_query_xyt_f64(float x_m, float y_m, int32_t elapsed_s) {
+  const WindQuery q = wind_query(x_m, y_m, 5000.0f, elapsed_s);
+  const float x_km = f_clamp(x_m / 1000.0f, -500.0f, 500.0f), y_km = f_clamp(y_m / 1000.0f, -500.0f, 500.0f);
+  const float t_h = wind_time_coord(elapsed_s);
+  WindQueryD d;
+  d.ix = q.ix; d.iy = q.iy; d.it = q.it;
+  d.wx = ((double)x_km - (-500.0 + 50.0 * (double)q.ix)) * (1.0 / 50.0);
+  d.wy = ((double)y_km - (-500.0 + 50.0 * (double)q.iy)) * (1.0 / 50.0);
+  d.wt = ((double)t_h - 6.0 * (double)q.it) * (1.0 / 6.0);
+  return d;
+}
+// One get_forecast lookup the way the reference evaluates it (float32 query, fp64 interpolation): the standalone
+// forecast entry points (ble_forecast_f32, ble_forecast_column_f32) and the observation use this form; the result is
+// within an ulp of fp64 of scipy's interpn.
+BLE_FN void wind_forecast_f64(const float* __restrict__ grid, float x_m, float y_m, float pressure, int32_t elapsed_s,
+                              double* u, double* v) {
+  const WindQueryD q = wind_query_xyt_f64(x_m, y_m, elapsed_s);
+  const float pc = f_clamp(pressure, 5000.0f, 14000.0f);
+  int ip = (int)((pc - 5000.0f) * (1.0f / 1000.0f));
+  ip = ip > 8 ? 8 : ip;
+  const double wp = ((double)pc - (5000.0 + 1000.0 * (double)ip)) * 1e-3;
+  double au = 0.0, av = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float* cell = grid + ((((q.ix + a) * 21 + (q.iy + b)) * 10 + (ip + c)) * 9 + q.it) * 2;
+        const double w3 = ((a ? q.wx : 1.0 - q.wx) * (b ? q.wy : 1.0 - q.wy)) * (c ? wp : 1.0 - wp);
+        const double w0 = w3 * (1.0 - q.wt), w1 = w3 * q.wt;
+        au = d_fma((double)cell[0], w0, au); av = d_fma((double)cell[1], w0, av);
+        au = d_fma((double)cell[2], w1, au); av = d_fma((double)cell[3], w1, av);
+      }
+  *u = au; *v = av;
 }
 // 16-corner gather + blend.  Each (x, y, p) corner is 4 contiguous floats (t, t+1) x (u, v):
 // 8 x 16 B per query.  The gather is split from the blend so that the kernel can issue the

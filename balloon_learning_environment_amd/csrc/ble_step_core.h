@@ -5,14 +5,16 @@
 // perciatelli_reward_function (env/balloon_env.py:44-102).  Called by the HIP kernel in
 // ble_kernels.hip with one lane per environment; also compiled on the host by tests/emul.
 //
-// Precision map.  The reference's vertical dynamics are an UNSTABLE map near float
+// Precision map (DESIGN.md section 5).  The reference's vertical dynamics are an UNSTABLE map near float
 // equilibrium: dh/dt = +-sqrt(|rho V - m| ...) has unbounded gain where rho V - m -> 0 and
 // |gain| ~ 1.5-3 per 10 s substep in the quasi-steady regime, so a 1e-7 relative error in
-// anything that feeds rho V - m (p, T_amb(p), V(n_air, T_int, p)) grows to O(1 Pa) within
-// one agent step.  That chain -- p, T_amb, T_int, n_air, V, superpressure and the
-// difference itself -- is therefore carried in fp64 registers across the 18 substeps
-// (inputs and outputs stay fp32).  Everything that only produces *increments* (thermal
-// model, ACS, solar geometry and power, dH series, drag) is fp32.
+// anything that feeds rho V - m (p, T_amb(p), V(n_air, T_int, p), the thermal and ACS increments)
+// grows to O(1 Pa) within one agent step.  That chain -- p, T_amb, T_int, n_air, V, superpressure,
+// the difference itself, dh/dt, 1/dH, the thermal increment (thermal_increment_f64) and the ACS mass
+// flow (acs_down_poly / the valve formula) -- is carried in fp64 registers across the 18 substeps
+// (inputs and outputs stay fp32).  fp64 too: the three solar nodes of a step, the safety layers'
+// comparisons.  fp32: the wind blend, refraction, attenuation, panel power, battery, reward -- they feed
+// nothing that is amplified.
 #pragma once
 #include "ble_physics.h"
 
@@ -227,10 +229,13 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (terminal) { ++k; break; }          // balloon.py:327-328
   }
-  // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments)
-  if (sp > 2380.0) status = kBurst;
-  if (k > 0 && sp <= 0.0) status = kZeroPressure;
-  if (k > 0 && batt <= 0.0f) status = kOutOfPower;
+  // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments;
+  // k >= 1 here: substeps >= 1 is checked by the host entry point).  The burst test is the loop's own
+  // `!(sp_new <= 2380)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
+  // frozen for the remaining steps of a fused launch instead of stepping on NaN state.
+  if (!(sp <= 2380.0)) status = kBurst;
+  if (sp <= 0.0) status = kZeroPressure;
+  if (batt <= 0.0f) status = kOutOfPower;
 
   s.x = x; s.y = y; s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
   s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;

@@ -22,6 +22,21 @@ def require_gpu(device) -> torch.device:
   return device
 
 
+def on_own_device(method):
+  """Decorator for methods of objects with a `.device`: launches go to the stream of the object's OWN device, so that
+  device is made current for the call (a kernel launched while another device is current would be enqueued with the
+  wrong context).  No-op -- one integer compare -- when it already is."""
+  import functools
+
+  @functools.wraps(method)
+  def wrapped(self, *args, **kwargs):
+    if torch.cuda.current_device() == self.device.index:
+      return method(self, *args, **kwargs)
+    with torch.cuda.device(self.device):
+      return method(self, *args, **kwargs)
+  return wrapped
+
+
 def stream_ptr(device) -> int:
   return torch.cuda.current_stream(device).cuda_stream
 

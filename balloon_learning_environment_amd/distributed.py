@@ -65,34 +65,55 @@ class OutputGatherer:
     self.rank = dist.get_rank() if initialized else 0
     self.dst = dst
     self.is_dst = self.rank == dst
+    self.k = k
     rows = self.world if self.is_dst else 0
     self.reward = torch.zeros((rows, k, n_local), dtype=torch.float32, device=device)
     self.terminal = torch.zeros((rows, k, n_local), dtype=torch.uint8, device=device)
     self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+    self.gathers = 0            # exchanges issued by this rank
+    self.rows_gathered = 0      # agent steps they carried
 
-  def _gather(self, reward_block, terminal_block):
+  def _gather(self, reward_block, terminal_block, c):
     if self.is_dst:
-      dist.gather(reward_block, [self.reward[r] for r in range(self.world)], dst=self.dst)
-      dist.gather(terminal_block, [self.terminal[r] for r in range(self.world)], dst=self.dst)
+      dist.gather(reward_block, [self.reward[r][:c] for r in range(self.world)], dst=self.dst)
+      dist.gather(terminal_block, [self.terminal[r][:c] for r in range(self.world)], dst=self.dst)
     else:
       dist.gather(reward_block, None, dst=self.dst)
       dist.gather(terminal_block, None, dst=self.dst)
 
   def gather(self, reward_block: torch.Tensor, terminal_block: torch.Tensor) -> None:
+    """`reward_block`, `terminal_block`: [c, n_local] with c <= k (a region's last launch may hold fewer steps than
+    the others: its rows are gathered too); rank `dst` finds them in reward[r][:c], terminal[r][:c]."""
+    c = int(reward_block.shape[0])
+    assert 0 < c <= self.k and tuple(terminal_block.shape) == tuple(reward_block.shape)
+    self.gathers += 1; self.rows_gathered += c
     if self.world == 1:
-      self.reward[0].copy_(reward_block); self.terminal[0].copy_(terminal_block)
+      self.reward[0][:c].copy_(reward_block); self.terminal[0][:c].copy_(terminal_block)
       return
     if self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream(reward_block.device))
       with torch.cuda.stream(self.stream):
-        self._gather(reward_block, terminal_block)
+        self._gather(reward_block, terminal_block, c)
         reward_block.record_stream(self.stream); terminal_block.record_stream(self.stream)
     else:
-      self._gather(reward_block, terminal_block)
+      self._gather(reward_block, terminal_block, c)
 
   def wait(self) -> None:
     if self.stream is not None:
       torch.cuda.current_stream(self.reward.device).wait_stream(self.stream)
+
+
+def run_region(launches, gatherer: Optional['OutputGatherer']) -> None:
+  """One region of a sharded rollout: every launch (a callable that enqueues <= k agent steps of this rank's shard and
+  fills its [c, n_local] reward / terminal blocks) is followed by the gather of exactly those blocks to the learner
+  rank -- the last, shorter launch of a region included -- and the region ends when the exchanges have been waited for.
+  `launches`: iterable of (launch, reward_block, terminal_block).  bench.py's timed region and the gloo tests run this."""
+  for launch, reward_block, terminal_block in launches:
+    launch()
+    if gatherer is not None:
+      gatherer.gather(reward_block, terminal_block)
+  if gatherer is not None:
+    gatherer.wait()
 
 
 class ObservationGatherer:
@@ -144,3 +165,53 @@ def sum_over_ranks(value: float, device) -> float:
   t = torch.tensor([value], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.SUM)
   return float(t.item())
+
+
+def joined_ranks(device) -> int:
+  """How many ranks actually take part in this job (an all-reduce of ones; 1 without a process group)."""
+  return int(round(sum_over_ranks(1.0, device)))
+
+
+def spawn_local_ranks(argv: List[str], n: int, env_extra: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+  """Runs `argv` as n processes of ONE node, one rank per process, with the environment torch.distributed.run would
+  set (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port).  Rank 0
+  inherits stdout (it prints the result line); the other ranks' stdout goes to stderr.  Returns 0 if every rank
+  exited with 0; if one fails the others are terminated (by PID) and its code is returned."""
+  import os
+  import socket
+  import subprocess
+  import sys
+  import time
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  procs = []
+  for rank in range(n):
+    env = dict(os.environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if env_extra:
+      env.update(env_extra)
+    procs.append(subprocess.Popen(argv, env=env, stdout=None if rank == 0 else sys.stderr))
+  deadline = None if timeout is None else time.monotonic() + timeout
+  code = 0
+  pending = list(procs)
+  while pending:
+    for p in list(pending):
+      rc = p.poll()
+      if rc is not None:
+        pending.remove(p)
+        if rc != 0 and code == 0:
+          code = rc
+    if code != 0 or (deadline is not None and time.monotonic() > deadline):
+      for p in pending:
+        p.terminate()
+      for p in pending:
+        try:
+          p.wait(10)
+        except subprocess.TimeoutExpired:
+          p.kill()
+      return code if code != 0 else -9
+    time.sleep(0.05)
+  return code

@@ -85,6 +85,7 @@ class VecBalloonArena:
       self.sim.reset_device(seed)
     else:
       self.sim.set_state(reset_host.sample_initial_state(self.num_envs, seed=seed, upwelling_ir=upwelling_ir))
+      self.sim.reset_observation_history()     # (reset_device does this itself: a new episode starts a new WindGP window)
     self.wind_field.reset(np.array([seed], np.uint32), None)
     self._field_epoch = 0
     if self.per_env_fields:
@@ -232,7 +233,9 @@ class BalloonArena(BalloonArenaInterface):
     self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
     self._bind_wind_field()
     self.feature_constructor = self._feature_constructor_factory(self._wind_field, self._vec.get_atmosphere())
-    if hasattr(self.feature_constructor, 'bind_state'):       # the device constructor reads this arena's state in place
+    # the device constructor reads this arena's state in place -- unless a subclass edits what the balloon "measures"
+    # (get_measurements overridden, e.g. sensor noise): then the observation object is the only truth
+    if hasattr(self.feature_constructor, 'bind_state') and type(self).get_measurements is BalloonArena.get_measurements:
       self.feature_constructor.bind_state(self._vec.sim)
     self._observe()
     return self.feature_constructor.get_features()

@@ -302,7 +302,21 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     assert getattr(self, '_bound', False)
     self._observe(observation, copy_state=False)
 
+  def _unbind(self) -> None:
+    """Back to a private copy of the state (the WindGP history stays): from here on observe() honours the
+    observation it is handed, like the reference's FeatureConstructor.observe(observation) contract."""
+    import torch
+    from balloon_learning_environment_amd import device as dev
+    self._sim.state = {name: t.clone() for name, t in self._sim.state.items()}
+    self._sim._struct = dev.state_struct(self._sim.state)
+    self._bound = False
+
   def observe(self, observation: simulator_data.SimulatorObservation) -> None:
+    """The reference's public contract (features.py:301-330): the observation handed in is what is observed.
+    A constructor bound to its arena's state (bind_state) that is called from outside -- e.g. with a noisy or
+    edited observation -- gives the alias up first and copies the observation's state like an unbound one."""
+    if getattr(self, '_bound', False):
+      self._unbind()
     self._observe(observation, copy_state=True)
 
   def _observe(self, observation: simulator_data.SimulatorObservation, copy_state: bool) -> None:
@@ -310,7 +324,6 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     from balloon_learning_environment_amd.env.balloon import balloon as balloon_lib
     b = observation.balloon_observation
     if copy_state:
-      assert not getattr(self, '_bound', False), 'a bound constructor observes its arena (observe_bound)'
       row = balloon_lib.row_from_state(b, self._alpha)
       self._sim.set_state({k: np.array([v]) for k, v in row.items()})
     fc = self._forecast.get_forecast(b.x, b.y, b.pressure, b.time_elapsed)

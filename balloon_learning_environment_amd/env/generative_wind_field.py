@@ -53,6 +53,7 @@ class GenerativeWindFieldSampler(grid_wind_field_sampler.GridWindFieldSampler):
   def field_shape(self):
     return self._shape
 
+  @dev.on_own_device
   def flow_fields(self, latents: torch.Tensor) -> torch.Tensor:
     """[n, 64] -> [n, 4410]: the MLP part of Decoder.__call__ (vae.py:145-148)."""
     z = latents.to(self.device, torch.float32)
@@ -62,6 +63,7 @@ class GenerativeWindFieldSampler(grid_wind_field_sampler.GridWindFieldSampler):
         z = torch.relu_(z)
     return z.contiguous()
 
+  @dev.on_own_device
   def decode(self, latents: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[n, 64] latents -> [n, 21, 21, 10, 9, 2] float32 wind grids on the device."""
     n = latents.shape[0]
@@ -77,6 +79,7 @@ class GenerativeWindFieldSampler(grid_wind_field_sampler.GridWindFieldSampler):
       flow.record_stream(torch.cuda.current_stream(self.device))
     return out
 
+  @dev.on_own_device
   def sample_latents(self, n: int, seed: int) -> torch.Tensor:
     gen = torch.Generator(device=self.device); gen.manual_seed(int(seed))
     return torch.randn((n, NUM_LATENTS), dtype=torch.float32, device=self.device, generator=gen)

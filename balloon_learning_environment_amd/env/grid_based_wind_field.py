@@ -29,6 +29,7 @@ class GridBasedWindField(wind_field.WindField):
   def reset_forecast(self, key, date_time: dt.datetime) -> None:
     self.set_field(self._wind_field_sampler.sample_field(key, date_time))
 
+  @dev.on_own_device
   def set_field(self, field) -> None:
     self.field = np.ascontiguousarray(field, np.float32)
     assert self.field.shape == tuple(self.field_shape.grid_shape())
@@ -40,6 +41,7 @@ class GridBasedWindField(wind_field.WindField):
       raise RuntimeError('Must call reset before get_forecast.')
     return self.get_forecast_column(x, y, [pressure], elapsed_time)[0]
 
+  @dev.on_own_device
   def get_forecast_column(self, x, y, pressures: Sequence[float], elapsed_time) -> List[wind_field.WindVector]:
     if self.grid is None:
       raise RuntimeError('Must call reset before get_forecast.')

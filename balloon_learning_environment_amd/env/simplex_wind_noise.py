@@ -26,6 +26,7 @@ class SimplexWindNoise:
   def reset(self, key) -> None:
     self._seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
 
+  @dev.on_own_device
   def get_wind_noise(self, x: units.Distance, y: units.Distance, pressure: float,
                      elapsed_time: dt.timedelta) -> wind_field.WindVector:
     if self._seed is None:

@@ -42,18 +42,7 @@ def raise_for_flags(flags: int) -> None:
     raise OverflowError('WindGP window holds more than 120 observations (agent steps shorter than 180 s)')
 
 
-def _on_own_device(method):
-  """Launches go to the stream of the simulator's OWN device: make it current for the call (a kernel
-  launched while another device is current would be enqueued with the wrong context)."""
-  import functools
-
-  @functools.wraps(method)
-  def wrapped(self, *args, **kwargs):
-    if torch.cuda.current_device() == self.device.index:
-      return method(self, *args, **kwargs)
-    with torch.cuda.device(self.device):
-      return method(self, *args, **kwargs)
-  return wrapped
+_on_own_device = dev.on_own_device
 
 
 class VecSimulator:
@@ -146,6 +135,7 @@ class VecSimulator:
           if name not in self._gp:
             continue
           setattr(self._gp_struct, name, ctypes.cast(ctypes.c_void_p(self._gp[name].data_ptr()), ctypes.POINTER(ct)))
+        self._gp_struct.chol_stride = _lib.GP_CHOL_STRIDE if carry_factor else 0
     if noise_uv is not None:
       assert noise_uv.dtype == torch.float32 and noise_uv.is_contiguous() and tuple(noise_uv.shape) == (self.n, 2)
     if out is None:

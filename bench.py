@@ -5,6 +5,7 @@
   python bench.py --gpus 1 --steps 192 --warmup 32
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W [--config 3|4]
+  python bench.py --gpus N ...                      # no launcher (WORLD_SIZE unset): bench.py starts the N ranks itself
 
 One "step" = one agent step (180 s = 18 x 10 s substeps + wind lookup + 3 safety layers +
 reward/terminal) of every environment of the rank.  The random policy's actions are known up front, so
@@ -12,8 +13,9 @@ ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (st
 
 Presets (`--config i` = BASELINE.json configs[i]; the default, 2, is the headline):
   1  4 096 envs, one decoded wind grid, 1 GPU
-  2  65 536 envs PER GPU, one decoded wind grid (weak scaling when N > 1: grid broadcast once over RCCL,
-     rewards/terminals gathered to rank 0 every 32 steps on a side stream, inside the timed region)
+  2  65 536 envs PER GPU, one decoded wind grid (weak scaling when N > 1: grid broadcast once over RCCL; the reward /
+     terminal rows of EVERY launch -- 32 steps, or fewer for the last launch of a region -- are gathered to rank 0 on a
+     side stream, inside the timed region: `config.exchanges` counts them)
   3  65 536 envs GLOBAL, sharded contiguously over the N ranks (strong scaling), same exchanges
   4  32 768 envs per GPU (262 144 on 8), every env flies in its own forecast decoded on the device by the
      VAE-decoder restatement (synthetic weights); no broadcast
@@ -26,7 +28,15 @@ The wall-clock repetitions launch through argument views built beforehand and ca
 duration (roofline) comes from 9 more, event-bracketed repetitions of the same region.
 Terminated environments are frozen by the kernel and are NOT counted.
 
+`n_gpus` is the number of ranks that actually joined (an all-reduce), and must equal --gpus.
+
 Besides `value`, the default run reports (rank 0; every leg is the same code path as the headline):
+  `policy_in_the_loop`  ONE launch per agent step (ble_step_f32, what an agent loop issues): >= 200 launches, the median
+                 HIP-event time of a launch and the rate of the back-to-back sequence
+  `roofline.traffic`    HBM bytes per launch MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+                 separate passes, kernel trace only) over the headline leg with the same --steps / --warmup, i.e. the
+                 same launch shape; 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md's gfx950 correction).  null (with
+                 `traffic_note`) if rocprofv3 is not on the box or the run is itself being profiled
   `configs`      env-steps/s of configs[1], [3]'s per-GPU shard (8 192 envs; the real sharded run when N > 1)
                  and [4]'s per-GPU share (32 768 envs with per-env grids), and the single-env facade
                  (configs[0]'s counterpart: BalloonEnv.step with the device observation)
@@ -36,10 +46,14 @@ Besides `value`, the default run reports (rank 0; every leg is the same code pat
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
 import json
 import os
+import shutil
 import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -155,23 +169,19 @@ class Rollout:
 
   def plan(self, k0, k1):
     """The launches of steps k0 .. k1 - 1, prepared once (VecSimulator.prepare_step_n: checks and argument marshalling
-    happen here, outside any timed region)."""
+    happen here, outside any timed region): (launch, reward rows, terminal rows) per launch."""
     out = []
     k = k0
     while k < k1:
       c = min(GATHER_EVERY, k1 - k)
       a, r, t = self.actions[k:k + c], self.rewards[k:k + c], self.terminals[k:k + c]
-      out.append((self.sim.prepare_step_n(a, r, t, None, substeps=self.substeps), r, t, c == GATHER_EVERY))
+      out.append((self.sim.prepare_step_n(a, r, t, None, substeps=self.substeps), r, t))
       k += c
     return out
 
   def run(self, k0, k1, plan=None):
-    for launch, r, t, full in (plan if plan is not None else self.plan(k0, k1)):
-      launch()
-      if self.gatherer is not None and full:
-        self.gatherer.gather(r, t)
-    if self.gatherer is not None:
-      self.gatherer.wait()
+    # every launch's rows -- the last, shorter one of a region too -- go to rank 0; the region ends when they have arrived
+    self.bdist.run_region(plan if plan is not None else self.plan(k0, k1), self.gatherer)
 
   def time_reps(self, reps):
     """Warm-up, snapshot, then `reps` x (restore snapshot; barrier+sync; K steps; sync+barrier).
@@ -185,6 +195,7 @@ class Rollout:
     wall, live, ev_ms = [], [], []
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     plan = self.plan(self.warmup, self.warmup + self.steps)
+    g0 = (self.gatherer.gathers, self.gatherer.rows_gathered) if self.gatherer is not None else (0, 0)
     # The wall-clock repetitions carry no event records (two records cost ~10 us of host time per region: 2.4 % of a
     # 20-step region); the kernel's own duration comes from separate, event-bracketed repetitions of the same region.
     n_ev = min(reps, 9)
@@ -210,6 +221,13 @@ class Rollout:
       live.append(self.bdist.sum_over_ranks(l, self.device))
     self.sim.check_errors()
     self.live_fraction_end = float((self.sim.state['status'] == 0).sum().item()) / max(1, self.n)
+    regions = reps + n_ev
+    if self.gatherer is not None:      # counted, not assumed: exchanges and agent-step rows per timed region
+      self.gathers_per_region = (self.gatherer.gathers - g0[0]) / regions
+      self.rows_gathered_per_region = (self.gatherer.rows_gathered - g0[1]) / regions
+      assert self.gathers_per_region == self.launches_per_region and self.rows_gathered_per_region == self.steps
+    else:
+      self.gathers_per_region = self.rows_gathered_per_region = 0
     return wall, live, ev_ms
 
   def summary(self, reps):
@@ -224,10 +242,12 @@ class Rollout:
             'ms_per_step_max': 1e3 * max(wall) / self.steps,
             'kernel_ms_median': ev_med / self.launches_per_region, 'kernel_ms_min': min(ev_ms) / self.launches_per_region,
             'live_env_steps_per_repetition': live[med], 'envs_per_gpu': self.n, 'global_envs': int(round(self.bdist.sum_over_ranks(float(self.n), self.device))),
-            'live_env_fraction_end': self.live_fraction_end, 'decode_ms': self.decode_ms}
+            'live_env_fraction_end': self.live_fraction_end, 'decode_ms': self.decode_ms,
+            'gathers_per_region': self.gathers_per_region, 'rows_gathered_per_region': self.rows_gathered_per_region,
+            'launches_per_region': self.launches_per_region}
 
 
-def observe_leg(roll, pairs, world):
+def observe_leg(roll, pairs, world, measure=False):
   """step + wind noise + 1099-feature observation with a full WindGP window (closed-loop cost)."""
   torch, bdist = roll.torch, roll.bdist
   sim, n, device = roll.sim, roll.n, roll.device
@@ -270,11 +290,11 @@ def observe_leg(roll, pairs, world):
           + 22 * 6 * 2 * 150)
   mfma_flop_executed = 1042 * 2048
   obs_bytes = 4396 + 2 * 60960 + 152 + 3072
-  traffic = None
-  try:
-    traffic = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('observe_hbm_bytes_per_launch')
-  except Exception:
-    pass
+  traffic, traffic_detail, traffic_note = None, None, 'not measured in this run'
+  if measure and world == 1 and n == 65536:
+    traffic_detail, traffic_note = measure_traffic('ble_observe_kernel', [sys.executable, os.path.join(ROOT, 'profiles', 'obs_only.py'), str(n)],
+                                                   launches_per_group=8, groups=1)
+    traffic = traffic_detail['bytes'] if traffic_detail else None
   tf = n * flop / (ms_obs * 1e-3) / 1e12
   return {'pairs': pairs, 'ms_per_observation_launch': ms_obs, 'ms_per_observation_launch_min': min(t_obs),
           'ms_per_step_plus_observation': ms_pair,
@@ -283,9 +303,96 @@ def observe_leg(roll, pairs, world):
           'includes_gather_to_rank0': world > 1,
           'kernel': 'ble_observe_kernel (fp64 WindGP: factor carried in HBM and slid with a stored drop vector, MFMA forward substitution)',
           'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS, 'achieved': tf, 'frac': tf / FP64_PEAK_TFLOPS,
-                       'traffic': traffic, 'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': obs_bytes,
+                       'traffic': traffic, 'traffic_detail': traffic_detail, 'traffic_note': traffic_note,
+                       'algorithmic_flop_per_env': flop, 'algorithmic_bytes_per_env': obs_bytes,
                        'executed_mfma_tflops': n * mfma_flop_executed / (ms_obs * 1e-3) / 1e12,
                        'hbm_gbs_algorithmic': n * obs_bytes / (ms_obs * 1e-3) / 1e9, 'hbm_gbs_measured': (traffic / (ms_obs * 1e-3) / 1e9) if traffic else None}}
+
+
+def policy_in_the_loop_leg(roll, launches=256):
+  """ONE kernel launch per agent step -- ble_step_f32, what VecBalloonArena.step and every agent loop
+  (`action = agent.step(reward, obs); env.step(action)`, eval/eval_lib.py:158-171) issues -- on the headline batch:
+  the back-to-back rate of `launches` launches and the median HIP-event duration of a single one."""
+  torch = roll.torch
+  sim, n = roll.sim, roll.n
+  sim.set_state(roll.host_state)
+  k_total = roll.actions.shape[0]
+  for i in range(8):
+    sim.step(roll.actions[i % k_total])
+  torch.cuda.synchronize()
+  # (a) per-launch duration: one event pair around each of 64 launches
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  per = []
+  for i in range(64):
+    e0.record(); sim.step(roll.actions[(8 + i) % k_total]); e1.record()
+    torch.cuda.synchronize()
+    per.append(e0.elapsed_time(e1) * 1e3)
+  # (b) the sequence: `launches` launches back to back, one synchronisation at the end.  The environments actually
+  # stepped (live when a step began) are counted by the kernel itself (ble_step_f32's active_count)
+  torch.cuda.synchronize()
+  c0 = int(sim.active_count.item())
+  t0 = time.perf_counter(); e0.record()
+  for i in range(launches):
+    sim.step(roll.actions[(72 + i) % k_total])
+  e1.record(); torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  sim.check_errors()
+  stepped = int(sim.active_count.item()) - c0
+  return {'launches': launches, 'envs': n, 'kernel': 'ble_step_kernel via ble_step_f32 (n_steps = 1)',
+          'us_per_launch_event_median': statistics.median(per), 'us_per_launch_event_min': min(per),
+          'us_per_step_back_to_back': e0.elapsed_time(e1) * 1e3 / launches, 'env_steps_per_s': stepped / dt,
+          'note': 'one launch per agent step: the per-launch fixed cost (state in/out, per-episode constants, wave launch and '
+                  'finish dispersion) is paid every step; the fused headline (ble_step_n_f32) pays it once per 32 steps'}
+
+
+def _pmc_pass(counter, cmd, workdir, timeout_s):
+  """One rocprofv3 --pmc pass (kernel trace only, as MI355X_MICROARCH.md prescribes) of `cmd`; returns the rows of the
+  counter-collection CSV."""
+  out_dir = os.path.join(workdir, counter)
+  full = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '-o', 'p', '--'] + cmd
+  env = dict(os.environ, TMPDIR='/tmp')
+  subprocess.run(full, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+  rows = []
+  for base, _, files in os.walk(out_dir):
+    for f in files:
+      if f.endswith('counter_collection.csv'):
+        with open(os.path.join(base, f)) as fh:
+          rows += [r for r in csv.DictReader(fh) if r['Counter_Name'] == counter]
+  return rows
+
+
+def being_profiled():
+  return any(k.startswith('ROCPROF') for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+
+
+def measure_traffic(kernel, cmd, launches_per_group, groups, timeout_s=240):
+  """HBM bytes per launch of `kernel`, measured now: FETCH_SIZE and WRITE_SIZE in two separate rocprofv3 --pmc passes of
+  `cmd`; the LAST groups x launches_per_group dispatches of the kernel are the steady-state / timed ones.  Units: the
+  counters are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read, hence the guide's
+  x 2 on the fetch side (`bytes` below; `bytes_raw` is the uncorrected sum)."""
+  if shutil.which('rocprofv3') is None:
+    return None, 'rocprofv3 not on PATH'
+  if being_profiled():
+    return None, 'this run is itself under a profiler: nested PMC pass skipped'
+  work = tempfile.mkdtemp(prefix='ble_pmc_', dir='/tmp')
+  try:
+    got = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+      rows = [r for r in _pmc_pass(counter, cmd, work, timeout_s) if kernel in r['Kernel_Name']]
+      rows.sort(key=lambda r: int(r['Dispatch_Id']))
+      take = rows[-groups * launches_per_group:]
+      if len(take) < launches_per_group:
+        return None, f'{counter}: only {len(rows)} dispatches of {kernel} found'
+      got[counter] = 1024.0 * sum(float(r['Counter_Value']) for r in take) / len(take)
+    return {'bytes': 2.0 * got['FETCH_SIZE'] + got['WRITE_SIZE'], 'bytes_raw': got['FETCH_SIZE'] + got['WRITE_SIZE'],
+            'fetch_size_bytes': got['FETCH_SIZE'], 'write_size_bytes': got['WRITE_SIZE'],
+            'dispatches_averaged': groups * launches_per_group,
+            'how': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) inside this bench.py run; '
+                   'bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of MI355X_MICROARCH.md)'}, None
+  except Exception as e:                  # never lose the line over the profiler
+    return None, f'PMC pass failed: {e!r}'[:300]
+  finally:
+    shutil.rmtree(work, ignore_errors=True)
 
 
 def facade_leg(steps=150):
@@ -319,7 +426,16 @@ def main():
   ap.add_argument('--per-env-grids', action='store_true', help='same as --config 4 data layout at the chosen size')
   ap.add_argument('--observe', type=int, default=8, metavar='N',
                   help='timed step+observation pairs of the observation leg (0 = skip)')
+  ap.add_argument('--traffic', choices=('auto', 'off'), default='auto',
+                  help='auto: measure roofline.traffic in this run with two rocprofv3 --pmc passes (N = 1, full run only)')
   args = ap.parse_args()
+
+  # ---- `python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and hand the
+  # result line of rank 0 through.  (Under torch.distributed.run WORLD_SIZE is set and this branch is not taken.)
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.path.insert(0, ROOT)
+    from balloon_learning_environment_amd import distributed as bdist_spawn
+    sys.exit(bdist_spawn.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
   import numpy as np
   import torch
@@ -330,17 +446,24 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+  assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks'
   assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU path)'
+  backend = os.environ.get('BLE_DIST_BACKEND', 'nccl')     # nccl = RCCL over xGMI; gloo only for smoke tests that put several ranks on one GPU
+  if world > 1 and backend == 'nccl':
+    assert torch.cuda.device_count() >= world, (f'{world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible '
+                                                '(BLE_DIST_BACKEND=gloo runs a smoke test with several ranks on one GPU)')
   dev_index = local_rank % torch.cuda.device_count()   # (== local_rank on a real multi-GPU node)
   torch.cuda.set_device(dev_index)
   device = torch.device('cuda', dev_index)
   if world > 1:
-    backend = os.environ.get('BLE_DIST_BACKEND', 'nccl')   # nccl = RCCL over xGMI; gloo only for single-GPU smoke tests
     if backend == 'nccl':
       dist.init_process_group('nccl', device_id=device)
     else:
       dist.init_process_group(backend)
+  n_joined = bdist.joined_ranks(device)                  # counted, not read from the command line
+  assert n_joined == args.gpus, f'{n_joined} ranks joined, --gpus {args.gpus}'
+  if args.config == 3:
+    assert 65536 % world == 0, 'configs[3] shards 65 536 environments into equal contiguous slices'
 
   # ---- the decoded wind grid: rank 0 owns it, everyone gets it by ONE broadcast (xGMI when world > 1)
   grid = torch.zeros(vec_state.GRID_SHAPE, dtype=torch.float32, device=device)
@@ -364,13 +487,19 @@ def main():
   n = head.n
   bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (hs['live_env_steps_per_repetition'] / world / head.launches_per_region)
   achieved = bytes_per_launch / (hs['kernel_ms_median'] * 1e-3) / 1e9
-  traffic = None
-  pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-  if os.path.exists(pmc_path):
-    try:
-      traffic = json.load(open(pmc_path)).get('hbm_bytes_per_launch')
-    except Exception:
-      traffic = None
+  # HBM traffic of the launch shape timed above, measured in this run (rank 0 of a 1-GPU full run; see measure_traffic)
+  traffic, traffic_detail, traffic_note = None, None, None
+  if world == 1 and args.traffic == 'auto' and not args.no_extras:
+    child = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
+             '--config', str(args.config), '--reps', '3', '--no-extras', '--traffic', 'off', '--substeps', str(args.substeps)]
+    if args.envs_per_gpu:
+      child += ['--envs-per-gpu', str(args.envs_per_gpu)]
+    if args.per_env_grids:
+      child += ['--per-env-grids']
+    traffic_detail, traffic_note = measure_traffic('ble_step_kernel', child, head.launches_per_region, groups=6)
+    traffic = traffic_detail['bytes'] if traffic_detail else None
+  else:
+    traffic_note = 'not measured in this run (N > 1, --no-extras or --traffic off)'
   issue = None
   for tag in ('r02', 'r01'):
     try:
@@ -386,10 +515,16 @@ def main():
   # ---- the other 1-GPU legs (same code path, fewer repetitions)
   configs = {f'configs[{args.config}]': {k: hs[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step')}}
   observe = None
+  policy = None
   if not args.no_extras:
     extra_reps = max(5, min(11, args.reps))
+    if rank == 0 and world == 1:
+      policy = policy_in_the_loop_leg(head)
+      configs[f'configs[{args.config}] one launch per step'] = {'env_steps_per_s': policy['env_steps_per_s'], 'envs_per_gpu': head.n,
+                                                               'us_per_launch_event_median': policy['us_per_launch_event_median'],
+                                                               'us_per_step_back_to_back': policy['us_per_step_back_to_back']}
     if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
-      observe = observe_leg(head, args.observe, world)
+      observe = observe_leg(head, args.observe, world, measure=(args.traffic == 'auto'))
     del head
     torch.cuda.empty_cache()
     for cfg in (1, 2, 3, 4):
@@ -416,7 +551,7 @@ def main():
   if rank == 0:
     out = {
         'metric': 'env-steps/sec at 65 536 parallel envs; achieved HBM GB/s fraction of peak',
-        'value': hs['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'value': hs['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': n_joined, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': hs['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong' if args.config == 3 else 'weak',
         'vs_baseline': None, 'dtype': 'f32+f64', 'data': 'synthetic',
         'dtype_note': 'state stored f32; vertical chain (p, T, V, n_air, thermal and ACS increments) computed in f64, solar geometry / wind blend in f32',
@@ -425,11 +560,16 @@ def main():
                    'substeps_per_step': args.substeps, 'live_env_fraction_end': hs['live_env_fraction_end'],
                    'per_env_grids': bool(args.config == 4 or args.per_env_grids), 'decode_ms': hs['decode_ms'],
                    'parallelism': f'env-sharded x{world}, ' + ('no broadcast (per-rank decode)' if args.config == 4 else 'grid broadcast once') +
-                                  f', reward/terminal gather to rank 0 every {GATHER_EVERY} steps'},
+                                  (f', reward/terminal rows of every launch (<= {GATHER_EVERY} steps) gathered to rank 0 on a side stream' if world > 1
+                                   else ', single rank: nothing to exchange'),
+                   # counted by the gatherer inside the timed regions (0 on one rank): never an exchange that did not run
+                   'exchanges': {'gathers_per_timed_region': hs['gathers_per_region'], 'agent_step_rows_gathered_per_timed_region': hs['rows_gathered_per_region'],
+                                 'launches_per_timed_region': hs['launches_per_region'],
+                                 'bytes_per_rank_per_timed_region': 5 * n * hs['rows_gathered_per_region']}},
         'repetitions': {k: hs[k] for k in ('repetitions', 'steps_per_repetition', 'env_steps_per_s_min', 'env_steps_per_s_max',
                                             'env_steps_per_s_first_repetition', 'ms_per_step_min', 'ms_per_step_max')},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_detail': traffic_detail, 'traffic_note': traffic_note,
                      'kernel': 'ble_step_kernel', 'kernel_ms': hs['kernel_ms_median'], 'kernel_ms_min': hs['kernel_ms_min'],
                      'agent_steps_per_launch': args.steps / -(-args.steps // GATHER_EVERY),
                      'kernel_us_per_agent_step': 1e3 * hs['kernel_ms_median'] * (-(-args.steps // GATHER_EVERY)) / args.steps,
@@ -440,6 +580,8 @@ def main():
                      'instruction_issue': issue},
         'configs': configs,
     }
+    if policy is not None:
+      out['policy_in_the_loop'] = policy
     if observe is not None:
       out['observe'] = observe
     if world == 1 and not args.no_cpu_baseline and not args.no_extras:

@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define BLE_ABI_VERSION 1
+/* 2: ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
+ *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
+#define BLE_ABI_VERSION 2
 
 /* return codes */
 #define BLE_OK 0
@@ -220,6 +222,9 @@ typedef struct ble_gp_history_f32 {
                          per-step refit of the reference (wind_gp.py:186-188) becomes an O(n^2) slide;
                          opaque to the caller; NULL = refit in LDS every call */
   int32_t* n_chol;    /* [n] rows of `chol` in use (required when chol != NULL), zero-initialised */
+  int64_t chol_stride; /* doubles between the slabs of consecutive environments in `chol`: >= BLE_GP_CHOL_STRIDE when
+                          chol != NULL (a smaller value is rejected with BLE_E_INVALID_ARG: the kernel would write
+                          past the caller's allocation); ignored when chol == NULL */
 } ble_gp_history_f32;
 int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
                     const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,

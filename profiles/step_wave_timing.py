@@ -1,0 +1,59 @@
+"""Where the time of ONE ble_step_kernel launch goes, wave by wave (profiling build, see profiles/instr/ble_step_instr.h):
+   bash profiles/build_variant.sh step_timing '-DBLE_STEP_INSTR_HEADER="../../profiles/instr/ble_step_instr.h"'
+   BLE_HIP_LIB=build_ab/libble_step_timing.so python profiles/step_wave_timing.py [n_envs]
+Launches of K = 1 and K = 32 agent steps; every wave records its entry / exit wall clock (100 MHz) and the shader-clock length
+of its phases.  Prints the launch span (first entry -> last exit), the dispatch ramp, the finish dispersion and the phases."""
+import ctypes, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from balloon_learning_environment_amd import vec_state, reset_host, device as dev
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+sim = vec_state.VecSimulator(n)
+field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)
+sim.set_grid(torch.from_numpy(field).cuda())
+sim.set_state(reset_host.sample_initial_state(n, seed=1000))
+gen = torch.Generator(device='cuda'); gen.manual_seed(7)
+acts = torch.randint(0, 3, (32, n), dtype=torch.uint8, device='cuda', generator=gen)
+rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
+waves = (n + 63) // 64
+dbg = torch.zeros((waves, 8), dtype=torch.int64, device='cuda')
+
+
+def launch(k):
+  code = sim.lib.ble_step_n_f32(ctypes.byref(sim._struct), acts.data_ptr(), sim.grid.data_ptr(), 0, rew.data_ptr(), term.data_ptr(),
+                                sim.err_flags.data_ptr(), dbg.data_ptr(), n, 18, k, dev.stream_ptr(sim.device))
+  assert code == 0
+
+
+for _ in range(3):
+  launch(32)
+torch.cuda.synchronize()
+snap = {k: t.clone() for k, t in sim.state.items()}
+names = ['state loads landed', 'ACS cubics + barrier', 'per-episode constants', 'agent steps', 'stores acknowledged']
+for k in (1, 1, 32):
+  for key, t in sim.state.items():
+    t.copy_(snap[key])
+  torch.cuda.synchronize()
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  e0.record(); launch(k); e1.record(); torch.cuda.synchronize()
+  d = dbg.cpu().numpy().astype(np.float64)
+  t_in, t_out = d[:, 0] * 0.01, d[:, 1] * 0.01            # us
+  span = t_out.max() - t_in.min()
+  ramp = t_in - t_in.min()
+  dur = t_out - t_in
+  fin = t_out - t_in.min()
+  clk = d[:, 7] / np.maximum(dur, 1e-9)                    # shader cycles per us
+  q = lambda a: ' '.join(f'{np.percentile(a, p):7.2f}' for p in (0, 10, 50, 90, 99, 100))
+  print(f'--- K = {k} agent steps per launch, {waves} waves; HIP events {e0.elapsed_time(e1) * 1e3:.1f} us; span first entry -> last exit {span:.2f} us')
+  print(f'    percentiles                0      10      50      90      99     100')
+  print(f'    wave entry after first  {q(ramp)}  us   (dispatch ramp)')
+  print(f'    wave duration           {q(dur)}  us')
+  print(f'    wave exit after first   {q(fin)}  us   (finish dispersion: the launch ends with the last one)')
+  print(f'    shader clock            {np.median(clk):.0f} cycles/us')
+  for j, name in enumerate(names):
+    us = d[:, 2 + j] / np.median(clk)
+    print(f'    {name:24s}{q(us)}  us')
+  late = np.argsort(dur)[-5:]
+  print('    slowest waves:', [(int(w), round(float(dur[w]), 2), round(float(d[w, 5] / np.median(clk)), 2)) for w in late], '(wave, duration, its agent-step phase)')
+sim.check_errors()

@@ -141,3 +141,78 @@ def test_broadcast_and_gather_world2(tmp_path):
   assert obs.shape == (12, 1099)
   assert torch.equal(obs, torch.arange(12, dtype=torch.float32)[:, None] + torch.arange(1099, dtype=torch.float32)[None, :] / 2048)
   assert outs[1]['obs'].numel() == 0                      # only the destination rank holds the gathered blocks
+
+
+def _region_worker(rank, world, port, out_dir):
+  """bench.py's timed region with the driver's flags (--steps 20): ONE launch of 20 agent steps, shorter than the
+  32-step block -- its rows must be gathered inside the region all the same; then a 72-step region = 32 + 32 + 8."""
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    n_local, every = 4096, 32
+    lo = rank * n_local
+    out = {'joined': bdist.joined_ranks('cpu')}
+    for steps in (20, 72):
+      rewards = torch.zeros((steps, n_local)); terminals = torch.zeros((steps, n_local), dtype=torch.uint8)
+      g = bdist.OutputGatherer(every, n_local, 'cpu', world)
+      seen = []
+
+      def make(k0, c):
+        def launch():                       # stands in for ble_step_n_f32: fills rows k0 .. k0 + c - 1 of this rank's shard
+          rewards[k0:k0 + c] = (torch.arange(lo, lo + n_local, dtype=torch.float32)[None, :] +
+                                1e6 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None])
+          terminals[k0:k0 + c] = ((torch.arange(lo, lo + n_local)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 5 == 0).to(torch.uint8)
+        return launch
+      plan, k = [], 0
+      while k < steps:
+        c = min(every, steps - k)
+        plan.append((make(k, c), rewards[k:k + c], terminals[k:k + c]))
+        k += c
+      got = []
+      for item in plan:                     # one launch at a time so that rank 0 can keep each gathered block
+        bdist.run_region([item], g)
+        if rank == 0:
+          c = item[1].shape[0]
+          got.append((g.reward[:, :c].clone(), g.terminal[:, :c].clone()))
+      out[steps] = dict(gathers=g.gathers, rows=g.rows_gathered, got=got)
+    torch.save(out, os.path.join(out_dir, f'g{rank}.pt'))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_partial_block_is_gathered_inside_the_region_world2(tmp_path):
+  world = 2
+  mp.spawn(_region_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  outs = [torch.load(os.path.join(tmp_path, f'g{r}.pt')) for r in range(world)]
+  assert [o['joined'] for o in outs] == [2, 2]
+  for steps, blocks in ((20, [20]), (72, [32, 32, 8])):
+    for o in outs:
+      assert o[steps]['gathers'] == len(blocks) and o[steps]['rows'] == steps       # counted on every rank
+    k0 = 0
+    for (rew, term), c in zip(outs[0][steps]['got'], blocks):
+      assert tuple(rew.shape) == (world, c, 4096)
+      glob = torch.cat([rew[r] for r in range(world)], dim=1)                       # [c, 8192] in env order
+      want = torch.arange(8192, dtype=torch.float32)[None, :] + 1e6 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None]
+      assert torch.equal(glob, want)
+      tglob = torch.cat([term[r] for r in range(world)], dim=1)
+      assert torch.equal(tglob, ((torch.arange(8192)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 5 == 0).to(torch.uint8))
+      k0 += c
+
+
+def test_spawn_local_ranks_starts_one_process_per_rank(tmp_path):
+  """`python bench.py --gpus N` without a launcher starts its ranks through spawn_local_ranks: every child gets the
+  torch.distributed.run environment, they rendezvous on 127.0.0.1 and count themselves."""
+  import sys
+  prog = ('import os, torch, torch.distributed as dist\n'
+          'from balloon_learning_environment_amd import distributed as b\n'
+          'dist.init_process_group("gloo")\n'
+          'n = b.joined_ranks("cpu")\n'
+          f'open(os.path.join({str(tmp_path)!r}, "rank" + os.environ["RANK"]), "w").write(f"{{n}} {{os.environ[\'LOCAL_RANK\']}} {{os.environ[\'WORLD_SIZE\']}}")\n'
+          'dist.destroy_process_group()\n')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = bdist.spawn_local_ranks([sys.executable, '-c', prog], 2, env_extra={'PYTHONPATH': root}, timeout=300)
+  assert code == 0
+  assert [open(os.path.join(tmp_path, f'rank{r}')).read() for r in range(2)] == ['2 0 2', '2 1 2']
+  # a failing rank is reported and the others are stopped
+  bad = 'import os, sys, time\nsys.exit(3) if os.environ["RANK"] == "1" else time.sleep(60)\n'
+  assert bdist.spawn_local_ranks([sys.executable, '-c', bad], 2, timeout=120) == 3

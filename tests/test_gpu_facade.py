@@ -289,3 +289,76 @@ def test_vec_balloon_env_defaults_per_env_fields_and_error_polling(mods):
   env.step(torch.ones(n, dtype=torch.uint8, device='cuda'))
   with pytest.raises((FloatingPointError, AssertionError, ValueError)):
     env.check_errors()
+
+
+def test_bound_device_constructor_honours_an_outside_observation(mods):
+  """FeatureConstructor.observe(observation) is the reference's public contract (features.py:301-330): a device
+  constructor that its arena bound to the arena's own state still observes what an outside caller hands it (it gives
+  the alias up), and an arena whose get_measurements is overridden is never bound."""
+  import dataclasses
+  balloon_arena, balloon_env, features, _ = mods
+  env = balloon_env.BalloonEnv(seed=33)
+  fc = env.arena.feature_constructor
+  assert isinstance(fc, features.DevicePerciatelliFeatureConstructor) and fc._bound
+  env.step(1)
+  before = fc.get_features()
+  meas = env.arena.get_measurements()
+  b = meas.balloon_observation
+  moved = dataclasses.replace(b, pressure=b.pressure + 900.0) if dataclasses.is_dataclass(b) else None
+  if moved is None:
+    import copy
+    moved = copy.copy(b); moved.pressure = b.pressure + 900.0
+  fc.observe(type(meas)(balloon_observation=moved, wind_at_balloon=meas.wind_at_balloon))      # no AssertionError
+  after = fc.get_features()
+  assert not fc._bound
+  assert abs(float(after[0]) - float(before[0]) - 0.1) < 1e-3                # feature 0 = (p - 5000) / 9000
+  # the arena's own state is untouched, and the arena keeps working through the unbound path
+  assert abs(env.arena.get_balloon_state().pressure - b.pressure) < 1e-3
+  obs, _, _, _ = env.step(2)
+  assert env.observation_space.contains(obs)
+
+  class NoisyArena(balloon_arena.BalloonArena):
+    def get_measurements(self):
+      m = super().get_measurements()
+      return m
+  arena = NoisyArena(features.perciatelli_feature_constructor, balloon_env.gaussian_wind_field_factory(), seed=3)
+  assert isinstance(arena.feature_constructor, features.DevicePerciatelliFeatureConstructor)
+  assert not getattr(arena.feature_constructor, '_bound', False)
+  assert arena.step(1).shape == (1099,)
+
+
+def test_host_reset_clears_the_observation_history(mods):
+  """VecBalloonArena.reset(seed, on_device=False) is reproducible whatever happened before: the WindGP window of the
+  previous episode does not leak into the new one."""
+  import torch
+  balloon_arena, _, _, _ = mods
+  arena = balloon_arena.VecBalloonArena(64, seed=5)
+  arena.reset(11, on_device=False)
+  first = arena.observe().clone()
+  for i in range(6):
+    arena.step(torch.full((64,), i % 3, dtype=torch.uint8, device='cuda'))
+    arena.observe()
+  arena.reset(11, on_device=False)
+  again = arena.observe()
+  arena.sim.check_errors()
+  assert torch.equal(first, again)
+  assert int(arena.sim._gp['count'].max()) == 1
+
+
+def test_env_on_a_non_current_device(mods):
+  """Every launch site makes its own device current (vec_state, the generative sampler, the noise model, the forecast):
+  an environment built on cuda:1 works while cuda:0 is the current device.  Needs two GPUs."""
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs 2 GPUs (the GPU boxes of this pool have one)')
+  _, balloon_env, _, _ = mods
+  torch.cuda.set_device(0)
+  env = balloon_env.VecBalloonEnv(128, seed=3, device='cuda:1')
+  obs = env.reset()
+  assert obs.device.index == 1 and torch.cuda.current_device() == 0
+  obs, reward, terminal = env.step(torch.ones(128, dtype=torch.uint8, device='cuda:1'))
+  env.check_errors()
+  assert obs.device.index == 1 and torch.cuda.current_device() == 0
+  per_env = balloon_env.VecBalloonEnv(64, seed=3, device='cuda:1', per_env_fields=True)      # the decode path (GEMMs + ble_decode_flow_fields_f32)
+  per_env.reset(); per_env.step(torch.ones(64, dtype=torch.uint8, device='cuda:1')); per_env.check_errors()
+  assert torch.cuda.current_device() == 0

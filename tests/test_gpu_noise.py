@@ -103,8 +103,10 @@ def test_facade_with_noise(lib):
 
 
 def test_device_noise_equals_host_build(lib):
-  """The device kernel and the g++ build of the same header agree (fp32 arithmetic, libm vs
-  hardware floor/sqrt: identical lattice decisions; values within 2e-5)."""
+  """TRIAGE, NOT PARITY: the device kernel against the g++ build of the SAME header (fp32 arithmetic, libm vs
+  hardware floor/sqrt: identical lattice decisions; values within 2e-5).  It shows that the kernel source means the
+  same thing on both compilers -- it says nothing about the reference, whose opensimplex 0.3 primitive is absent
+  (row f4 stays "parity unpinned")."""
   import test_noise_decode_host as host
   rng = np.random.default_rng(5)
   n = 20000

@@ -6,9 +6,13 @@
    produced by the step kernel itself, long enough for the 6 h window to slide;
  * API behaviour: get_features without observe, episode reset, ragged batch sizes.
 
-Tolerances (features are float32, all O(1)): discrete pattern of unreachable levels identical;
-|diff| <= 2e-4 everywhere (the bearing feature is arccos(.)/pi whose conditioning near aligned
-winds turns the fp32 forecast's 1e-7 into ~1e-4), and <= 1e-5 for at least 99.9 % of entries.
+Tolerances (features are float32, all O(1)): discrete pattern of unreachable levels identical and
+|diff| <= 1e-5 on EVERY entry whenever the device and the oracle see the same inputs (the state as the
+float32 values the device holds) -- no outlier budget.  The reference's fixtures F11 / F12 were computed from
+float64 states; rounding those states to float32 (the north star's state format) moves the REFERENCE'S OWN
+features by up to 1e-4 (the bearing feature is arccos(.)/pi: a 6e-8 change of x next to an aligned wind), so
+the direct comparison with a fixture allows 1e-5 + that sensitivity, computed in the test, per entry:
+|oracle(float32 inputs) - fixture|.
 """
 import numpy as np
 import pytest
@@ -34,22 +38,38 @@ def rows_to_arrays(rows):
   return {k: np.array([r[k] for r in rows]) for k in rows[0]}
 
 
-def check(got, want, what):
+TOL = 1e-5
+
+
+def check(got, want, what, slack=None):
+  """|got - want| <= 1e-5 (+ `slack`, a per-entry array: the reference's own sensitivity to the float32 rounding
+  of its inputs) on every entry; the pattern of unreachable levels and the discrete features exact."""
   np.testing.assert_array_equal(UNREACHABLE(got), UNREACHABLE(want), err_msg=what)
   np.testing.assert_array_equal(got[..., 8:14], want[..., 8:14], err_msg=what)
   err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-  assert err.max() <= 2e-4, (what, err.max(), np.unravel_index(err.argmax(), err.shape))
-  assert (err > 1e-5).mean() <= 1e-3, (what, (err > 1e-5).mean())
+  excess = err - (TOL if slack is None else TOL + slack)
+  assert excess.max() <= 0.0, (what, err.max(), np.unravel_index(excess.argmax(), excess.shape))
   return err
 
 
-def drive_fixture(vec_state, name, envs, carry=True):
+def row32(row):
+  """The row as the device holds it: float fields rounded to float32 (integers unchanged)."""
+  return {k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in row.items()}
+
+
+def drive_fixture(vec_state, name, envs, carry=True, keep_last=None):
+  """Writes the fixture's states into the device step by step and observes.  Returns the device features, the
+  feature oracle's on the SAME float32 inputs, and the fixture."""
+  import features_oracle
   g = helpers.golden(name)
   field = helpers.fixture_field(g)
   sim = vec_state.VecSimulator(len(envs))
   sim.set_grid(torch.from_numpy(field).cuda())
   n_steps = g['x'].shape[1]
+  first = 0 if keep_last is None else n_steps - keep_last
   out = np.zeros((len(envs), n_steps, 1099), np.float32)
+  same_inputs = np.zeros((len(envs), n_steps, 1099), np.float32)
+  oracles = [features_oracle.FeatureOracle(field, float(np.float32(g['alpha'][j]))) for j in envs]
   for i in range(n_steps):
     rows = [helpers.feature_row(g, j, i) for j in envs]
     sim.set_state(rows_to_arrays(rows))
@@ -58,21 +78,30 @@ def drive_fixture(vec_state, name, envs, carry=True):
     noise = np.stack([g['wind_measured'][envs, i, 0] - fu, g['wind_measured'][envs, i, 1] - fv], 1).astype(np.float32)
     out[:, i] = sim.observe(torch.from_numpy(noise).cuda(), carry_factor=carry).cpu().numpy()
     sim.check_errors()
-  return out, g
+    for e, (fo, row) in enumerate(zip(oracles, rows)):
+      fo.observe(row32(row), noise[e].astype(np.float64))
+      if i >= first:
+        same_inputs[e, i] = fo.features()
+  return out, same_inputs, g
 
 
 @pytest.mark.parametrize('carry', [True, False])
 def test_observe_matches_reference_features(vec_state, carry):
   """carry=True: the WindGP factor is slid from call to call (HBM-resident); False: refit in LDS."""
-  got, g = drive_fixture(vec_state, 'f11_features', [0, 1, 2], carry)
-  err = check(got, g['features'], 'F11')
-  print('F11 device observation: max |diff| %.3g, median of non-zero %.3g' % (err.max(), np.median(err[err > 0])))
+  got, same, g = drive_fixture(vec_state, 'f11_features', [0, 1, 2], carry)
+  err = check(got, same, 'F11 vs the oracle on the same float32 inputs')
+  sens = np.abs(same.astype(np.float64) - g['features'].astype(np.float64))
+  err_ref = check(got, g['features'], 'F11 vs the reference', slack=sens)
+  print('F11 device observation: max |diff| %.3g vs the oracle on the same inputs; %.3g vs the reference fixture, whose own '
+        'sensitivity to the float32 rounding of its inputs is %.3g' % (err.max(), err_ref.max(), sens.max()))
 
 
 @pytest.mark.parametrize('carry', [True, False])
 def test_observe_long_horizon_matches_reference(vec_state, carry):
-  got, g = drive_fixture(vec_state, 'f12_features_long', [0], carry)
-  check(got[:, -16:], g['features'], 'F12')
+  got, same, g = drive_fixture(vec_state, 'f12_features_long', [0], carry, keep_last=16)
+  check(got[:, -16:], same[:, -16:], 'F12 vs the oracle on the same float32 inputs')
+  sens = np.abs(same[:, -16:].astype(np.float64) - g['features'].astype(np.float64))
+  check(got[:, -16:], g['features'], 'F12 vs the reference', slack=sens)
 
 
 @pytest.mark.parametrize('carry', [True, False])
@@ -435,7 +464,7 @@ def test_observe_full_size_65536_envs(vec_state):
   diff = (final_a.double() - final_c.double()).abs()[live]
   frac_loose = float((diff.amax(dim=1) > 1e-5).double().mean())
   print(f'carried vs refitted at 65536 envs: max |diff| {float(diff.max()):.3g}, envs beyond 1e-5: {frac_loose:.2e}')
-  assert float(diff.max()) <= 2e-4 and frac_loose <= 1e-3
+  assert float(diff.max()) <= TOL and frac_loose == 0.0
 
 
 def test_irregular_history_carried_equals_refit_at_occupancy(vec_state):
@@ -485,7 +514,7 @@ def test_irregular_history_carried_equals_refit_at_occupancy(vec_state):
     assert torch.equal(la, lb)
     d = (oa.double() - ob.double()).abs()[la]
     worst = max(worst, float(d.max()))
-    assert float(d.max()) <= 2e-4 and float((d.amax(dim=1) > 1e-5).double().mean()) <= 1e-3, (i, float(d.max()))
+    assert float(d.max()) <= TOL, (i, float(d.max()))
   print(f'irregular history at 16384 envs, carried vs refitted: {len(a)} compared steps, worst |diff| {worst:.3g}')
 
 

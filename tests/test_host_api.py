@@ -40,9 +40,10 @@ def test_state_struct_matches_header_order():
 def test_gp_history_struct_matches_header_order():
   header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
   body = header[header.index('typedef struct ble_gp_history_f32 {'):header.index('} ble_gp_history_f32;')]
-  names = re.findall(r'\*\s*(\w+);', body)
-  assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_]
+  names = re.findall(r'(?:\*|int64_t)\s*(\w+);', body)       # the pointer members, then the int64 slab stride (ABI 2)
+  assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_] and names[-1] == 'chol_stride'
   assert ctypes.sizeof(_abi.BleGpHistoryF32) == 8 * len(names)
+  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 2
   assert int(re.search(r'#define BLE_OBS_DIM (\d+)', header).group(1)) == _lib.OBS_DIM
   assert int(re.search(r'#define BLE_GP_CAPACITY (\d+)', header).group(1)) == _lib.GP_CAPACITY
   assert int(re.search(r'#define BLE_GP_CHOL_STRIDE (\d+)', header).group(1)) == _lib.GP_CHOL_STRIDE
