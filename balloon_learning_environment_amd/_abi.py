@@ -28,15 +28,20 @@ DERIVED_FLOATS = FIELD_NAMES[9:13]
 EPISODE_CONSTS = FIELD_NAMES[13:18]
 
 
+EPISODE_CACHE_ROWS = 7     # BLE_EPISODE_CACHE_ROWS
+
+
 class BleStateF32(ctypes.Structure):
-  _fields_ = [(name, ctypes.POINTER(ct)) for name, _, ct in STATE_FIELDS]
+  # the per-env arrays, then the optional [EPISODE_CACHE_ROWS][n] float64 cache of per-episode derived constants
+  _fields_ = [(name, ctypes.POINTER(ct)) for name, _, ct in STATE_FIELDS] + [('episode_cache', ctypes.POINTER(ctypes.c_double))]
 
 
-def state_struct(pointers):
-  """Builds a BleStateF32 from a {field: integer address} mapping."""
+def state_struct(pointers, episode_cache: int = 0):
+  """Builds a BleStateF32 from a {field: integer address} mapping (+ the address of the optional episode cache)."""
   st = BleStateF32()
   for name, _, ct in STATE_FIELDS:
     setattr(st, name, ctypes.cast(ctypes.c_void_p(int(pointers[name])), ctypes.POINTER(ct)))
+  st.episode_cache = ctypes.cast(ctypes.c_void_p(int(episode_cache) or None), ctypes.POINTER(ctypes.c_double))
   return st
 
 

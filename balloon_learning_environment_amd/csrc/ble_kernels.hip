@@ -8,15 +8,7 @@
 // 8 x (4 contiguous floats).  Nothing here is a dense contraction: no MFMA.
 // Target: gfx950 only (hipcc --offload-arch=gfx950); no other backend, no shims.
 #include <hip/hip_runtime.h>
-
-#include "../../include/ble_abi.h"
-#include "ble_reset.h"
-#include "ble_step_core.h"
-#include "ble_observe.h"
-#include "ble_noise.h"
-#include "ble_decode.h"
-
-using namespace ble;
+#include <stddef.h>
 
 // Instrumentation hooks of ble_step_kernel: empty in the product build.  A profiling build
 // (profiles/build_variant.sh ... -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
@@ -27,8 +19,18 @@ using namespace ble;
 #define BLE_STEP_INSTR_BEGIN() do {} while (0)
 #define BLE_STEP_MARK(i) do {} while (0)
 #define BLE_STEP_INSTR_END() do {} while (0)
+#define BLE_STEP_STEP_DONE(k) do {} while (0)
 #define BLE_STEP_COUNTS_LIVE 1
 #endif
+
+#include "../../include/ble_abi.h"
+#include "ble_reset.h"
+#include "ble_step_core.h"
+#include "ble_observe.h"
+#include "ble_noise.h"
+#include "ble_decode.h"
+
+using namespace ble;
 
 namespace {
 
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   uint32_t flags = 0;
   EnvRegs s;
   EnvConst c;
+  EpisodeCacheRow cached = {};
   bool live = false;
   BLE_STEP_INSTR_BEGIN();
   if (in_range) {
@@ -79,17 +82,27 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     s.alt_fsm = st.alt_fsm[i]; s.env_fsm = st.env_fsm[i]; s.paused = st.power_paused[i];
     c.lat0_deg = st.center_lat_deg[i]; c.lng0_deg = st.center_lng_deg[i];
     c.ir = st.upwelling_infrared[i]; c.alpha = st.alpha[i]; c.start_unix = st.start_unix[i];
+    if (st.episode_cache != nullptr) cached = episode_cache_load(st.episode_cache, n, i);
     live = s.status == kOk;
   }
-  // (the ACS table's piecewise cubics are built while the state loads above are in flight)
+  // the ACS table's piecewise cubics: a compile-time table, constant memory -> LDS (the loop reads it by a per-lane index)
+  acs_poly[threadIdx.x] = kAcsPoly.c[threadIdx.x];
+  if (threadIdx.x < kAcsPolyDoubles - kBlock) acs_poly[kBlock + threadIdx.x] = kAcsPoly.c[kBlock + threadIdx.x];
   BLE_STEP_MARK(1);
-  if (threadIdx.x < 12) acs_build_poly(kAcsEfficiency, (int)threadIdx.x, acs_poly + 6 * threadIdx.x);
   __syncthreads();
   BLE_STEP_MARK(2);
   const bool was_live = live;
   int last_act = 0;
   EnvHoisted hc;
-  if (live) hc = hoist_constants(c);
+  if (live) {
+    // per-episode constants: from the cache unless its entry belongs to other constants (then: recompute, store)
+    if (st.episode_cache != nullptr && episode_cache_hit(cached, c)) {
+      hc = hoisted_from_cache(cached, c);
+    } else {
+      hc = hoist_constants(c);
+      if (st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
+    }
+  }
   BLE_STEP_MARK(3);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
@@ -124,6 +137,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
                   (unsigned long long)__popcll(m));
     }
     live = live && s.status == kOk;
+    BLE_STEP_STEP_DONE(k);
   }
   BLE_STEP_MARK(4);
   if (was_live) {
@@ -287,10 +301,8 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   if (i >= n) return;
   // power and mass flow through the transition's piecewise-cubic form, the efficiency through the two-table form
   const double prm1 = (double)pr[i] - 1.0;
-  double poly[kAcsPolyDoubles];
-  for (int k = 0; k < 12; ++k) acs_build_poly(kAcsEfficiency, k, poly + 6 * k);
   double w, md;
-  acs_down_poly(poly, prm1, &w, &md);
+  acs_down_poly(kAcsPoly.c, prm1, &w, &md);       // the compile-time table the transition copies into LDS
   power[i] = (float)w; eff[i] = (float)acs_efficiency_f64(kAcsEfficiency, prm1, acs_power_f64(prm1)); mdot[i] = (float)md;
 }
 
@@ -398,6 +410,11 @@ __global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, con
     st.sunrise_h_rel[i] = (int32_t)(sunrise + 1800 - start);                             // power_safety.py:43-48
     st.sunset_rel[i] = (int32_t)(sunset - start);
     st.status[i] = kOk; st.last_command[i] = kStay; st.alt_fsm[i] = 0; st.env_fsm[i] = 0; st.power_paused[i] = 0;
+    if (st.episode_cache != nullptr) {       // what the transition derives from this episode's constants alone
+      EnvConst c;
+      c.lat0_deg = lat0; c.lng0_deg = lng0; c.ir = ir; c.alpha = alpha; c.start_unix = start;
+      episode_cache_store(st.episode_cache, n, i, c, hoist_constants(c));
+    }
   }
   report_flags(flags, err_flags);
 }
@@ -444,7 +461,7 @@ inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1)
 inline bool state_ok(const ble_state_f32* st) {
   if (!st) return false;
   const void* const* p = reinterpret_cast<const void* const*>(st);
-  for (size_t k = 0; k < sizeof(ble_state_f32) / sizeof(void*); ++k)
+  for (size_t k = 0; k < offsetof(ble_state_f32, episode_cache) / sizeof(void*); ++k)      // (episode_cache is optional)
     if (p[k] == nullptr) return false;
   return true;
 }

@@ -787,7 +787,11 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           const double* bsrc = old_row + (r - 4);          // columns k_hi - 3 .. k_hi, k_hi = r - 1 - j
           const double2* bpb = pbv + (r - 4);
           double* bdst = new_row + (r - 4);
-          double* sink = &sh.z[2][0] + 4 * lane;           // (z[2..3] are idle until the sweep)
+          // masked stores go to a sink (a select of the address, not a branch).  Lane L's sink is z[2] + L, so store i of
+          // the round writes z[2][L + i] / z[2][L + 3 - i]: consecutive lanes hit consecutive banks (the former 4 L spacing put
+          // every eighth lane on the same bank pair: a 4-way conflict on each of the 8 stores of a round for the lanes that
+          // had finished their half -- profiles/r03_observe_lds.md); lanes overlap in the sink, nobody reads it
+          double* sink = &sh.z[2][0] + lane;               // (z[2..3] are idle until the sweep)
           for (int j0 = 0; j0 < steps; j0 += 4) {
             double2 fp[4], bp[4]; double fl[4], bl[4];
 #pragma unroll

@@ -21,6 +21,11 @@
 // lives in this directory.)
 #include "ble_intrinsics.h"
 
+// (profiling builds count how often the rare paths of the transition are taken: profiles/instr/ble_step_instr.h)
+#ifndef BLE_STEP_EVENT
+#define BLE_STEP_EVENT(i) do {} while (0)
+#endif
+
 namespace ble {
 
 // ---------------------------------------------------------------- constants
@@ -319,13 +324,17 @@ BLE_FN double atm_height_f64c(int i) {
 // bound every pressure a flying balloon can reach -- two pows; constant over an episode, so the fused
 // multi-step kernel evaluates it once per launch.
 struct AtmBase { double l0, l1, l2, t1, p1, t2, p2; };
+// (the part that costs nothing: lapse rates and layer-top temperatures; the two transition pressures are the pows)
+BLE_FN void atm_base_linear(double alpha, AtmBase* b) {
+  b->l0 = atm_lapse_f64(0, alpha); b->l1 = atm_lapse_f64(1, alpha); b->l2 = atm_lapse_f64(2, alpha);
+  b->t1 = 300.0 + b->l0 * (17000.0 - -610.0);
+  b->t2 = b->t1 + b->l1 * (21000.0 - 17000.0);
+}
 BLE_FN AtmBase atm_base(double alpha) {
   const double g = 9.80665;
   AtmBase b;
-  b.l0 = atm_lapse_f64(0, alpha); b.l1 = atm_lapse_f64(1, alpha); b.l2 = atm_lapse_f64(2, alpha);
-  b.t1 = 300.0 + b.l0 * (17000.0 - -610.0);
+  atm_base_linear(alpha, &b);
   b.p1 = 108870.8213 * d_pow_fast(b.t1 * (1.0 / 300.0), -g * d_rcp(kAirSpecificGasD * b.l0));
-  b.t2 = b.t1 + b.l1 * (21000.0 - 17000.0);
   b.p2 = b.p1 * d_pow_fast(b.t2 * d_rcp(b.t1), -g * d_rcp(kAirSpecificGasD * b.l1));
   return b;
 }
@@ -341,6 +350,7 @@ BLE_FN AtmWindow atm_window_from(const AtmBase& b, double alpha, double p, uint3
   w.hb = in0 ? -610.0 : 17000.0;
   w.lapse_m1 = l0; w.lapse_0 = in0 ? l0 : l1; w.lapse_p1 = in0 ? l1 : l2;
   if (__builtin_expect(!(p > p2), 0)) {
+    BLE_STEP_EVENT(3);
     double t_base = t2, p_base = p2, lapse = l2, t_top = t2, p_top = p2;
     int i = 2;
 #pragma unroll 1
@@ -427,6 +437,7 @@ BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, 
   const bool below = q > cur_hi;            // q in the layer with higher pressure
   const bool above = !(q > cur_lo);
   if (__builtin_expect(below || above, 0)) {
+    BLE_STEP_EVENT(2);
     // transition that separates p and q, and the lapse rate on q's side
     const bool at_pb = (j == 0) ? below : (j < 0);
     const double pb = at_pb ? w.pb : w.pt, r_pb = at_pb ? w.r_pb : w.r_pt, tb = at_pb ? w.tb : w.tt;
@@ -1079,11 +1090,14 @@ BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, do
 // acs.py:24-68.  prm1 = pressure_ratio - 1.
 // Fan-efficiency table acs.py:31-41, rows = power 100/200/300/400 W, columns = pressure
 // ratio 1.05 .. 1.35 step 0.025.  `tab` points at 4 x 13 floats (LDS copy in the kernel).
-BLE_CONST_TABLE float kAcsEfficiency[4 * 13] = {
+struct AcsEfficiencyTable { float v[4 * 13]; };
+constexpr AcsEfficiencyTable kAcsEfficiencyValues = {{
     0.4f, 0.4f, 0.3f, 0.2f, 0.2f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
     0.4f, 0.3f, 0.3f, 0.30f, 0.25f, 0.23f, 0.20f, 0.15f, 0.12f, 0.10f, 0.0f, 0.0f, 0.0f,
     0.0f, 0.3f, 0.25f, 0.25f, 0.25f, 0.20f, 0.20f, 0.20f, 0.2f, 0.15f, 0.13f, 0.12f, 0.11f,
-    0.0f, 0.23f, 0.23f, 0.23f, 0.23f, 0.23f, 0.20f, 0.20f, 0.20f, 0.18f, 0.16f, 0.15f, 0.13f};
+    0.0f, 0.23f, 0.23f, 0.23f, 0.23f, 0.23f, 0.20f, 0.20f, 0.20f, 0.18f, 0.16f, 0.15f, 0.13f}};
+BLE_CONST_TABLE AcsEfficiencyTable kAcsEfficiencyTable = kAcsEfficiencyValues;
+#define kAcsEfficiency (kAcsEfficiencyTable.v)
 // fp64 versions for the transition (the mass flow feeds rho V - m); table entries are exact in fp32
 BLE_FN double acs_power_f64(double prm1) {
   const double seg1 = d_fma(prm1 - 0.05, 200.0 / 0.15, 100.0);
@@ -1112,20 +1126,38 @@ BLE_FN double acs_efficiency_f64(const float* tab, double prm1, double power) {
 // acs.py:44-68 `fill_value=None` / the flat end segments of the power curve).  Identical to the two-table
 // form to 1e-16 (tests: probe vs oracle); 3 LDS reads + 5 FMAs instead of two dependent table walks.
 constexpr int kAcsPolyDoubles = 12 * 6;
-BLE_FN void acs_build_poly(const float* tab, int i, double* c) {
-  const double x0 = 0.05 + 0.025 * (double)i;
-  const double w0 = acs_power_f64(x0), w1 = (acs_power_f64(x0 + 0.025) - w0) * 40.0;
-  const double wm = acs_power_f64(x0 + 0.0125);
-  int iy = (int)d_max(d_min((wm - 100.0) * 0.01, 3.0), 0.0); iy = iy > 2 ? 2 : iy;
-  const double a0 = (w0 - 100.0) * 0.01 - (double)iy, a1 = w1 * 0.01;
-  const double z00 = (double)tab[iy * 13 + i], z01 = (double)tab[iy * 13 + i + 1];
-  const double z10 = (double)tab[iy * 13 + 13 + i], z11 = (double)tab[iy * 13 + 14 + i];
-  const double l0 = z00, l1 = (z01 - z00) * 40.0, h0 = z10, h1 = (z11 - z10) * 40.0;
-  const double e0 = l0 + a0 * (h0 - l0), e1 = l1 + a0 * (h1 - l1) + a1 * (h0 - l0), e2 = a1 * (h1 - l1);
-  c[0] = e0 * w0 * (1.0 / 3600.0); c[1] = (e0 * w1 + e1 * w0) * (1.0 / 3600.0);
-  c[2] = (e1 * w1 + e2 * w0) * (1.0 / 3600.0); c[3] = e2 * w1 * (1.0 / 3600.0);
-  c[4] = w0; c[5] = w1;
+// The 12 x 6 coefficients are a COMPILE-TIME table (constexpr evaluation: plain IEEE double arithmetic, no FMA
+// contraction, the same numbers on the device and in the host build of the test tooling); the transition copies it from
+// constant memory into LDS at kernel entry instead of rebuilding it per launch.
+struct AcsPolyTable { double c[kAcsPolyDoubles]; };
+constexpr double acs_power_constexpr(double prm1) {        // acs.py:44-50 == acs_power_f64
+  const double w = prm1 <= 0.2 ? (prm1 - 0.05) * (200.0 / 0.15) + 100.0 : (prm1 - 0.2) * (100.0 / 0.05) + 300.0;
+  return w > 400.0 ? 400.0 : (w < 100.0 ? 100.0 : w);
 }
+constexpr AcsPolyTable make_acs_poly_table() {
+  AcsPolyTable t = {};
+  for (int i = 0; i < 12; ++i) {
+    double* c = t.c + 6 * i;
+    const double x0 = 0.05 + 0.025 * (double)i;
+    const double w0 = acs_power_constexpr(x0), w1 = (acs_power_constexpr(x0 + 0.025) - w0) * 40.0;
+    const double wm = acs_power_constexpr(x0 + 0.0125);
+    double fy = (wm - 100.0) * 0.01;
+    fy = fy > 3.0 ? 3.0 : (fy < 0.0 ? 0.0 : fy);
+    int iy = (int)fy; iy = iy > 2 ? 2 : iy;
+    const double a0 = (w0 - 100.0) * 0.01 - (double)iy, a1 = w1 * 0.01;
+    const float* tab = kAcsEfficiencyValues.v;
+    const double z00 = (double)tab[iy * 13 + i], z01 = (double)tab[iy * 13 + i + 1];
+    const double z10 = (double)tab[iy * 13 + 13 + i], z11 = (double)tab[iy * 13 + 14 + i];
+    const double l0 = z00, l1 = (z01 - z00) * 40.0, h0 = z10, h1 = (z11 - z10) * 40.0;
+    const double e0 = l0 + a0 * (h0 - l0), e1 = l1 + a0 * (h1 - l1) + a1 * (h0 - l0), e2 = a1 * (h1 - l1);
+    c[0] = e0 * w0 * (1.0 / 3600.0); c[1] = (e0 * w1 + e1 * w0) * (1.0 / 3600.0);
+    c[2] = (e1 * w1 + e2 * w0) * (1.0 / 3600.0); c[3] = e2 * w1 * (1.0 / 3600.0);
+    c[4] = w0; c[5] = w1;
+  }
+  return t;
+}
+constexpr AcsPolyTable kAcsPolyValues = make_acs_poly_table();
+BLE_CONST_TABLE AcsPolyTable kAcsPoly = kAcsPolyValues;
 BLE_FN void acs_down_poly(const double* poly, double prm1, double* power_w, double* mdot) {
   int i = (int)((prm1 - 0.05) * 40.0);             // truncation: [-1, 1) -> 0
   i = i < 0 ? 0 : (i > 11 ? 11 : i);

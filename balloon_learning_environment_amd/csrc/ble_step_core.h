@@ -30,20 +30,64 @@ struct EnvConst {
   float lat0_deg, lng0_deg, ir, alpha;
   int64_t start_unix;
 };
-// What depends on the per-episode constants only: evaluated once per launch by the fused multi-step
-// kernel (two pows, one sincos per agent step otherwise).
+// What depends on the per-episode constants only (two pows, a sincos, two square roots): the atmosphere's transition
+// pressures, the station latitude's sine and cosine, the earth-IR heat per unit area.  Constant over an episode, so it is
+// kept in HBM next to the state (`ble_state_f32.episode_cache`, [kEpisodeCacheRows][n] doubles, coalesced): ble_reset_f32
+// fills it, and a transition whose cached entry was computed for other constants -- a caller edited alpha / the centre /
+// the IR by hand, or never reset on the device -- recomputes and stores it itself.  The entry is keyed by the bit
+// patterns of (alpha, centre latitude, upwelling IR); an all-zero (freshly allocated) row never matches.
 struct EnvHoisted {
   AtmBase atm;
   double sin_lat0, cos_lat0;
   double q_earth;          // earth-IR heat per unit area (thermal.py:209-213): a function of the episode's IR alone
   uint32_t flags;          // its total_absorptivity range check
 };
+constexpr int kEpisodeCacheRows = 7;    // p1, p2, sin lat0, cos lat0, q_earth, key (alpha | lat0), key (IR | valid | flags)
 BLE_FN EnvHoisted hoist_constants(const EnvConst& c) {
   EnvHoisted h;
   h.atm = atm_base((double)c.alpha);
   sincos_f64((double)c.lat0_deg * (kPiD / 180.0), &h.sin_lat0, &h.cos_lat0);
   h.flags = 0;
   h.q_earth = earth_heat_per_area_f64((double)c.ir, &h.flags);
+  return h;
+}
+BLE_FN uint32_t float_bits(float v) { uint32_t u; __builtin_memcpy(&u, &v, 4); return u; }
+BLE_FN void episode_cache_keys(const EnvConst& c, uint64_t* k1, uint64_t* k2) {
+  *k1 = ((uint64_t)float_bits(c.alpha) << 32) | (uint64_t)float_bits(c.lat0_deg);
+  *k2 = ((uint64_t)float_bits(c.ir) << 32) | 0x80000000ull;
+}
+BLE_FN void episode_cache_store(double* cache, int64_t n, int64_t i, const EnvConst& c, const EnvHoisted& h) {
+  uint64_t k1, k2;
+  episode_cache_keys(c, &k1, &k2);
+  k2 |= (uint64_t)(h.flags & 0x7fffffffu);
+  double d1, d2;
+  __builtin_memcpy(&d1, &k1, 8); __builtin_memcpy(&d2, &k2, 8);
+  cache[i] = h.atm.p1; cache[n + i] = h.atm.p2; cache[2 * n + i] = h.sin_lat0; cache[3 * n + i] = h.cos_lat0;
+  cache[4 * n + i] = h.q_earth; cache[5 * n + i] = d1; cache[6 * n + i] = d2;
+}
+// the seven cached doubles of a lane, requested together with the state
+struct EpisodeCacheRow { double v[kEpisodeCacheRows]; };
+BLE_FN EpisodeCacheRow episode_cache_load(const double* cache, int64_t n, int64_t i) {
+  EpisodeCacheRow r;
+#pragma unroll
+  for (int k = 0; k < kEpisodeCacheRows; ++k) r.v[k] = cache[k * n + i];
+  return r;
+}
+BLE_FN bool episode_cache_hit(const EpisodeCacheRow& r, const EnvConst& c) {
+  uint64_t k1, k2, g1, g2;
+  episode_cache_keys(c, &k1, &k2);
+  __builtin_memcpy(&g1, &r.v[5], 8); __builtin_memcpy(&g2, &r.v[6], 8);
+  return g1 == k1 && (g2 & 0xffffffff80000000ull) == k2;
+}
+// the cheap, alpha-only part of AtmBase (lapse rates, layer-top temperatures) around the two cached transition pressures
+BLE_FN EnvHoisted hoisted_from_cache(const EpisodeCacheRow& r, const EnvConst& c) {
+  EnvHoisted h;
+  atm_base_linear((double)c.alpha, &h.atm);
+  h.atm.p1 = r.v[0]; h.atm.p2 = r.v[1];
+  h.sin_lat0 = r.v[2]; h.cos_lat0 = r.v[3]; h.q_earth = r.v[4];
+  uint64_t g2;
+  __builtin_memcpy(&g2, &r.v[6], 8);
+  h.flags = (uint32_t)(g2 & 0x7fffffffull);
   return h;
 }
 
@@ -123,6 +167,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     bool near;
     SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
     if (__builtin_expect(near, 0)) {
+      BLE_STEP_EVENT(0);
       const double dk = 10.0 * (double)kk;
       r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
                     c.start_unix + (int64_t)(t_start + 10 * kk));
@@ -214,6 +259,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     {
       double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
       if (__builtin_expect(p_new > cur_hi || !(p_new > cur_lo), 0)) {
+        BLE_STEP_EVENT(1);
         const int lay_new = atm_window_layer(win, p_new);
         const bool low_pair = (lay + lay_new) < 0;            // crossing pb (else pt)
         anchor_p = low_pair ? win.pb : win.pt;

@@ -45,11 +45,17 @@ def ptr(t) -> int:
   return 0 if t is None else t.data_ptr()
 
 
-def state_struct(tensors):
-  """BleStateF32 from {field: torch tensor} (contiguous, right dtype, same device)."""
+def state_struct(tensors, episode_cache=None):
+  """BleStateF32 from {field: torch tensor} (contiguous, right dtype, same device); `episode_cache`: the optional
+  [EPISODE_CACHE_ROWS, n] float64 tensor of per-episode derived constants (zero-initialised; opaque)."""
   ptrs = {}
+  n = None
   for name in _abi.FIELD_NAMES:
     t = tensors[name]
     assert t.is_contiguous() and t.dtype == torch_dtype(_abi.FIELD_DTYPES[name]), name
     ptrs[name] = t.data_ptr()
-  return _abi.state_struct(ptrs)
+    n = t.numel()
+  if episode_cache is not None:
+    assert episode_cache.is_contiguous() and episode_cache.dtype == torch.float64
+    assert tuple(episode_cache.shape) == (_abi.EPISODE_CACHE_ROWS, n)
+  return _abi.state_struct(ptrs, 0 if episode_cache is None else episode_cache.data_ptr())

@@ -294,7 +294,7 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     from balloon_learning_environment_amd import device as dev
     assert sim.n == 1 and sim.device == self._sim.device
     self._sim.state = sim.state
-    self._sim._struct = dev.state_struct(sim.state)
+    self._sim._struct = dev.state_struct(sim.state, getattr(sim, 'episode_cache', None))
     self._bound = True
 
   def observe_bound(self, observation: simulator_data.SimulatorObservation) -> None:
@@ -308,7 +308,7 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     import torch
     from balloon_learning_environment_amd import device as dev
     self._sim.state = {name: t.clone() for name, t in self._sim.state.items()}
-    self._sim._struct = dev.state_struct(self._sim.state)
+    self._sim._struct = dev.state_struct(self._sim.state, self._sim.episode_cache)
     self._bound = False
 
   def observe(self, observation: simulator_data.SimulatorObservation) -> None:

@@ -64,7 +64,11 @@ class VecSimulator:
       self.episode = torch.zeros(self.n, dtype=torch.int32, device=self.device)   # per-env episode counter
     self.grid: Optional[torch.Tensor] = None
     self.grid_env_stride = 0
-    self._struct = dev.state_struct(self.state)
+    # per-episode derived constants (atmosphere transition pressures, station sin / cos, earth-IR heat): filled by the reset
+    # kernel, re-derived by the step kernel itself wherever an entry does not match the constants above -- never stale
+    with torch.cuda.device(self.device):
+      self.episode_cache = torch.zeros(_abi.EPISODE_CACHE_ROWS, self.n, dtype=torch.float64, device=self.device)
+    self._struct = dev.state_struct(self.state, self.episode_cache)
     self._gp = None                 # WindGP history ring (allocated by the first observe())
     self._obs_reset = None          # envs whose history must restart at the next observe()
 

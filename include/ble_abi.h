@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 2: ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
+/* 2: ble_state_f32 gained the optional episode_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
  *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
 #define BLE_ABI_VERSION 2
 
@@ -102,7 +102,15 @@ typedef struct ble_state_f32 {
   uint8_t* alt_fsm;      /* 0 NOMINAL 1 LOW 2 VERY_LOW         (altitude_safety.py:40-44) */
   uint8_t* env_fsm;      /* 0 NOMINAL 1 LOW_CRITICAL 2 LOW 3 HIGH 4 HIGH_CRITICAL (envelope_safety.py:45-50) */
   uint8_t* power_paused; /* PowerSafetyLayer.navigation_is_paused */
+  /* OPTIONAL (may be NULL), opaque: [BLE_EPISODE_CACHE_ROWS][n] doubles, zero-initialised by the caller.  What the
+   * transition derives from the per-episode constants alone (the atmosphere's two transition pressures -- two pows --,
+   * sin / cos of the centre latitude, the earth-IR heat per unit area), keyed by the bit patterns of (alpha,
+   * center_lat_deg, upwelling_infrared).  ble_reset_f32 fills it; ble_step_f32 / ble_step_n_f32 read it and, where an
+   * entry does not match the constants in `st` (edited by hand, or never reset on the device), recompute and store it --
+   * so it can never go stale.  NULL: recomputed by every launch (0.8 us per launch). */
+  double* episode_cache;
 } ble_state_f32;
+#define BLE_EPISODE_CACHE_ROWS 7
 
 int ble_abi_version(void);
 

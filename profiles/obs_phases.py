@@ -1,4 +1,4 @@
-"""Per-phase instruction counts of ble_observe_kernel (profile build: hipcc ... -DBLE_OBS_PHASE_PROFILE, see
+"""Per-phase instruction counts of ble_observe_kernel (profile build: profiles/build_variant.sh phase '-DBLE_OBS_INSTR_HEADER="../../profiles/instr/ble_observe_instr.h"' -DBLE_OBS_PHASE_PROFILE, see
 profiles/prof_obs_phases.sh).  After the window is full, launches that return after phase k (stop code in bits 8.. of
 `append`; nothing is committed) are issued in the order stop = 1, 2, 3 (three each), then one complete launch: the counters of a phase are
 differences of consecutive groups.   python profiles/obs_phases.py [n_envs]"""

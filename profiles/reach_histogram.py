@@ -1,4 +1,4 @@
-"""Histogram of reachable levels per environment after 125 steps (needs a -DBLE_OBS_TIMING build: BLE_HIP_LIB=...).
+"""Histogram of reachable levels per environment after 125 steps (needs the BLE_OBS_TIMING profiling build, see profiles/instr/ble_observe_instr.h: BLE_HIP_LIB=...).
    python profiles/reach_histogram.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')

@@ -17,7 +17,7 @@ gen = torch.Generator(device='cuda'); gen.manual_seed(7)
 acts = torch.randint(0, 3, (32, n), dtype=torch.uint8, device='cuda', generator=gen)
 rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
 waves = (n + 63) // 64
-dbg = torch.zeros((waves, 8), dtype=torch.int64, device='cuda')
+dbg = torch.zeros((waves, 48), dtype=torch.int64, device='cuda')
 
 
 def launch(k):
@@ -31,9 +31,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 snap = {k: t.clone() for k, t in sim.state.items()}
 names = ['state loads landed', 'ACS cubics + barrier', 'per-episode constants', 'agent steps', 'stores acknowledged']
-for k in (1, 1, 32):
+for k in (1, 1, 2, 32):
   for key, t in sim.state.items():
     t.copy_(snap[key])
+  dbg.zero_()
   torch.cuda.synchronize()
   e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
   e0.record(); launch(k); e1.record(); torch.cuda.synchronize()
@@ -54,6 +55,19 @@ for k in (1, 1, 32):
   for j, name in enumerate(names):
     us = d[:, 2 + j] / np.median(clk)
     print(f'    {name:24s}{q(us)}  us')
-  late = np.argsort(dur)[-5:]
-  print('    slowest waves:', [(int(w), round(float(dur[w]), 2), round(float(d[w, 5] / np.median(clk)), 2)) for w in late], '(wave, duration, its agent-step phase)')
+  c = np.median(clk)
+  steps_us = d[:, 8:8 + k] / c                     # [waves, k]
+  print(f'    agent step 0 of the launch {q(steps_us[:, 0])}  us')
+  if k > 1:
+    print(f'    agent steps 1 .. {k - 1}         {q(steps_us[:, 1:].ravel())}  us   (every wave, every step)')
+    print(f'    per-wave mean of steps 1..  {q(steps_us[:, 1:].mean(1))}  us')
+  ev = d[:, 40:44]
+  ev_names = ['exact solar chain', 'layer transition crossed', 'p +- 1 Pa straddles a transition', 'window above 21 km']
+  for j, name in enumerate(ev_names):
+    hit = ev[:, j] > 0
+    print(f'    {name:34s} lanes {int(ev[:, j].sum()):7d} in {int(hit.sum()):5d} waves; agent-step phase of those waves {np.median(d[hit, 5]) / c if hit.any() else 0:8.2f} us median vs {np.median(d[~hit, 5]) / c if (~hit).any() else 0:8.2f} without')
+  by_xcd = [np.median(dur[np.arange(waves) % 8 == x]) for x in range(8)]
+  print('    median wave duration by workgroup index mod 8 (XCD):', ' '.join(f'{v:.2f}' for v in by_xcd))
+  late = np.argsort(dur)[-6:]
+  print('    slowest waves (wave, duration us, agent-step phase us, events):', [(int(w), round(float(dur[w]), 2), round(float(d[w, 5] / c), 2), [int(v) for v in ev[w]]) for w in late])
 sim.check_errors()

@@ -1,5 +1,5 @@
 """Per-launch timing of ble_observe_f32 while the WindGP window fills, and -- with a timing build
-(hipcc ... -DBLE_OBS_TIMING -o lib.so; BLE_HIP_LIB=lib.so) -- the in-kernel cycle marks quoted in
+(profiles/build_variant.sh obs_timing '-DBLE_OBS_INSTR_HEADER="../../profiles/instr/ble_observe_instr.h"' -DBLE_OBS_TIMING; BLE_HIP_LIB=build_ab/libble_obs_timing.so) -- the in-kernel cycle marks quoted in
 DESIGN.md 3b.  Usage: python profiles/time_observe.py [n_envs]"""
 import time, numpy as np, torch, sys
 sys.path.insert(0, '.')

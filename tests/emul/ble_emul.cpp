@@ -14,8 +14,7 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
                              const float* wind_uv, float* reward, uint8_t* terminal, uint8_t* effective_action,
                              uint32_t* err_flags, int64_t n, int substeps) {
   uint32_t flags_all = 0;
-  double acs_poly[kAcsPolyDoubles];
-  for (int k = 0; k < 12; ++k) acs_build_poly(kAcsEfficiency, k, acs_poly + 6 * k);
+  const double* acs_poly = kAcsPoly.c;       // the compile-time table (the device copies it into LDS)
   for (int64_t i = 0; i < n; ++i) {
     if (st->status[i] != kOk) { reward[i] = 0.0f; terminal[i] = 1; if (effective_action) effective_action[i] = action[i]; continue; }
     EnvRegs s;

@@ -830,3 +830,50 @@ def test_config4_share_32768_envs_per_env_grids_sampled(ble):
   print(f'config 4 share: {len(idx)} sampled envs x {k} steps on per-env grids, worst {worst:.2g}; fused == unfused for all {n}')
   # distinct forecasts really are in use
   assert not torch.equal(grids[0], grids[n - 1])
+
+
+def test_episode_cache_is_transparent(ble):
+  """ble_state_f32.episode_cache (per-episode derived constants kept in HBM): a launch that reads them from the cache is
+  bit-identical to one that derives them (cache NULL); the reset kernel fills the cache; constants edited by hand
+  afterwards are noticed (the entry is keyed by their bit patterns) and never produce a stale result."""
+  import ctypes
+  from balloon_learning_environment_amd import device as dev, reset_host
+  n = 4096
+  field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(5).integers(0, 3, (6, n)).astype(np.uint8)).cuda()
+
+  def fly(use_cache, edit=False, device_reset=False):
+    sim = ble.VecSimulator(n)
+    sim.set_grid(field)
+    if device_reset:
+      sim.reset_device(seed=5)
+      keys = sim.episode_cache[6].view(torch.int64)
+      assert bool(((keys >> 31) & 1).all())                  # every entry valid straight after the reset kernel
+    else:
+      sim.set_state(reset_host.sample_initial_state(n, seed=5))
+      assert float(sim.episode_cache.abs().sum()) == 0.0     # host-set state: nothing cached yet
+    if not use_cache:
+      sim._struct = dev.state_struct(sim.state, None)
+    out = []
+    for k in range(6):
+      if edit and k == 3:                                    # new per-episode constants under the cache's feet
+        sim.state['alpha'].copy_(1.0 - sim.state['alpha'])
+        sim.state['center_lat_deg'].mul_(-0.5)
+        sim.state['upwelling_infrared'].add_(7.0)
+      r, t = sim.step(acts[k])
+      out.append((r.clone(), t.clone()))
+    sim.check_errors()
+    return sim.get_state(), out, sim
+
+  for kw in (dict(), dict(edit=True), dict(device_reset=True), dict(device_reset=True, edit=True)):
+    a, ra, sim_a = fly(True, **kw)
+    b, rb, _ = fly(False, **kw)
+    for k in a:
+      np.testing.assert_array_equal(a[k], b[k], err_msg=f'{kw} {k}')
+    for (r1, t1), (r2, t2) in zip(ra, rb):
+      assert torch.equal(r1, r2) and torch.equal(t1, t2)
+    live = torch.from_numpy(a['status'] == 0).cuda()
+    keys = sim_a.episode_cache[6].view(torch.int64)
+    assert bool(((keys >> 31) & 1)[live].all())              # every live lane's entry is valid after a step
+    ir_bits = sim_a.state['upwelling_infrared'].view(torch.int32).to(torch.int64) & 0xffffffff
+    assert torch.equal(((keys >> 32) & 0xffffffff)[live], ir_bits[live])     # ... and belongs to the CURRENT constants

@@ -33,8 +33,10 @@ def test_state_struct_matches_header_order():
   header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
   body = header[header.index('typedef struct ble_state_f32 {'):header.index('} ble_state_f32;')]
   names = re.findall(r'\*\s*(\w+);', body)
-  assert tuple(names) == _abi.FIELD_NAMES
-  assert ctypes.sizeof(_abi.BleStateF32) == 8 * len(_abi.FIELD_NAMES)
+  assert tuple(names) == _abi.FIELD_NAMES + ('episode_cache',)        # the per-env arrays, then the optional cache
+  assert [f[0] for f in _abi.BleStateF32._fields_] == names
+  assert ctypes.sizeof(_abi.BleStateF32) == 8 * len(names)
+  assert int(re.search(r'#define BLE_EPISODE_CACHE_ROWS (\d+)', header).group(1)) == _abi.EPISODE_CACHE_ROWS
 
 
 def test_gp_history_struct_matches_header_order():
