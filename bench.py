@@ -365,7 +365,7 @@ def being_profiled():
   return any(k.startswith('ROCPROF') for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
 
 
-def measure_traffic(kernel, cmd, launches_per_group, groups, timeout_s=240):
+def measure_traffic(kernel, cmd, launches_per_group, groups, timeout_s=100):
   """HBM bytes per launch of `kernel`, measured now: FETCH_SIZE and WRITE_SIZE in two separate rocprofv3 --pmc passes of
   `cmd`; the LAST groups x launches_per_group dispatches of the kernel are the steady-state / timed ones.  Units: the
   counters are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read, hence the guide's
@@ -501,7 +501,7 @@ def main():
   else:
     traffic_note = 'not measured in this run (N > 1, --no-extras or --traffic off)'
   issue = None
-  for tag in ('r02', 'r01'):
+  for tag in ('r03', 'r02', 'r01'):
     try:
       d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
       per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)

@@ -5,7 +5,7 @@
 # combine with sys/hip/hsa/memory-copy tracing.  Raw output goes to gpurun_out/ (scratch);
 # profiles/summarize.py turns it into the committed profiles/<tag>_*.json / .md files.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -13,6 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 # ---- transition kernel: the headline leg of bench.py alone (5 repetitions of 192 steps = 30 launches of 32 steps)
 BENCH="python $ROOT/bench.py --steps 192 --warmup 32 --reps 5 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+# ---- the driver's shape: python bench.py --gpus 1 --steps 20 --warmup 5 (one 20-step launch per timed region), headline leg alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -o trace20 -- python $ROOT/bench.py --steps 20 --warmup 5 --reps 9 --no-extras > $OUT/trace20.log 2>&1
+# ---- one launch per agent step (policy in the loop): 300 launches of ble_step_f32
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o trace1 -- python $ROOT/profiles/step_single.py 65536 > $OUT/trace1.log 2>&1
 run_pmc () {  # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH > $OUT/$name.log 2>&1

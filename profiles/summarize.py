@@ -31,6 +31,19 @@ def main(tag):
     if 'ble_step_kernel' in r['Name']:
       out['kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
                              'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3}
+  # the driver-shaped run (one 20-step launch per region) and the one-launch-per-step run, from their raw kernel traces
+  for sub, key, pick in (('trace20', 'kernel_trace_20_step_launches', lambda durs: durs[1:]),       # [0] is the 5-step warm-up launch
+                         ('trace1', 'kernel_trace_1_step_launches', lambda durs: durs[44:])):        # 44 warm-up launches
+    p = os.path.join(base, sub, f'{sub}_kernel_trace.csv')
+    if os.path.exists(p):
+      with open(p) as f:
+        durs = [(int(r['Start_Timestamp']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+                for r in csv.DictReader(f) if 'ble_step_kernel' in r['Kernel_Name']]
+      durs = pick([d for _, d in sorted(durs)])
+      if durs:
+        srt = sorted(durs)
+        out[key] = {'launches': len(durs), 'avg_us': sum(durs) / len(durs), 'median_us': srt[len(srt) // 2], 'min_us': srt[0], 'max_us': srt[-1]}
+        md.append(f"| `ble_step_kernel`, {key.replace('kernel_trace_', '').replace('_', ' ')} | {len(durs)} | {out[key]['avg_us']:.2f} | {srt[0]:.2f} | {srt[-1]:.2f} | (raw trace: {sub}) |")
   counters = collections.defaultdict(list)
   meta = {}
   for name in sorted(os.listdir(base)):

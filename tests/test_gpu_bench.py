@@ -38,6 +38,13 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks_and_gathers_the_partia
   out3 = _bench(['--gpus', '2', '--steps', '40', '--warmup', '5', '--reps', '3', '--no-extras', '--config', '3'], {'BLE_DIST_BACKEND': 'gloo'})
   assert out3['n_gpus'] == 2 and out3['config']['global_envs'] == 65536 and out3['config']['envs_per_gpu'] == 32768
   assert out3['config']['exchanges']['gathers_per_timed_region'] == 2 and out3['scaling'] == 'strong'
+  # configs[4]: every rank decodes its own per-environment forecasts (no broadcast); 8 192 per rank here instead of 32 768
+  # (two ranks share one GPU: 2 x 10.4 GB of grids would fit, the decode time would not be worth it in a test)
+  out4 = _bench(['--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '3', '--no-extras', '--config', '4', '--envs-per-gpu', '8192'],
+                {'BLE_DIST_BACKEND': 'gloo'})
+  assert out4['n_gpus'] == 2 and out4['config']['per_env_grids'] and out4['config']['global_envs'] == 2 * 8192
+  assert 'no broadcast' in out4['config']['parallelism'] and out4['config']['exchanges']['gathers_per_timed_region'] == 1
+  assert out4['config']['decode_ms'] > 0
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
