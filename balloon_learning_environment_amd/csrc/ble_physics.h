@@ -25,6 +25,9 @@
 #ifndef BLE_STEP_EVENT
 #define BLE_STEP_EVENT(i) do {} while (0)
 #endif
+#ifndef BLE_STEP_TICK
+#define BLE_STEP_TICK(i) do {} while (0)
+#endif
 
 namespace ble {
 

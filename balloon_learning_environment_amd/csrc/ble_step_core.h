@@ -98,6 +98,7 @@ BLE_FN EnvHoisted hoisted_from_cache(const EpisodeCacheRow& r, const EnvConst& c
 BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int action, const WindCorners& corners, const WindQuery& wq,
                       float noise_u, float noise_v, int substeps, const double* acs_poly, float* reward,
                       uint32_t* flags) {
+  BLE_STEP_TICK(0);
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   const float p0_in = s.p;
   double p = (double)s.p;
@@ -114,15 +115,18 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
   eff = envelope_safety(eff, s.sp, &s.env_fsm);
   eff = altitude_safety(eff, altitude, &s.alt_fsm);
+  BLE_STEP_TICK(1);
 
   // ---- per-step constants
   const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
   const Ephemeris e0 = ephemeris(t0);
   const float step_s = (float)(10 * substeps);
   const float fl0 = e0.flux, dfl = e0.flux_rate * 10.0f;
+  BLE_STEP_TICK(2);
   float u, v;
   wind_blend_corners(corners, wq, &u, &v);         // wind at the PRE-step position/time
   u += noise_u; v += noise_v;                      // WindField.get_ground_truth = forecast + noise
+  BLE_STEP_TICK(3);
   // Solar geometry: 1 - sin(el_uncorrected) at substep indices 0, n/2, n in fp64, then a
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
   float oms_c0, oms_c1, oms_c2;
@@ -157,6 +161,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
     oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
   }
+  BLE_STEP_TICK(4);
   // Sun at stride k of this step: quadratic through the three fp64 nodes, fp32; the reference's
   // own fp64 chain on the (rare) strides where a solar threshold is within the fp32 floor.
   // (position and time at the START of the step, by value: the reward below calls this after s has been advanced)
@@ -275,6 +280,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (terminal) { ++k; break; }          // balloon.py:327-328
   }
+  BLE_STEP_TICK(5);
   // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments;
   // k >= 1 here: substeps >= 1 is checked by the host entry point).  The burst test is the loop's own
   // `!(sp_new <= 2380)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
@@ -305,6 +311,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     }
   }
   *reward = r;
+  BLE_STEP_TICK(6);
   return eff;
 }
 

@@ -17,7 +17,7 @@ gen = torch.Generator(device='cuda'); gen.manual_seed(7)
 acts = torch.randint(0, 3, (32, n), dtype=torch.uint8, device='cuda', generator=gen)
 rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
 waves = (n + 63) // 64
-dbg = torch.zeros((waves, 48), dtype=torch.int64, device='cuda')
+dbg = torch.zeros((waves, 64), dtype=torch.int64, device='cuda')
 
 
 def launch(k):
@@ -66,7 +66,12 @@ for k in (1, 1, 2, 32):
   for j, name in enumerate(ev_names):
     hit = ev[:, j] > 0
     print(f'    {name:34s} lanes {int(ev[:, j].sum()):7d} in {int(hit.sum()):5d} waves; agent-step phase of those waves {np.median(d[hit, 5]) / c if hit.any() else 0:8.2f} us median vs {np.median(d[~hit, 5]) / c if (~hit).any() else 0:8.2f} without')
+  sec = d[:, 48:54] / c / k
+  sec_names = ['atmosphere + safety layers', 'ephemeris', 'wind blend', 'three solar nodes', 'substep loop (18)', 'status + reward']
+  print('    sections of an agent step, us per step (median over waves):', ', '.join(f'{nm} {np.median(sec[:, j]):.2f}' for j, nm in enumerate(sec_names)),
+        f'; sum {np.median(sec.sum(1)):.2f}')
   by_xcd = [np.median(dur[np.arange(waves) % 8 == x]) for x in range(8)]
+  print('    median shader clock by workgroup index mod 8 (XCD), cycles/us:', ' '.join(f'{np.median(clk[np.arange(waves) % 8 == x]):.0f}' for x in range(8)))
   print('    median wave duration by workgroup index mod 8 (XCD):', ' '.join(f'{v:.2f}' for v in by_xcd))
   late = np.argsort(dur)[-6:]
   print('    slowest waves (wave, duration us, agent-step phase us, events):', [(int(w), round(float(dur[w]), 2), round(float(d[w, 5] / c), 2), [int(v) for v in ev[w]]) for w in late])
