@@ -77,3 +77,22 @@ def test_wind_noise_structure():
   vals = np.array([wind_noise([xx], [0.0], [9000.0], [0], seed=3)[0] for xx in xs[:200]])
   assert np.array_equal(vals[0], path[0])
   assert np.abs(np.diff(vals[:, 0])).max() < 0.2
+
+
+def test_decoder_resize_matches_pytorch_half_pixel_bilinear():
+  """The decoder's 7 x 7 -> 23 x 23 resize (generative/vae.py:157-160: jax.image.resize(..., 'linear')) is half-pixel
+  linear upsampling with edge-clamped taps.  jax is absent, so the oracle's restatement is anchored on an INDEPENDENT
+  implementation of the same published operator: torch.nn.functional.interpolate(mode='bilinear',
+  align_corners=False) (no antialiasing; for upsampling jax's default antialias has no effect).  This does not pin jax
+  itself (row f3 stays "parity unpinned"): it shows that the restatement is the operator it claims to be."""
+  import torch
+  import vae_oracle
+  rng = np.random.default_rng(11)
+  psi = rng.standard_normal((3, 7, 7, 90))
+  w = vae_oracle.resize_weights()
+  ours = np.einsum('ai,bj,nijf->nabf', w, w, psi)
+  t = torch.from_numpy(psi).permute(0, 3, 1, 2)                       # [n, f, 7, 7], float64
+  theirs = torch.nn.functional.interpolate(t, size=(23, 23), mode='bilinear', align_corners=False).permute(0, 2, 3, 1).numpy()
+  assert np.abs(ours - theirs).max() < 1e-12
+  # and the separable weights are a partition of unity with at most two taps per output pixel
+  assert np.allclose(w.sum(1), 1.0) and ((w > 0).sum(1) <= 2).all()
