@@ -27,6 +27,7 @@ BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH = 64, 128
 OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
+NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
 EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
@@ -83,7 +84,7 @@ def lib():
   l.ble_reset_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
   l.ble_observe_f32.argtypes = [st, _vp, _i64, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
   l.ble_decode_flow_fields_f32.argtypes = [_vp, _vp, _i64, _vp]
-  l.ble_wind_noise_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
+  l.ble_wind_noise_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _vp, _i64, _vp]
   l.ble_forecast_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_forecast_column_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]

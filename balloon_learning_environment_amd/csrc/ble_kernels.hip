@@ -335,12 +335,16 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
                                                              const float* __restrict__ pressure,
                                                              const int32_t* __restrict__ elapsed, unsigned long long seed,
                                                              const uint32_t* __restrict__ episode, int mode,
-                                                             float* __restrict__ noise_uv, int64_t n) {
+                                                             uint32_t* harmonic_cache, float* __restrict__ noise_uv, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float u, v;
   if (mode == 0) {
-    wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, episode ? episode[i] : 0u, &u, &v);
+    const uint32_t ep = episode ? episode[i] : 0u;
+    if (harmonic_cache != nullptr)
+      wind_noise_cached(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, harmonic_cache, n, &u, &v);
+    else
+      wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, &u, &v);
   } else {
     u = simplex4(x[i], y[i], pressure[i], (float)elapsed[i] * (1.0f / 3600.0f), (uint32_t)seed);
     v = 0.0f;
@@ -558,12 +562,12 @@ int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, v
 }
 
 int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
-                       unsigned long long seed, const uint32_t* episode, int mode, float* noise_uv, int64_t n,
-                       void* stream) {
+                       unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
+                       float* noise_uv, int64_t n, void* stream) {
   if (!x_m || !y_m || !pressure || !elapsed_s || !noise_uv || n < 0 || mode < 0 || mode > 1) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(ble_wind_noise_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x_m, y_m, pressure,
-             elapsed_s, seed, episode, mode, noise_uv, n);
+             elapsed_s, seed, episode, mode, harmonic_cache, noise_uv, n);
   return launch_status();
 }
 

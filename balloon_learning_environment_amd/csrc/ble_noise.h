@@ -35,6 +35,9 @@ BLE_FN Harmonic harmonic_params(int comp, int h) {
 constexpr float kSimplex4Variance = 0.088392f;   // of simplex4() below: measured 0.0889 (tests/test_gpu_noise.py) == the reference's SIMPLEX_VARIANCE (:70)
 constexpr float kNoiseVariance = 1.02f;          // simplex_wind_noise.py:73
 
+BLE_FN uint32_t float_bits_u32(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); return b; }
+BLE_FN float u32_bits_float(uint32_t b) { float v; __builtin_memcpy(&v, &b, 4); return v; }
+
 BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
   uint32_t h = seed;
   h = (h ^ (uint32_t)i) * 0x9E3779B1u; h ^= h >> 15;
@@ -82,28 +85,81 @@ BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed) {
   return 27.0f * n;
 }
 
-// NoisyWindComponent.get_noise (:190-211) for both components; the per-harmonic generator seeds and
-// offsets (NoisyWindHarmonic.reset :97-114) come from the environment's Philox stream.
+// NoisyWindHarmonic.reset (:97-114): the generator seed and the random offset of one harmonic, from the environment's
+// Philox stream (10 harmonics per environment, in the order u0..u4, v0..v4).
+struct HarmonicDraw { uint32_t hseed; float ox, oy, op, ot; };
+BLE_FN HarmonicDraw harmonic_draw(Philox& g) {
+  HarmonicDraw d;
+  d.hseed = philox_u32(g);
+  d.ox = (float)(2.0 * philox_uniform(g) - 1.0); d.oy = (float)(2.0 * philox_uniform(g) - 1.0);
+  d.op = (float)(2.0 * philox_uniform(g) - 1.0); d.ot = (float)(2.0 * philox_uniform(g) - 1.0);
+  return d;
+}
+// NoisyWindComponent.get_noise (:190-211): the weighted harmonics of one component, variance-adjusted.
+struct NoiseAccumulator { float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f; };
+BLE_FN void noise_add_harmonic(NoiseAccumulator& a, int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure,
+                               float t_h) {
+  const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
+  const Harmonic hp = harmonic_params(comp, h);
+  const float nz = magnitude * simplex4(x_km / hp.x_spacing + d.ox, y_km / hp.y_spacing + d.oy, pressure / hp.p_spacing + d.op,
+                                        t_h / hp.t_spacing + d.ot, d.hseed);
+  a.acc = f_fma(nz, hp.weight, a.acc); a.wsum += hp.weight; a.w2sum = f_fma(hp.weight, hp.weight, a.w2sum);
+}
+BLE_FN float noise_finish(const NoiseAccumulator& a) { return a.acc / a.wsum * sqrtf(a.wsum / a.w2sum); }
+
+// Both components at one point, the harmonics' seeds and offsets drawn on the spot (50 Philox draws).
 BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env,
                                   uint32_t episode, float* u, float* v) {
   Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
   const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
-  const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
   float out[2];
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
-    float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f;
+    NoiseAccumulator a;
 #pragma unroll 1
     for (int h = 0; h < 5; ++h) {
-      const uint32_t hseed = philox_u32(g);
-      const float ox = (float)(2.0 * philox_uniform(g) - 1.0), oy = (float)(2.0 * philox_uniform(g) - 1.0),
-                  op = (float)(2.0 * philox_uniform(g) - 1.0), ot = (float)(2.0 * philox_uniform(g) - 1.0);
-      const Harmonic hp = harmonic_params(comp, h);
-      const float nz = magnitude * simplex4(x_km / hp.x_spacing + ox, y_km / hp.y_spacing + oy,
-                                            pressure / hp.p_spacing + op, t_h / hp.t_spacing + ot, hseed);
-      acc = f_fma(nz, hp.weight, acc); wsum += hp.weight; w2sum = f_fma(hp.weight, hp.weight, w2sum);
+      const HarmonicDraw d = harmonic_draw(g);
+      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
     }
-    out[comp] = acc / wsum * sqrtf(wsum / w2sum);
+    out[comp] = noise_finish(a);
+  }
+  *u = out[0]; *v = out[1];
+}
+
+// The same with the draws kept in HBM between calls, as the reference keeps them in its NoisyWindHarmonic objects between
+// resets: `cache` is [kNoiseCacheRows][n] 32-bit words (coalesced), rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic k
+// = 5 comp + h, rows 50 .. 52 the key (episode + 1, seed lo, seed hi) the entry was drawn for; an entry drawn for another
+// (seed, episode) -- or an all-zero, fresh one -- is redrawn and stored.  Same values as wind_noise(), bit for bit.
+constexpr int kNoiseCacheRows = 53;
+BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint32_t episode,
+                              uint32_t* cache, int64_t n, float* u, float* v) {
+  uint32_t* mine = cache + env;
+  const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
+  if (!(mine[50 * n] == k0 && mine[51 * n] == k1 && mine[52 * n] == k2)) {
+    Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
+#pragma unroll 1
+    for (int k = 0; k < 10; ++k) {
+      const HarmonicDraw d = harmonic_draw(g);
+      uint32_t* row = mine + (int64_t)(5 * k) * n;
+      row[0] = d.hseed; row[n] = float_bits_u32(d.ox); row[2 * n] = float_bits_u32(d.oy); row[3 * n] = float_bits_u32(d.op);
+      row[4 * n] = float_bits_u32(d.ot);
+    }
+    mine[50 * n] = k0; mine[51 * n] = k1; mine[52 * n] = k2;
+  }
+  const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
+  float out[2];
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    NoiseAccumulator a;
+#pragma unroll 1
+    for (int h = 0; h < 5; ++h) {
+      const uint32_t* row = mine + (int64_t)(5 * (5 * comp + h)) * n;
+      HarmonicDraw d;
+      d.hseed = row[0]; d.ox = u32_bits_float(row[n]); d.oy = u32_bits_float(row[2 * n]); d.op = u32_bits_float(row[3 * n]);
+      d.ot = u32_bits_float(row[4 * n]);
+      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
+    }
+    out[comp] = noise_finish(a);
   }
   *u = out[0]; *v = out[1];
 }

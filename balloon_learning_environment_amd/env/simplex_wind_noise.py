@@ -35,7 +35,7 @@ class SimplexWindNoise:
     self._t[0] = int(elapsed_time.total_seconds())
     b = self._buf
     _lib.check(self._lib.ble_wind_noise_f32(b[0:1].data_ptr(), b[1:2].data_ptr(), b[2:3].data_ptr(), self._t.data_ptr(),
-                                            self._seed, 0, 0, b[4:6].data_ptr(), 1, dev.stream_ptr(self.device)),
+                                            self._seed, 0, 0, 0, b[4:6].data_ptr(), 1, dev.stream_ptr(self.device)),
                'ble_wind_noise_f32')
     u, v = b[4:6].cpu().numpy()
     return wind_field.WindVector(units.Velocity(mps=float(u)), units.Velocity(mps=float(v)))

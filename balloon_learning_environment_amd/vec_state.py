@@ -69,6 +69,7 @@ class VecSimulator:
     with torch.cuda.device(self.device):
       self.episode_cache = torch.zeros(_abi.EPISODE_CACHE_ROWS, self.n, dtype=torch.float64, device=self.device)
     self._struct = dev.state_struct(self.state, self.episode_cache)
+    self._noise_cache = None        # per-episode draws of the wind noise's harmonics (allocated by the first wind_noise())
     self._gp = None                 # WindGP history ring (allocated by the first observe())
     self._obs_reset = None          # envs whose history must restart at the next observe()
 
@@ -159,10 +160,12 @@ class VecSimulator:
     `noise_uv` input of step() / observe().  One noise field per (seed, env, episode)."""
     if out is None:
       out = torch.empty(self.n, 2, dtype=torch.float32, device=self.device)
+    if self._noise_cache is None:      # the harmonics' seeds and offsets, drawn once per (seed, episode) like the reference's
+      self._noise_cache = torch.zeros(_lib.NOISE_CACHE_ROWS, self.n, dtype=torch.int32, device=self.device)
     s = self.state
     code = self.lib.ble_wind_noise_f32(s['x'].data_ptr(), s['y'].data_ptr(), s['pressure'].data_ptr(),
                                        s['time_elapsed_s'].data_ptr(), int(seed) & (2 ** 64 - 1), self.episode.data_ptr(),
-                                       0, out.data_ptr(), self.n, dev.stream_ptr(self.device))
+                                       0, self._noise_cache.data_ptr(), out.data_ptr(), self.n, dev.stream_ptr(self.device))
     _lib.check(code, 'ble_wind_noise_f32')
     return out
 

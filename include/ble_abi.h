@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 2: ble_state_f32 gained the optional episode_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
+/* 2: ble_state_f32 gained the optional episode_cache; ble_wind_noise_f32 the optional harmonic_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
  *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
 #define BLE_ABI_VERSION 2
 
@@ -253,10 +253,16 @@ int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, v
  * Five harmonics per component with the reference's weights and spacings; generator seeds and
  * offsets per (seed, env, episode[i]).  The 4-D noise primitive is NOT opensimplex 0.3's (absent,
  * unpinned): see csrc/ble_noise.h.  mode 1 is a test probe of the raw primitive.
+ *   harmonic_cache  optional (may be NULL), opaque: [BLE_NOISE_CACHE_ROWS][n] 32-bit words, zero-initialised by the caller.
+ *                   The reference draws a harmonic's generator seed and offsets once per reset and keeps them in its
+ *                   NoisyWindHarmonic objects (simplex_wind_noise.py:97-114); this is where they are kept here, keyed by
+ *                   (seed, episode[i]) -- an entry drawn for another key is redrawn (50 Philox draws) and stored.
+ *                   NULL: redrawn by every call.  Same values either way.
  */
+#define BLE_NOISE_CACHE_ROWS 53
 int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
-                       unsigned long long seed, const uint32_t* episode, int mode, float* noise_uv, int64_t n,
-                       void* stream);
+                       unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
+                       float* noise_uv, int64_t n, void* stream);
 
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,

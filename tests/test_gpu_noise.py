@@ -24,7 +24,7 @@ def raw(lib, pts, seed):
   d = [torch.from_numpy(np.ascontiguousarray(pts[:, k], np.float32)).cuda() for k in range(3)]
   t = torch.from_numpy(np.ascontiguousarray(pts[:, 3] * 3600.0).astype(np.int32)).cuda()
   out = torch.empty(n, 2, device='cuda')
-  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), t.data_ptr(), seed, 0, 1, out.data_ptr(), n, 0) == 0
+  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), t.data_ptr(), seed, 0, 1, 0, out.data_ptr(), n, 0) == 0
   torch.cuda.synchronize()
   return out[:, 0].cpu().numpy().astype(np.float64)
 
@@ -116,8 +116,29 @@ def test_device_noise_equals_host_build(lib):
   d = [torch.from_numpy(a).cuda() for a in (x, y, p)]
   td, epd = torch.from_numpy(t).cuda(), torch.from_numpy(ep.astype(np.int32)).cuda()
   out = torch.empty(n, 2, device='cuda')
-  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), td.data_ptr(), 77, epd.data_ptr(), 0,
+  assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), td.data_ptr(), 77, epd.data_ptr(), 0, 0,
                                 out.data_ptr(), n, 0) == 0
   torch.cuda.synchronize()
   want = host.wind_noise(x, y, p, t, seed=77, episode=ep)
   np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5)
+  # the harmonics' draws kept in HBM between calls (harmonic_cache): the same bits as drawing them on the spot -- on the
+  # first call (entries drawn and stored), on the second (read back), after the episode counters moved on (redrawn for the
+  # lanes whose key changed) and with another seed
+  from balloon_learning_environment_amd import _lib
+  cache = torch.zeros(_lib.NOISE_CACHE_ROWS, n, dtype=torch.int32, device='cuda')
+  got = torch.empty(n, 2, device='cuda')
+
+  def both(seed, episodes):
+    assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), td.data_ptr(), seed, episodes.data_ptr(), 0, 0,
+                                  out.data_ptr(), n, 0) == 0
+    assert lib.ble_wind_noise_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), td.data_ptr(), seed, episodes.data_ptr(), 0,
+                                  cache.data_ptr(), got.data_ptr(), n, 0) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, got)
+  both(77, epd); both(77, epd)
+  assert torch.equal(cache[50], epd + 1)
+  epd2 = epd.clone(); epd2[::3] += 1
+  both(77, epd2)
+  assert torch.equal(cache[50], epd2 + 1)
+  both(2 ** 40 + 5, epd2)
+  assert int(cache[52][0]) == 2 ** 8 and int(cache[51][0]) == 5
