@@ -131,6 +131,34 @@ class VecBalloonArena:
     if self.per_env_fields and self._stale is not None:
       torch.maximum(self._stale, mask, out=self._stale)
 
+  # ---- checkpoint / resume ------------------------------------------------------------
+  def state_dict(self) -> dict:
+    """The simulator's state_dict plus what this arena adds: the seed bookkeeping of reset(), the wind field (host copy)
+    and its noise seed, the per-environment grids' refresh state.  torch.save-able."""
+    wf = self.wind_field
+    noise = getattr(wf, 'noise_model', None)
+    return {'sim': self.sim.state_dict(), 'seed0': self._seed0, 'reset_count': self._reset_count, 'seed': getattr(self, '_seed', None),
+            'field_epoch': self._field_epoch, 'per_env_fields': self.per_env_fields,
+            # (torch tensors and plain Python scalars only: loadable with torch.load's default weights_only=True)
+            'field': None if getattr(wf, 'field', None) is None else torch.from_numpy(np.array(wf.field, copy=True)),
+            'noise_seed': None if noise is None else noise._seed,
+            'stale': None if self._stale is None else self._stale.clone()}
+
+  def load_state_dict(self, d: dict) -> None:
+    assert bool(d['per_env_fields']) == self.per_env_fields, 'checkpoint and arena differ in per_env_fields'
+    self._seed0, self._reset_count, self._seed, self._field_epoch = d['seed0'], d['reset_count'], d['seed'], d['field_epoch']
+    if d['field'] is not None:
+      self.wind_field.set_field(d['field'].cpu().numpy())
+    noise = getattr(self.wind_field, 'noise_model', None)
+    if noise is not None and d['noise_seed'] is not None:
+      noise._seed = d['noise_seed']
+    self.sim.load_state_dict(d['sim'])
+    if self.per_env_fields:
+      self._grids = self.sim.grid                          # the restored per-environment grids
+      self._stale = d['stale'].clone() if d['stale'] is not None else torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+    else:
+      self.sim.set_grid(self.wind_field.grid)
+
   def step(self, actions: torch.Tensor, noise_uv: Optional[torch.Tensor] = None):
     """actions: uint8 device tensor [N] -> (reward [N] f32, terminal [N] u8) device tensors."""
     return self.sim.step(actions, noise_uv)

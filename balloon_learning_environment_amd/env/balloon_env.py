@@ -178,6 +178,19 @@ class VecBalloonEnv:
     self._steps_since_refresh = 0
     return self.arena.observe(self._noise_now())
 
+  def state_dict(self) -> dict:
+    """Checkpoint of the whole batch (balloons, episode counters, wind field(s), WindGP histories, seeds): a run restored
+    with load_state_dict() continues bit for bit -- same observations, rewards, terminals, auto-resets."""
+    return {'arena': self.arena.state_dict(), 'seed': self._seed, 'reseed': bool(getattr(self, '_reseed', False)),
+            'steps_since_refresh': self._steps_since_refresh,
+            'noise': None if self._noise is None else self._noise.clone()}
+
+  def load_state_dict(self, d: dict) -> None:
+    self.arena.load_state_dict(d['arena'])
+    self._seed, self._reseed, self._steps_since_refresh = int(d['seed']), bool(d['reseed']), int(d['steps_since_refresh'])
+    self._noise = None if d['noise'] is None else d['noise'].clone()
+    self._graph = None                       # a captured graph holds the old buffers: capture again after a resume
+
   def check_errors(self) -> None:
     """Synchronises and raises what the reference would have raised inside step / observe since the last
     call (non-finite state, pressure out of range, WindGP window overflow, failed pressure-range search...)."""

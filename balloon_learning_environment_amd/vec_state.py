@@ -124,23 +124,7 @@ class VecSimulator:
     env) and slide it from step to step instead of refactoring the whole window every call."""
     assert self.grid is not None, 'Must call set_grid (reset) before observe.'
     if self._gp is None:
-      with torch.cuda.device(self.device):
-        cap = _lib.GP_CAPACITY
-        self._gp = dict(xyp=torch.zeros(self.n, cap, 3, dtype=torch.float32, device=self.device),
-                        elapsed_s=torch.zeros(self.n, cap, dtype=torch.int32, device=self.device),
-                        err_uv=torch.zeros(self.n, cap, 2, dtype=torch.float32, device=self.device),
-                        count=torch.zeros(self.n, dtype=torch.int32, device=self.device))
-        if carry_factor:
-          self._gp['chol'] = torch.zeros(self.n, _lib.GP_CHOL_STRIDE, dtype=torch.float64, device=self.device)
-          self._gp['n_chol'] = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-        self._obs_reset = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
-        self._gp_struct = _abi.BleGpHistoryF32()
-        for name, ct in (('xyp', ctypes.c_float), ('elapsed_s', ctypes.c_int32), ('err_uv', ctypes.c_float),
-                         ('count', ctypes.c_int32), ('chol', ctypes.c_double), ('n_chol', ctypes.c_int32)):
-          if name not in self._gp:
-            continue
-          setattr(self._gp_struct, name, ctypes.cast(ctypes.c_void_p(self._gp[name].data_ptr()), ctypes.POINTER(ct)))
-        self._gp_struct.chol_stride = _lib.GP_CHOL_STRIDE if carry_factor else 0
+      self._allocate_history(carry_factor)
     if noise_uv is not None:
       assert noise_uv.dtype == torch.float32 and noise_uv.is_contiguous() and tuple(noise_uv.shape) == (self.n, 2)
     if out is None:
@@ -153,6 +137,60 @@ class VecSimulator:
     _lib.check(code, 'ble_observe_f32')
     self._obs_reset.zero_()         # stream-ordered after the kernel
     return out
+
+
+  def _allocate_history(self, carry_factor: bool) -> None:
+    """The WindGP ring of every environment (and, with carry_factor, the HBM-resident factor slab)."""
+    with torch.cuda.device(self.device):
+      cap = _lib.GP_CAPACITY
+      self._gp = dict(xyp=torch.zeros(self.n, cap, 3, dtype=torch.float32, device=self.device),
+                      elapsed_s=torch.zeros(self.n, cap, dtype=torch.int32, device=self.device),
+                      err_uv=torch.zeros(self.n, cap, 2, dtype=torch.float32, device=self.device),
+                      count=torch.zeros(self.n, dtype=torch.int32, device=self.device))
+      if carry_factor:
+        self._gp['chol'] = torch.zeros(self.n, _lib.GP_CHOL_STRIDE, dtype=torch.float64, device=self.device)
+        self._gp['n_chol'] = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+      self._obs_reset = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+      self._gp_struct = _abi.BleGpHistoryF32()
+      for name, ct in (('xyp', ctypes.c_float), ('elapsed_s', ctypes.c_int32), ('err_uv', ctypes.c_float),
+                       ('count', ctypes.c_int32), ('chol', ctypes.c_double), ('n_chol', ctypes.c_int32)):
+        if name not in self._gp:
+          continue
+        setattr(self._gp_struct, name, ctypes.cast(ctypes.c_void_p(self._gp[name].data_ptr()), ctypes.POINTER(ct)))
+      self._gp_struct.chol_stride = _lib.GP_CHOL_STRIDE if carry_factor else 0
+
+  # ------------------------------------------------------------------ checkpoint / resume
+  def state_dict(self) -> dict:
+    """Everything a resumed run needs to continue bit for bit: the balloon state, the per-environment episode counters,
+    the wind grid(s), the WindGP history (ring, carried factor, pending resets) and the live-environment counter --
+    clones, on the simulator's device.  The derived caches (per-episode constants, noise draws) are not part of it: they
+    are keyed by what they were derived from and refill themselves."""
+    d = {'n': self.n, 'state': {k: t.clone() for k, t in self.state.items()}, 'episode': self.episode.clone(),
+         'active_slots': self.active_slots.clone(), 'err_flags': self.err_flags.clone(),
+         'grid': None if self.grid is None else self.grid.clone(), 'grid_env_stride': self.grid_env_stride, 'gp': None}
+    if self._gp is not None:
+      d['gp'] = {k: t.clone() for k, t in self._gp.items()}
+      d['obs_reset'] = self._obs_reset.clone()
+    return d
+
+  @_on_own_device
+  def load_state_dict(self, d: dict) -> None:
+    """Restores a state_dict() of a simulator of the same size (in place: device pointers handed out before stay valid)."""
+    assert int(d['n']) == self.n, f"checkpoint of {d['n']} environments, simulator of {self.n}"
+    for k, t in self.state.items():
+      t.copy_(d['state'][k])
+    self.episode.copy_(d['episode']); self.active_slots.copy_(d['active_slots']); self.err_flags.copy_(d['err_flags'])
+    if d['grid'] is not None:
+      self.set_grid(d['grid'].clone(), per_env=int(d['grid_env_stride']) != 0)
+    if d['gp'] is None:
+      self._gp, self._obs_reset = None, None
+    else:
+      carried = 'chol' in d['gp']
+      if self._gp is None or ('chol' in self._gp) != carried:
+        self._allocate_history(carried)
+      for k, t in self._gp.items():
+        t.copy_(d['gp'][k])
+      self._obs_reset.copy_(d['obs_reset'])
 
   @_on_own_device
   def wind_noise(self, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -362,3 +362,45 @@ def test_env_on_a_non_current_device(mods):
   per_env = balloon_env.VecBalloonEnv(64, seed=3, device='cuda:1', per_env_fields=True)      # the decode path (GEMMs + ble_decode_flow_fields_f32)
   per_env.reset(); per_env.step(torch.ones(64, dtype=torch.uint8, device='cuda:1')); per_env.check_errors()
   assert torch.cuda.current_device() == 0
+
+
+@pytest.mark.parametrize('per_env_fields', [False, True])
+def test_vec_env_checkpoint_resumes_bit_for_bit(mods, per_env_fields, tmp_path):
+  """state_dict() / load_state_dict(): a batch restored into a DIFFERENT env object (other seed, other history) continues
+  exactly like the original -- observations, rewards, terminals, auto-resets with their new episodes, wind noise."""
+  import torch
+  _, balloon_env, _, _ = mods
+  n = 192
+  gen = torch.Generator(device='cuda'); gen.manual_seed(4)
+  acts = torch.randint(0, 3, (20, n), dtype=torch.uint8, device='cuda', generator=gen)
+  env = balloon_env.VecBalloonEnv(n, seed=9, per_env_fields=per_env_fields, field_refresh_every=4)
+  env.reset()
+  for k in range(6):
+    if k == 3:
+      env.arena.sim.state['battery_charge'][:24] = 1e-3          # some episodes end and restart before the checkpoint ...
+    env.step(acts[k])
+  path = str(tmp_path / 'ckpt.pt')
+  torch.save(env.state_dict(), path)
+
+  def fly(e):
+    out = []
+    for k in range(6, 20):
+      if k == 11:
+        e.arena.sim.state['battery_charge'][40:72] = 1e-3        # ... and after it
+      o, r, t = e.step(acts[k])
+      out.append((o.clone(), r.clone(), t.clone()))
+    e.check_errors()
+    return out, {k: v.clone() for k, v in e.arena.sim.state.items()}
+
+  a, sa = fly(env)
+  other = balloon_env.VecBalloonEnv(n, seed=1234, per_env_fields=per_env_fields, field_refresh_every=4)
+  other.reset()
+  for k in range(3):
+    other.step(acts[k])
+  other.load_state_dict(torch.load(path))
+  b, sb = fly(other)
+  for (oa, ra, ta), (ob, rb, tb) in zip(a, b):
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb)
+  for k in sa:
+    assert torch.equal(sa[k], sb[k]), k
+  assert sum(int(t.sum()) for _, _, t in a) >= 8                   # episodes did end on the way (the night-side ones of the 32 drained)
