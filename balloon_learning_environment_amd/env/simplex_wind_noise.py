@@ -20,17 +20,24 @@ class SimplexWindNoise:
     self.device = dev.require_gpu(device)
     self._lib = _lib.lib()
     self._seed = None
+    self._last = None
     self._buf = torch.zeros(8, dtype=torch.float32, device=self.device)      # x, y, p | u, v
     self._t = torch.zeros(1, dtype=torch.int32, device=self.device)
 
   def reset(self, key) -> None:
     self._seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
+    self._last = None
 
   @dev.on_own_device
   def get_wind_noise(self, x: units.Distance, y: units.Distance, pressure: float,
                      elapsed_time: dt.timedelta) -> wind_field.WindVector:
     if self._seed is None:
       raise ValueError('Must call reset before get_noise.')            # simplex_wind_noise.py:133-134
+    # the arena asks for the same point twice per step (the observation's measured wind, then the next transition's
+    # ground truth): the second answer is the first one, without a kernel launch and a read-back
+    query = (float(x.m), float(y.m), float(pressure), int(elapsed_time.total_seconds()), self._seed)
+    if getattr(self, '_last', None) is not None and self._last[0] == query:
+      return self._last[1]
     self._buf[:3] = torch.tensor([x.m, y.m, pressure], dtype=torch.float32)
     self._t[0] = int(elapsed_time.total_seconds())
     b = self._buf
@@ -38,4 +45,6 @@ class SimplexWindNoise:
                                             self._seed, 0, 0, 0, b[4:6].data_ptr(), 1, dev.stream_ptr(self.device)),
                'ble_wind_noise_f32')
     u, v = b[4:6].cpu().numpy()
-    return wind_field.WindVector(units.Velocity(mps=float(u)), units.Velocity(mps=float(v)))
+    out = wind_field.WindVector(units.Velocity(mps=float(u)), units.Velocity(mps=float(v)))
+    self._last = (query, out)
+    return out
