@@ -65,11 +65,13 @@ class OutputGatherer:
     self.rank = dist.get_rank() if initialized else 0
     self.dst = dst
     self.is_dst = self.rank == dst
-    self.k = k
+    self.k, self.n_local, self.device = k, n_local, device
     rows = self.world if self.is_dst else 0
+    # receive buffers on rank dst ([world, k, n_local]; empty elsewhere): reward / terminal for gather(), `packed` for gather_packed()
     self.reward = torch.zeros((rows, k, n_local), dtype=torch.float32, device=device)
     self.terminal = torch.zeros((rows, k, n_local), dtype=torch.uint8, device=device)
     self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+    self.packed = None          # [world, 5 k n_local] uint8 on rank dst: the packed blocks of gather_packed
     self.gathers = 0            # exchanges issued by this rank
     self.rows_gathered = 0      # agent steps they carried
 
@@ -98,20 +100,61 @@ class OutputGatherer:
     else:
       self._gather(reward_block, terminal_block, c)
 
+  def gather_packed(self, block: torch.Tensor, c: int) -> None:
+    """ONE exchange per launch instead of two: `block` is the launch's packed output (packed_output_block: the [c, n_local]
+    float32 rewards followed by the [c, n_local] uint8 terminals, 5 c n_local bytes); rank `dst` finds rank r's copy in
+    packed[r][:5 c n_local] (unpack()).  Fewer, larger messages: every point-to-point gather costs its latency once."""
+    nbytes = int(block.numel())
+    assert block.dtype == torch.uint8 and block.is_contiguous() and nbytes == 5 * int(c) * self.n_local and 0 < int(c) <= self.k
+    if self.packed is None:
+      rows = self.world if self.is_dst else 0
+      self.packed = torch.zeros((rows, 5 * self.k * self.n_local), dtype=torch.uint8, device=block.device)
+    self.gathers += 1; self.rows_gathered += int(c)
+    if self.world == 1:
+      self.packed[0][:nbytes].copy_(block)
+      return
+
+    def go():
+      dist.gather(block, [self.packed[r][:nbytes] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
+    if self.stream is not None:
+      self.stream.wait_stream(torch.cuda.current_stream(block.device))
+      with torch.cuda.stream(self.stream):
+        go()
+        block.record_stream(self.stream)
+    else:
+      go()
+
+  def unpack(self, r: int, c: int):
+    """(reward [c, n_local] float32, terminal [c, n_local] uint8) views of rank r's last packed block (rank `dst` only)."""
+    n = self.n_local
+    row = self.packed[r]
+    return row[:4 * c * n].view(torch.float32).view(c, n), row[4 * c * n:5 * c * n].view(c, n)
+
   def wait(self) -> None:
     if self.stream is not None:
       torch.cuda.current_stream(self.reward.device).wait_stream(self.stream)
+
+
+def packed_output_block(c: int, n_local: int, device):
+  """The outputs of one launch of c agent steps in ONE buffer, so that they travel in one message: returns
+  (buffer uint8 [5 c n], reward view float32 [c, n], terminal view uint8 [c, n])."""
+  buf = torch.zeros(5 * c * n_local, dtype=torch.uint8, device=device)
+  return buf, buf[:4 * c * n_local].view(torch.float32).view(c, n_local), buf[4 * c * n_local:].view(c, n_local)
 
 
 def run_region(launches, gatherer: Optional['OutputGatherer']) -> None:
   """One region of a sharded rollout: every launch (a callable that enqueues <= k agent steps of this rank's shard and
   fills its [c, n_local] reward / terminal blocks) is followed by the gather of exactly those blocks to the learner
   rank -- the last, shorter launch of a region included -- and the region ends when the exchanges have been waited for.
-  `launches`: iterable of (launch, reward_block, terminal_block).  bench.py's timed region and the gloo tests run this."""
-  for launch, reward_block, terminal_block in launches:
-    launch()
+  `launches`: iterable of (launch, reward_block, terminal_block) or, for one exchange per launch, (launch, packed buffer,
+  reward view, terminal view) from packed_output_block.  bench.py's timed region and the gloo tests run this."""
+  for item in launches:
+    item[0]()
     if gatherer is not None:
-      gatherer.gather(reward_block, terminal_block)
+      if len(item) == 3:
+        gatherer.gather(item[1], item[2])                 # (launch, reward rows, terminal rows): two exchanges
+      else:
+        gatherer.gather_packed(item[1], item[2].shape[0])  # (launch, packed buffer, reward view, terminal view): one
   if gatherer is not None:
     gatherer.wait()
 

@@ -162,20 +162,19 @@ class Rollout:
       self.sim.set_grid(shared_field)
     gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
     self.actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
-    self.rewards = torch.zeros((k_total, n), dtype=torch.float32, device=device)
-    self.terminals = torch.zeros((k_total, n), dtype=torch.uint8, device=device)
     self.gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world) if world > 1 else None
     self.launches_per_region = -(-steps // GATHER_EVERY)
 
   def plan(self, k0, k1):
     """The launches of steps k0 .. k1 - 1, prepared once (VecSimulator.prepare_step_n: checks and argument marshalling
-    happen here, outside any timed region): (launch, reward rows, terminal rows) per launch."""
+    happen here, outside any timed region): (launch, packed output buffer, reward rows, terminal rows) per launch.  A
+    launch's rewards and terminals live in ONE buffer (5 B per env-step) so that they go to rank 0 in one message."""
     out = []
     k = k0
     while k < k1:
       c = min(GATHER_EVERY, k1 - k)
-      a, r, t = self.actions[k:k + c], self.rewards[k:k + c], self.terminals[k:k + c]
-      out.append((self.sim.prepare_step_n(a, r, t, None, substeps=self.substeps), r, t))
+      buf, r, t = self.bdist.packed_output_block(c, self.n, self.device)
+      out.append((self.sim.prepare_step_n(self.actions[k:k + c], r, t, None, substeps=self.substeps), buf, r, t))
       k += c
     return out
 
@@ -216,7 +215,7 @@ class Rollout:
         continue
       wall.append(self.bdist.max_over_ranks(dt, self.device))
       # an env is stepped iff it was not terminal after the previous step; counted outside the timed region
-      term = self.terminals[self.warmup:self.warmup + self.steps - 1].to(torch.int64).sum(dim=1)
+      term = torch.cat([item[3] for item in plan])[:self.steps - 1].to(torch.int64).sum(dim=1)
       l = live0 + float((self.n - term).sum().item())
       live.append(self.bdist.sum_over_ranks(l, self.device))
     self.sim.check_errors()
@@ -560,7 +559,7 @@ def main():
                    'substeps_per_step': args.substeps, 'live_env_fraction_end': hs['live_env_fraction_end'],
                    'per_env_grids': bool(args.config == 4 or args.per_env_grids), 'decode_ms': hs['decode_ms'],
                    'parallelism': f'env-sharded x{world}, ' + ('no broadcast (per-rank decode)' if args.config == 4 else 'grid broadcast once') +
-                                  (f', reward/terminal rows of every launch (<= {GATHER_EVERY} steps) gathered to rank 0 on a side stream' if world > 1
+                                  (f', reward + terminal rows of every launch (<= {GATHER_EVERY} steps) gathered to rank 0 as ONE packed message on a side stream' if world > 1
                                    else ', single rank: nothing to exchange'),
                    # counted by the gatherer inside the timed regions (0 on one rank): never an exchange that did not run
                    'exchanges': {'gathers_per_timed_region': hs['gathers_per_region'], 'agent_step_rows_gathered_per_timed_region': hs['rows_gathered_per_region'],

@@ -175,6 +175,21 @@ def _region_worker(rank, world, port, out_dir):
           c = item[1].shape[0]
           got.append((g.reward[:, :c].clone(), g.terminal[:, :c].clone()))
       out[steps] = dict(gathers=g.gathers, rows=g.rows_gathered, got=got)
+      # the same region with ONE packed message per launch (what bench.py sends): rewards and terminals of a launch in one buffer
+      gp = bdist.OutputGatherer(every, n_local, 'cpu', world)
+      got_p, k = [], 0
+      while k < steps:
+        c = min(every, steps - k)
+        buf, r, t = bdist.packed_output_block(c, n_local, 'cpu')
+
+        def launch(k0=k, c=c, r=r, t=t):
+          r.copy_(torch.arange(lo, lo + n_local, dtype=torch.float32)[None, :] + 1e6 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None])
+          t.copy_(((torch.arange(lo, lo + n_local)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 5 == 0).to(torch.uint8))
+        bdist.run_region([(launch, buf, r, t)], gp)
+        if rank == 0:
+          got_p.append([tuple(v.clone() for v in gp.unpack(q, c)) for q in range(world)])
+        k += c
+      out[('packed', steps)] = dict(gathers=gp.gathers, rows=gp.rows_gathered, got=got_p)
     torch.save(out, os.path.join(out_dir, f'g{rank}.pt'))
   finally:
     dist.destroy_process_group()
@@ -195,6 +210,16 @@ def test_partial_block_is_gathered_inside_the_region_world2(tmp_path):
       want = torch.arange(8192, dtype=torch.float32)[None, :] + 1e6 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None]
       assert torch.equal(glob, want)
       tglob = torch.cat([term[r] for r in range(world)], dim=1)
+      assert torch.equal(tglob, ((torch.arange(8192)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 5 == 0).to(torch.uint8))
+      k0 += c
+    # one packed message per launch: the same rows arrive, half the exchanges' messages
+    for o in outs:
+      assert o[('packed', steps)]['gathers'] == len(blocks) and o[('packed', steps)]['rows'] == steps
+    k0 = 0
+    for per_rank, c in zip(outs[0][('packed', steps)]['got'], blocks):
+      glob = torch.cat([per_rank[r][0] for r in range(world)], dim=1)
+      assert torch.equal(glob, torch.arange(8192, dtype=torch.float32)[None, :] + 1e6 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None])
+      tglob = torch.cat([per_rank[r][1] for r in range(world)], dim=1)
       assert torch.equal(tglob, ((torch.arange(8192)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 5 == 0).to(torch.uint8))
       k0 += c
 
