@@ -49,7 +49,7 @@ def test_station_seeker_episode_teacher_forced(vec_state):
   sim.set_grid(torch.from_numpy(field).cuda())
   import features_oracle
   fo = features_oracle.FeatureOracle(field, float(np.float32(g['alpha'][0])))
-  worst_obs = 0.0; worst_ref = 0.0; worst_sens = 0.0; worst_state = 0.0
+  worst_obs = 0.0; worst_ref = 0.0; worst_sens = 0.0; worst_state = 0.0; compared = 0
   for i in range(n):
     row = helpers.feature_row(g, 0, i)
     sim.set_state(_arrays(row))
@@ -62,17 +62,21 @@ def test_station_seeker_episode_teacher_forced(vec_state):
     unreachable = lambda f: (f[16::3] == 0) & (f[17::3] == 1) & (f[18::3] == 1)
     np.testing.assert_array_equal(unreachable(obs), unreachable(want), err_msg=f'step {i}')
     np.testing.assert_array_equal(obs[8:14], want[8:14], err_msg=f'step {i}')
-    # the oracle on the device's own inputs (float32 state and noise): every entry within 1e-5
+    # the oracle on the device's own inputs (float32 state and noise): every entry within 1e-5.  The oracle sees every
+    # observation; its 1099-vector (a 120 x 120 GP fit in NumPy: 66 ms) is formed on the first 130 steps -- the window
+    # fills and starts to slide --, then on every 8th step, and on the last 20.
     fo.observe({k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in row.items()},
                g['noise_uv'][0, i].astype(np.float32).astype(np.float64))
-    same = fo.features().astype(np.float64)
-    err = np.abs(obs.astype(np.float64) - same)
-    assert err.max() <= 1e-5, (i, err.max(), int(err.argmax()))
-    # the reference's vector directly: 1e-5 + what the float32 rounding of the inputs does to the reference itself
-    sens = np.abs(same - want.astype(np.float64))
-    err_ref = np.abs(obs.astype(np.float64) - want.astype(np.float64))
-    assert (err_ref - sens).max() <= 1e-5, (i, err_ref.max(), int((err_ref - sens).argmax()))
-    worst_obs = max(worst_obs, float(err.max())); worst_ref = max(worst_ref, float(err_ref.max())); worst_sens = max(worst_sens, float(sens.max()))
+    if i < 130 or i % 8 == 0 or i >= n - 20:
+      same = fo.features().astype(np.float64)
+      err = np.abs(obs.astype(np.float64) - same)
+      assert err.max() <= 1e-5, (i, err.max(), int(err.argmax()))
+      # the reference's vector directly: 1e-5 + what the float32 rounding of the inputs does to the reference itself
+      sens = np.abs(same - want.astype(np.float64))
+      err_ref = np.abs(obs.astype(np.float64) - want.astype(np.float64))
+      assert (err_ref - sens).max() <= 1e-5, (i, err_ref.max(), int((err_ref - sens).argmax()))
+      worst_obs = max(worst_obs, float(err.max())); worst_ref = max(worst_ref, float(err_ref.max())); worst_sens = max(worst_sens, float(sens.max()))
+      compared += 1
     # the transition with the agent's action and the ground-truth wind
     act = torch.tensor([g['actions'][0, i]], dtype=torch.uint8).cuda()
     reward, terminal = sim.step(act, noise)
@@ -85,7 +89,8 @@ def test_station_seeker_episode_teacher_forced(vec_state):
     for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
       assert int(got[k][0]) == int(g[k][0, i + 1]), (i, k)
     assert abs(float(reward[0]) - g['reward'][0, i]) <= 2e-5 and int(terminal[0]) == 0
-  print(f'F13 teacher-forced: 960/960 actions equal; worst |obs diff| {worst_obs:.2e} vs the oracle on the same inputs, '
+  assert compared >= 250
+  print(f'F13 teacher-forced: 960/960 actions equal; on {compared} steps worst |obs diff| {worst_obs:.2e} vs the oracle on the same inputs, '
         f'{worst_ref:.2e} vs the reference (own input-rounding sensitivity {worst_sens:.2e}); worst state rel err {worst_state:.2e}')
 
 
