@@ -1,0 +1,94 @@
+"""One-element calls into the device functions of the transition (`ble_probe_*`, include/ble_abi.h): what the per-function
+mirror modules next to this file (standard_atmosphere, solar, thermal, acs, stable_init) are made of.  Each call runs
+exactly the lane function `ble_step_f32` uses, on a batch of one, and reads the result back.  Needs a HIP device."""
+import numpy as np
+import torch
+
+from balloon_learning_environment_amd import _lib
+from balloon_learning_environment_amd import device as dev
+from balloon_learning_environment_amd import vec_state
+
+
+def _f32(*values):
+  return [torch.tensor([float(v)], dtype=torch.float32, device='cuda') for v in values]
+
+
+def _out(n=1, dtype=torch.float32):
+  return torch.empty(n, dtype=dtype, device='cuda')
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _flags():
+  return torch.zeros(1, dtype=torch.int32, device='cuda')
+
+
+def _raise(flags):
+  code = int(flags.item())
+  if code:
+    vec_state.raise_for_flags(code)
+
+
+def atmosphere(alpha, pressure):
+  """Atmosphere.at_pressure -> (height m, temperature K); raises like the reference outside the model's range."""
+  dev.require_gpu('cuda')
+  a, p = _f32(alpha, pressure)
+  h, t, flags = _out(), _out(), _flags()
+  _lib.check(_lib.lib().ble_probe_atmosphere_f32(a.data_ptr(), p.data_ptr(), h.data_ptr(), t.data_ptr(), flags.data_ptr(), 1,
+                                                 _stream()), 'ble_probe_atmosphere_f32')
+  _raise(flags)
+  return float(h.item()), float(t.item())
+
+
+def solar(lat_deg, lng_deg, unix_s):
+  """solar_calculator at a site -> (refraction-corrected elevation deg, flux W/m^2)."""
+  dev.require_gpu('cuda')
+  la, lo, x, y = _f32(lat_deg, lng_deg, 0.0, 0.0)
+  t = torch.tensor([int(unix_s)], dtype=torch.int64, device='cuda')
+  el, flux = _out(), _out()
+  _lib.check(_lib.lib().ble_probe_solar_f32(la.data_ptr(), lo.data_ptr(), x.data_ptr(), y.data_ptr(), t.data_ptr(), el.data_ptr(),
+                                            flux.data_ptr(), 1, _stream()), 'ble_probe_solar_f32')
+  return float(el.item()), float(flux.item())
+
+
+def solar_power(el_deg, pressure):
+  """-> (attenuation, panel power W)."""
+  dev.require_gpu('cuda')
+  e, p = _f32(el_deg, pressure)
+  att, pw = _out(), _out()
+  _lib.check(_lib.lib().ble_probe_solar_power_f32(e.data_ptr(), p.data_ptr(), att.data_ptr(), pw.data_ptr(), 1, _stream()),
+             'ble_probe_solar_power_f32')
+  return float(att.item()), float(pw.item())
+
+
+def thermal(volume, t_int, t_amb, pressure, el_deg, flux, earth_flux):
+  """d_balloon_temperature_dt [K/s] (envelope mass 68.5 kg, the kernel's constant)."""
+  dev.require_gpu('cuda')
+  args = _f32(volume, t_int, t_amb, pressure, el_deg, flux, earth_flux)
+  out, flags = _out(), _flags()
+  _lib.check(_lib.lib().ble_probe_thermal_f32(*[a.data_ptr() for a in args], out.data_ptr(), flags.data_ptr(), 1, _stream()),
+             'ble_probe_thermal_f32')
+  _raise(flags)
+  return float(out.item())
+
+
+def acs(pressure_ratio):
+  """-> (most efficient power W, fan efficiency at that power, mass flow kg/s)."""
+  dev.require_gpu('cuda')
+  pr, = _f32(pressure_ratio)
+  w, eff, md = _out(), _out(), _out()
+  _lib.check(_lib.lib().ble_probe_acs_f32(pr.data_ptr(), w.data_ptr(), eff.data_ptr(), md.data_ptr(), 1, _stream()), 'ble_probe_acs_f32')
+  return float(w.item()), float(eff.item()), float(md.item())
+
+
+def reset_one(row: dict):
+  """`ble_reset_f32(sample = 0)` on ONE environment whose position, pressure, centre, IR, alpha and start time are those of
+  `row`: the Newton cold start (stable_init.py:132-157) and PowerSafetyLayer's sunrise / sunset search
+  (solar.py:432-483).  Returns the state row after the reset (python scalars)."""
+  sim = vec_state.VecSimulator(1)
+  sim.set_state({k: np.array([v]) for k, v in row.items()})
+  sim.reset_device(seed=0, sample=False)
+  sim.check_errors()
+  return {k: t[0].item() for k, t in sim.state.items()}

@@ -176,3 +176,61 @@ def row_from_state(s: BalloonState, alpha: float) -> dict:
               start_unix=start, time_elapsed_s=elapsed, sunrise_h_rel=sunrise_h - start, sunset_rel=sunset - start,
               status=s.status.value, last_command=int(s.last_command), alt_fsm=s.altitude_safety_layer.state_code,
               env_fsm=s.envelope_safety_layer.state_code, power_paused=int(s.power_safety_layer.navigation_is_paused))
+
+
+# ---- Balloon: the reference's hot-path object (balloon.py:253-328) over the HIP transition -----------------------------
+class Balloon:
+  """`Balloon(balloon_state).simulate_step(wind_vector, atmosphere, action, time_delta)` as in the reference: the three
+  safety layers, then time_delta / stride strides of _simulate_step_internal -- here ONE launch of `ble_step_f32` on a
+  one-environment batch (the wind handed in is constant over the step, like the reference's argument: it goes through the
+  kernel's additive wind input over an all-zero grid).  `self.state` is updated in place.  Needs a HIP device."""
+
+  def __init__(self, balloon_state: BalloonState, device='cuda:0'):
+    self.state = balloon_state
+    self._device, self._sim = device, None
+
+  def simulate_step(self, wind_vector, atmosphere, action: control.AltitudeControlCommand, time_delta: dt.timedelta,
+                    stride: dt.timedelta = dt.timedelta(seconds=10)) -> None:
+    import torch
+    from balloon_learning_environment_amd import vec_state
+    self.state.last_command = control.AltitudeControlCommand(int(action))
+    assert self.state.status == BalloonStatus.OK, (
+        f'Stepping balloon after a terminal event occured. ({self.state.status.name})')          # balloon.py:288-290
+    outer, inner = int(time_delta.total_seconds()), int(stride.total_seconds())
+    assert outer % inner == 0, (f'The outer simulation stride (time_delta={time_delta}) must be a '
+                                f'multiple of the inner simulation stride (stride={stride})')   # balloon.py:316-319
+    if inner != 10:
+      raise NotImplementedError('the transition kernel integrates with the reference\'s default 10 s stride')
+    if self._sim is None:
+      self._sim = vec_state.VecSimulator(1, self._device)
+      self._sim.set_grid(np.zeros(vec_state.GRID_SHAPE, np.float32))
+    sim = self._sim
+    row = row_from_state(self.state, float(atmosphere.alpha))
+    sim.set_state({k: np.array([v]) for k, v in row.items()})
+    wind = torch.tensor([[wind_vector.u.mps, wind_vector.v.mps]], dtype=torch.float32, device=sim.device)
+    sim.step(torch.tensor([int(action)], dtype=torch.uint8, device=sim.device), wind, substeps=outer // inner)
+    sim.check_errors()
+    new = state_from_row({k: t[0].item() for k, t in sim.state.items()})
+    constants = ('envelope_volume_base', 'envelope_volume_dv_pressure', 'envelope_mass', 'envelope_max_superpressure', 'envelope_cod',
+                 'payload_mass', 'nighttime_power_load', 'daytime_power_load', 'acs_valve_hole_diameter', 'battery_capacity',
+                 'mols_lift_gas')
+    for f in dataclasses.fields(BalloonState):           # in place: callers may hold a reference to the state object
+      if f.name not in constants:
+        setattr(self.state, f.name, getattr(new, f.name))
+
+
+def calculate_superpressure_and_volume(mols_lift_gas: float, mols_air: float, internal_temperature: float, pressure: float,
+                                       envelope_volume_base: float, envelope_volume_dv_pressure: float):
+  """balloon.py:552-609 -> (envelope_volume, superpressure), evaluated by the device function the transition uses
+  (`ble_probe_sp_volume_f32`); the flight vehicle's constants are compile-time constants of the kernel."""
+  import torch
+  from balloon_learning_environment_amd import _lib
+  if (mols_lift_gas, envelope_volume_base, envelope_volume_dv_pressure) != (6830.0, 1804, 0.0199):
+    raise NotImplementedError('the kernel is built for the reference flight vehicle (6830 mol He, 1804 m^3, 0.0199 m^3/Pa)')
+  lib = _lib.lib()
+  a = torch.tensor([mols_air, internal_temperature, pressure], dtype=torch.float32, device='cuda')
+  out = torch.empty(2, dtype=torch.float32, device='cuda')
+  _lib.check(lib.ble_probe_sp_volume_f32(a[0:1].data_ptr(), a[1:2].data_ptr(), a[2:3].data_ptr(), out[0:1].data_ptr(),
+                                         out[1:2].data_ptr(), 1, torch.cuda.current_stream().cuda_stream), 'ble_probe_sp_volume_f32')
+  v, sp = out.cpu().tolist()
+  return v, sp

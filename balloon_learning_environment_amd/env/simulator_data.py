@@ -4,12 +4,14 @@ from typing import Any
 
 from balloon_learning_environment_amd.env import wind_field
 from balloon_learning_environment_amd.env.balloon import balloon
+from balloon_learning_environment_amd.env.balloon import standard_atmosphere
 
 
 @dataclasses.dataclass
-class Atmosphere:
+class Atmosphere(standard_atmosphere.AtmosphereOps):
   """Per-episode atmosphere: the reference object holds lapse-rate tables; all of them are a
-  function of one scalar `alpha` (standard_atmosphere.py:76-87), which is what the kernel reads."""
+  function of one scalar `alpha` (standard_atmosphere.py:76-87), which is what the kernel reads.  `at_pressure` /
+  `at_height` like the reference's (env/balloon/standard_atmosphere.py here)."""
   alpha: float
 
 

@@ -1,0 +1,155 @@
+"""The reference's own unit tests, written against this package's mirror of the reference modules
+(env/balloon/{standard_atmosphere, solar, thermal, acs, stable_init}.py) -- same calls, same literals
+(tests/golden/reference_known_answers.json: the inline known answers of the reference's *_test.py files, as data) --
+with every call landing in the device functions of the transition (`ble_probe_*`, `ble_reset_f32`)."""
+import datetime as dt
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from balloon_learning_environment_amd.utils import units
+
+pytestmark = pytest.mark.gpu
+KA = helpers.known_answers()
+
+
+@pytest.fixture(scope='module')
+def mods():
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device; none visible')
+  from balloon_learning_environment_amd.env.balloon import acs, balloon, solar, stable_init, standard_atmosphere, thermal
+  return dict(acs=acs, balloon=balloon, solar=solar, stable_init=stable_init, atm=standard_atmosphere, thermal=thermal)
+
+
+def test_standard_atmosphere_like_the_reference(mods):
+  """standard_atmosphere_test.py:36-126: ranges over the atmospheres of keys 0..9, assertions outside the model."""
+  atm = mods['atm']
+  atmospheres = [atm.Atmosphere(np.array([0, k], np.uint32)) for k in range(10)]
+  assert len({a.alpha for a in atmospheres}) == 10 and all(0.0 <= a.alpha < 1.0 for a in atmospheres)
+  # (the reference's ranges hold for the alphas ITS ten jax keys draw -- not for the extremes 0 and 1 --: the same interior
+  # alphas as tests/test_oracle_golden.py::test_atmosphere_reference_test_ranges)
+  for k, alpha in enumerate((0.15, 0.37, 0.5, 0.85)):
+    atmospheres[k].alpha = alpha
+  for pressure, (h_lo, h_hi), (t_lo, t_hi), (d_lo, d_hi) in KA['atmosphere_at_pressure']['cases']:
+    for a in atmospheres[:4]:
+      v = a.at_pressure(pressure)
+      assert h_lo - 0.5 <= v.height.meters <= h_hi + 0.5 and t_lo - 0.01 <= v.temperature <= t_hi + 0.01, (pressure, a.alpha, v)
+      assert d_lo - 0.01 <= v.density <= d_hi + 0.01 and v.pressure == pressure
+  for height, (p_lo, p_hi), (t_lo, t_hi), (d_lo, d_hi) in KA['atmosphere_at_height']['cases']:
+    v = atmospheres[2].at_height(units.Distance(meters=height))
+    assert p_lo * 0.9999 <= v.pressure <= p_hi * 1.0001 and t_lo - 0.01 <= v.temperature <= t_hi + 0.01
+  for p in KA['atmosphere_out_of_range']['pressures_raise']:
+    with pytest.raises(AssertionError):
+      atmospheres[1].at_pressure(p)
+  for h in KA['atmosphere_out_of_range']['heights_raise']:
+    with pytest.raises(AssertionError):
+      atmospheres[1].at_height(units.Distance(meters=h))
+  # at_pressure(at_height(h).pressure) gives h back (device lookup against host tables)
+  for h in (12000.0, 17500.0, 19000.0):
+    a = atmospheres[2]
+    assert abs(a.at_pressure(a.at_height(units.Distance(meters=h)).pressure).height.meters - h) < 0.5
+
+
+def test_solar_like_the_reference(mods):
+  """solar_test.py:47-256."""
+  solar, balloon = mods['solar'], mods['balloon']
+  for lat, lng, unix, el, _az, flux in KA['solar_calculator']['cases']:
+    got_el, got_az, got_flux = solar.solar_calculator(balloon.LatLng.from_degrees(lat, lng), units.datetime_from_timestamp(unix))
+    assert abs(got_el - el) < 0.06 and np.isnan(got_az)                       # assertAlmostEqual(places=1)
+    if flux is not None:
+      assert abs(got_flux - flux) < 0.06
+  for el, pressure, want in KA['solar_attenuation']['cases']:
+    assert abs(solar.solar_atmospheric_attenuation(el, pressure) - want) < 6e-6     # places=5
+  for p in KA['solar_attenuation_raises']['pressure_raise']:
+    with pytest.raises(ValueError):
+      solar.solar_atmospheric_attenuation(30.0, p)
+  for el, height, want in KA['balloon_shadow']['cases']:
+    assert abs(solar.balloon_shadow(el, height) - want) < 1e-3
+  site = balloon.LatLng.from_degrees(0.0, 0.0)
+  for now, sunrise, sunset in KA['sunrise_sunset']['cases']:
+    parse = lambda s: dt.datetime.fromisoformat(s).replace(tzinfo=dt.timezone.utc)
+    got = solar.get_next_sunrise_sunset(site, parse(now))
+    assert got == (parse(sunrise), parse(sunset)), (now, got)
+  assert solar.solar_power(-10.0, 8000.0).watts == 0.0 and solar.solar_power(60.0, 8000.0).watts > 500.0
+
+
+def test_acs_like_the_reference(mods):
+  """acs_test.py:26-68 (the efficiency table is read along the operating curve the simulator flies)."""
+  acs = mods['acs']
+  for pr, w in KA['acs']['power_eq']:
+    assert acs.get_most_efficient_power(pr).watts == pytest.approx(w, abs=1e-3)
+  for pr, w in KA['acs']['power_le']:
+    assert acs.get_most_efficient_power(pr).watts <= w + 1e-3
+  for pr, w in KA['acs']['power_ge']:
+    assert acs.get_most_efficient_power(pr).watts >= w - 1e-3
+  for pr, w, eff in KA['acs']['eff_eq']:
+    assert acs.get_fan_efficiency(pr, units.Power(watts=w)) == pytest.approx(eff, abs=1e-6)
+  for eff, w, flow in KA['acs']['mass_flow']:
+    assert acs.get_mass_flow(units.Power(watts=w), eff) == pytest.approx(flow)
+  with pytest.raises(NotImplementedError):
+    acs.get_fan_efficiency(1.2, units.Power(watts=123.0))
+
+
+def test_thermal_and_stable_init_like_the_reference(mods):
+  """thermal.py has no reference test; stable_init_test.py:42-83: a balloon started at the cold-start solution stays within
+  100 Pa of its pressure over 100 strides of 10 s."""
+  thermal, stable_init, balloon = mods['thermal'], mods['stable_init'], mods['balloon']
+  assert thermal.black_body_flux_to_temperature(thermal.black_body_temperature_to_flux(250.0)) == pytest.approx(250.0)
+  with pytest.raises(ValueError):
+    thermal.total_absorptivity(thermal.absorptivity_ir(5.0), 0.0291)                # thermal.py:142-145
+  warm = thermal.d_balloon_temperature_dt(1804.0, 68.5, 200.0, 215.0, 8000.0, 50.0, 1360.0, 260.0)
+  cold = thermal.d_balloon_temperature_dt(1804.0, 68.5, 260.0, 215.0, 8000.0, -20.0, 1360.0, 260.0)
+  assert warm > 0.0 > cold
+  from balloon_learning_environment_amd.env import simulator_data, wind_field
+  from balloon_learning_environment_amd.env.balloon import control
+  solar = mods['solar']
+  # The reference builds its atmosphere from PRNGKey(38); its |dp| < 100 Pa assertion holds for the upper end of the alpha
+  # range only (the pinned oracle: -96 Pa at alpha = 1, -148 Pa at alpha = 0.4 for the 11 500 Pa case -- the cold start is not
+  # an equilibrium of the dynamics).  alpha = 0.999 here; the alpha = 0.4 drift is compared with the oracle's below.
+  atmosphere = simulator_data.Atmosphere(0.999)
+
+  def create_balloon(pressure, date_time):                    # utils/test_helpers.py:96-130
+    state = balloon.BalloonState(center_latlng=balloon.LatLng.from_degrees(0.0, 0.0), date_time=date_time, pressure=pressure,
+                                 upwelling_infrared=250.0)
+    state.battery_charge = units.Energy(watt_hours=0.95 * state.battery_capacity.watt_hours)
+    stable_init.cold_start_to_stable_params(state, atmosphere)
+    return balloon.Balloon(state)
+  # mols_air: created at midnight (the superpressure is very sensitive to the time of day), flown for 100 strides
+  for pressure in (9500.0, 11500.0, 6500.0):                  # stable_init_test.py:36-60
+    b = create_balloon(pressure, units.datetime(2020, 6, 1, 0, 0, 0))
+    assert b.state.mols_air >= 0.0 and b.state.envelope_volume > 1000.0 and 180.0 < b.state.ambient_temperature < 240.0
+    wind = wind_field.WindVector(units.Velocity(mps=3.0), units.Velocity(mps=-4.0))
+    for _ in range(100):
+      b.simulate_step(wind, atmosphere, control.AltitudeControlCommand.STAY, dt.timedelta(seconds=10.0))
+    assert abs(b.state.pressure - pressure) < 100.0, (pressure, b.state.pressure)
+  # the same flight at alpha = 0.4 drifts further -- exactly as far as the reference's arithmetic (oracle) says
+  import oracle
+  atmosphere = simulator_data.Atmosphere(0.4)
+  unix = int(units.datetime(2020, 6, 1).timestamp())
+  for pressure in (9500.0, 11500.0):
+    b = create_balloon(pressure, units.datetime(2020, 6, 1, 0, 0, 0))
+    for _ in range(100):
+      b.simulate_step(wind, atmosphere, control.AltitudeControlCommand.STAY, dt.timedelta(seconds=10.0))
+    out, err = oracle.stable_init(np.array([pressure]), np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1), np.array([unix], np.int64),
+                                  np.array([250.0]), np.array([0.4]))
+    st = oracle.new_state(1)
+    st['pressure'][:] = pressure; st['upwelling_infrared'][:] = 250.0; st['alpha'][:] = 0.4; st['start_unix'][:] = unix
+    for k in ('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume', 'superpressure'):
+      st[k][:] = out[k]
+    st['battery_charge'][:] = 0.95 * 3058.56
+    sr, ss = oracle.next_sunrise_sunset(np.zeros(1), np.zeros(1), np.array([unix], np.int64))
+    st['sunrise_h'][:] = sr + 1800; st['sunset'][:] = ss
+    for _ in range(100):
+      oracle.step(st, np.array([1], np.uint8), wind_uv=np.array([[3.0, -4.0]]), substeps=1)
+    assert abs(b.state.pressure - float(st['pressure'][0])) < 0.5 and abs(b.state.pressure - pressure) > 100.0
+  atmosphere = simulator_data.Atmosphere(0.999)
+  # temperature: at the cold-start solution the internal temperature is (nearly) stationary
+  for pressure in (9500.0, 11500.0, 5000.0):                  # stable_init_test.py:62-83
+    b = create_balloon(pressure, units.datetime(2013, 3, 25, 9, 25, 32))
+    el, _, flux = solar.solar_calculator(b.state.latlng, b.state.date_time)
+    d_internal_temp = thermal.d_balloon_temperature_dt(b.state.envelope_volume, b.state.envelope_mass, b.state.internal_temperature,
+                                                       b.state.ambient_temperature, b.state.pressure, el, flux,
+                                                       b.state.upwelling_infrared)
+    assert d_internal_temp < 1e-3
