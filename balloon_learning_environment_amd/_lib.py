@@ -32,7 +32,8 @@ NOISE_CACHE_ROWS = 53
 # every symbol include/ble_abi.h declares
 EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
            'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32',
-           'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_f64_prims')
+           'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
+           'ble_probe_f64_prims')
 
 
 class BleLibraryError(RuntimeError):
@@ -94,6 +95,7 @@ def lib():
   l.ble_probe_thermal_f32.argtypes = [_vp] * 9 + [_i64, _vp]
   l.ble_probe_sp_volume_f32.argtypes = [_vp] * 5 + [_i64, _vp]
   l.ble_probe_acs_f32.argtypes = [_vp] * 4 + [_i64, _vp]
+  l.ble_probe_safety_f32.argtypes = [_int, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_f64_prims.argtypes = [_vp, _vp, _int, _i64, _vp]
   for name in EXPORTS:
     getattr(l, name).restype = _int

@@ -306,6 +306,34 @@ __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* 
   power[i] = (float)w; eff[i] = (float)acs_efficiency_f64(kAcsEfficiency, prm1, acs_power_f64(prm1)); mdot[i] = (float)md;
 }
 
+// The three safety layers one at a time (ble_probe_safety_f32): the lane functions of agent_step on their own state bytes.
+__global__ __launch_bounds__(256) void probe_safety_kernel(int layer, const uint8_t* action, const float* value,
+                                                           const float* alpha, int32_t* clocks, double night_load_w,
+                                                           double capacity_wh, uint8_t* fsm, uint8_t* effective,
+                                                           uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n) {
+    uint8_t state = fsm[i];
+    int eff;
+    if (layer == 0) {                               // value = pressure: the altitude the transition compares (fp64)
+      const double p = (double)value[i];
+      const AtmWindow w = atm_window((double)alpha[i], p, &flags);
+      double h, t;
+      atm_at_pressure_f64(w, (double)alpha[i], p, &h, &t);
+      eff = altitude_safety(action[i], h, &state);
+    } else if (layer == 1) {                        // value = superpressure
+      eff = envelope_safety(action[i], value[i], &state);
+    } else {                                        // value = battery charge; clocks (now, sunrise + 1/2 h, sunset)
+      int32_t sr = clocks[3 * i + 1], ss = clocks[3 * i + 2];
+      eff = power_safety(action[i], clocks[3 * i], value[i], &sr, &ss, &state, night_load_w, capacity_wh);
+      clocks[3 * i + 1] = sr; clocks[3 * i + 2] = ss;
+    }
+    fsm[i] = state; effective[i] = (uint8_t)eff;
+  }
+  report_flags(flags, err_flags);
+}
+
 // Decoder tail of the wind-field VAE (generative/vae.py:149-186): flow fields psi [n][7][7][90]
 // (the last Dense layer's output, flow-field index fastest) -> half-pixel linear resize to
 // 23 x 23 (jax.image.resize 'linear': triangle kernel, edge weights renormalised == clamped
@@ -650,6 +678,17 @@ int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* effici
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(probe_acs_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pressure_ratio,
                      power_w, efficiency, mass_flow, n);
+  return launch_status();
+}
+
+int ble_probe_safety_f32(int layer, const uint8_t* action, const float* value, const float* alpha, int32_t* clocks,
+                         double night_load_w, double capacity_wh, uint8_t* fsm, uint8_t* effective_action,
+                         uint32_t* err_flags, int64_t n, void* stream) {
+  if (layer < 0 || layer > 2 || !action || !value || !fsm || !effective_action || n < 0) return BLE_E_INVALID_ARG;
+  if ((layer == 0 && !alpha) || (layer == 2 && (!clocks || !(capacity_wh > 0.0)))) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(probe_safety_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, layer, action, value, alpha,
+                     clocks, night_load_w, capacity_wh, fsm, effective_action, err_flags, n);
   return launch_status();
 }
 

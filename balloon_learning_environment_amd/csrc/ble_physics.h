@@ -504,14 +504,14 @@ BLE_FN int envelope_safety(int action, float superpressure, uint8_t* fsm) {
 }
 // power_safety.py:52-126.  Times in seconds relative to start_unix.
 BLE_FN int power_safety(int action, int32_t now, float battery_wh, int32_t* sunrise_h, int32_t* sunset,
-                        uint8_t* paused) {
+                        uint8_t* paused, double night_load_w = 183.7, double capacity_wh = 3058.56) {
   BLE_NO_CONTRACT
   int32_t sr = *sunrise_h, ss = *sunset;
   if (now > sr) sr += ((now - sr + 86399) / 86400) * 86400;   // while now > sr: sr += 1 day
   if (now > ss) ss += ((now - ss + 86399) / 86400) * 86400;
   *sunrise_h = sr; *sunset = ss;
   const int paused_action = (action == kDown) ? kStay : action;
-  const double batt = battery_wh, cap = 3058.56;
+  const double batt = battery_wh, cap = capacity_wh;   // (the transition's constants unless the probe says otherwise)
   if (ss < sr) {  // daytime
     double soc = batt / cap;
     if (*paused && soc < 0.05) return paused_action;
@@ -520,7 +520,7 @@ BLE_FN int power_safety(int action, int32_t now, float battery_wh, int32_t* sunr
   }
   if (*paused) return paused_action;
   double hours = (double)(sr - now) / 3600.0;
-  double floating_charge = 183.7 * hours;
+  double floating_charge = night_load_w * hours;
   double expected = (batt - floating_charge) / cap;
   if (expected < 0.025) { *paused = 1; return paused_action; }
   return action;

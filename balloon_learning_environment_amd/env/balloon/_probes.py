@@ -92,3 +92,20 @@ def reset_one(row: dict):
   sim.reset_device(seed=0, sample=False)
   sim.check_errors()
   return {k: t[0].item() for k, t in sim.state.items()}
+
+
+def safety(layer, action, value, fsm, alpha=0.0, clocks=None, night_load_w=183.7, capacity_wh=3058.56):
+  """One call of one safety layer (`ble_probe_safety_f32`): layer 0 altitude (value = pressure), 1 envelope (value =
+  superpressure), 2 power (value = battery Wh, clocks = (now, sunrise + 30 min, sunset) in seconds from a common epoch).
+  -> (effective action, new fsm byte, clocks after the call or None)."""
+  dev.require_gpu('cuda')
+  a = torch.tensor([int(action)], dtype=torch.uint8, device='cuda')
+  v, al = _f32(value, alpha)
+  state = torch.tensor([int(fsm)], dtype=torch.uint8, device='cuda')
+  ck = torch.tensor([list(clocks) if clocks is not None else [0, 0, 0]], dtype=torch.int32, device='cuda')
+  eff, flags = _out(dtype=torch.uint8), _flags()
+  _lib.check(_lib.lib().ble_probe_safety_f32(int(layer), a.data_ptr(), v.data_ptr(), al.data_ptr(), ck.data_ptr(), float(night_load_w),
+                                             float(capacity_wh), state.data_ptr(), eff.data_ptr(), flags.data_ptr(), 1, _stream()),
+             'ble_probe_safety_f32')
+  _raise(flags)
+  return int(eff.item()), int(state.item()), (tuple(ck[0].tolist()) if clocks is not None else None)

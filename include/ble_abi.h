@@ -295,6 +295,21 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
 int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency,
                       float* mass_flow, int64_t n, void* stream);
 
+/* The three safety layers of the transition one at a time, stateful across calls through `fsm` (in/out, one byte per
+ * element; a fresh layer = 0):
+ *   layer 0  AltitudeSafetyLayer.get_action (altitude_safety.py:63-111): value = pressure [Pa], alpha = the
+ *            atmosphere's lapse-rate blend; fsm 0 NOMINAL 1 LOW 2 VERY_LOW;
+ *   layer 1  EnvelopeSafetyLayer.get_action (envelope_safety.py:109-157, max superpressure 2380 Pa): value =
+ *            superpressure [Pa]; fsm 0 NOMINAL 1 LOW_CRITICAL 2 LOW 3 HIGH 4 HIGH_CRITICAL;
+ *   layer 2  PowerSafetyLayer.get_action (power_safety.py:52-126): value = battery charge [Wh]; clocks [n][3] =
+ *            (now, sunrise + 30 min, sunset) in seconds from a common epoch -- the layer moves the two events on
+ *            by whole days, in place; fsm = navigation_is_paused; night_load_w / capacity_wh as the reference's
+ *            arguments (the transition passes 183.7 W and 3058.56 Wh).
+ * effective_action [n] = the layer's answer to action [n] (0 DOWN 1 STAY 2 UP). */
+int ble_probe_safety_f32(int layer, const uint8_t* action, const float* value, const float* alpha,
+                         int32_t* clocks, double night_load_w, double capacity_wh, uint8_t* fsm,
+                         uint8_t* effective_action, uint32_t* err_flags, int64_t n, void* stream);
+
 /* The kernel's own fp64 primitives (reciprocal / rsqrt seeds and refinements, log, exp,
  * sincos), element-wise on device doubles.  op: 0 rcp seed, 1 rcp, 2 rsq seed, 3 rsqrt,
  * 4 sqrt, 5 log, 6 exp, 7 sin, 8 cos.  Test-only. */

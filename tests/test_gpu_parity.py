@@ -276,6 +276,72 @@ def test_probe_solar_power_thermal_volume_acs(ble):
   np.testing.assert_allclose(md.cpu().numpy(), mo, rtol=1e-6, atol=1e-9)
 
 
+def test_safety_layer_probe_matches_oracle_traces(ble):
+  """`ble_probe_safety_f32`: each of the three layers on its own, 96 independent flights of 160 calls carried through the FSM
+  byte (and, for the power layer, the two clocks it advances), against the oracle's per-layer traces.  Bit-exact."""
+  from balloon_learning_environment_amd import _lib
+  lib = _lib.lib()
+  rng = np.random.default_rng(2024)
+  n, T = 96, 160
+  actions = rng.integers(0, 3, (T, n)).astype(np.uint8)
+  fl = torch.zeros(1, dtype=torch.int32).cuda()
+
+  def flight(layer, values, alpha=None, clocks=None, load=183.7, cap=3058.56):
+    fsm = torch.zeros(n, dtype=torch.uint8).cuda(); eff = torch.empty(n, dtype=torch.uint8).cuda()
+    out_a, out_f, out_c = [], [], []
+    ck = None
+    for t in range(T):
+      if clocks is not None:
+        now = _dev(clocks[0][t], np.int32)
+        ck = torch.stack([now, ck[:, 1] if t else _dev(clocks[1], np.int32), ck[:, 2] if t else _dev(clocks[2], np.int32)], 1).contiguous()
+      _call(lib, 'ble_probe_safety_f32', layer, _dev(actions[t], np.uint8), _dev(values[t], np.float32),
+            None if alpha is None else _dev(alpha, np.float32), ck, load, cap, fsm, eff, fl, n, None)
+      out_a.append(eff.cpu().numpy().copy()); out_f.append(fsm.cpu().numpy().copy())
+      if ck is not None:
+        out_c.append(ck.cpu().numpy().copy())
+    assert int(fl.item()) == 0
+    return np.array(out_a), np.array(out_f), np.array(out_c)
+
+  # altitude: random walks in height across the three bands, as float32 pressures of each flight's atmosphere
+  alpha = rng.uniform(0.05, 0.95, n).astype(np.float32)
+  feet = 50500.0 + np.cumsum(rng.normal(0.0, 220.0, (T, n)), 0)
+  pressure = np.stack([oracle.at_height(float(alpha[e]), feet[:, e] * 0.3048)[0] for e in range(n)], 1).astype(np.float32)
+  ga, gf, _ = flight(0, pressure, alpha=alpha)
+  for e in range(n):
+    oa, of, err = oracle.altitude_safety_trace(float(alpha[e]), actions[:, e], pressure[:, e].astype(np.float64))
+    assert err == 0
+    np.testing.assert_array_equal(ga[:, e], oa); np.testing.assert_array_equal(gf[:, e], of)
+  assert set(np.unique(gf)) == {0, 1, 2}
+
+  # envelope: random walks over 0 .. 2400 Pa (all five states)
+  sp = np.abs(1200.0 + np.cumsum(rng.normal(0.0, 160.0, (T, n)), 0)) % 2400.0
+  sp = sp.astype(np.float32)
+  ga, gf, _ = flight(1, sp)
+  for e in range(n):
+    oa, of = oracle.envelope_safety_trace(actions[:, e], sp[:, e].astype(np.float64))
+    np.testing.assert_array_equal(ga[:, e], oa); np.testing.assert_array_equal(gf[:, e], of)
+  assert set(np.unique(gf)) == {0, 1, 2, 3, 4}
+
+  # power: four days in 36-minute calls, batteries draining at night; two load / capacity pairs (the transition's and the
+  # reference test's small battery)
+  for load, cap in ((183.7, 3058.56), (1.0, 100.0)):
+    now = (np.arange(T)[:, None] * 2160 + rng.integers(0, 600, (T, n))).astype(np.int64)
+    now.sort(axis=0)
+    sunrise_h = rng.integers(3600, 86400, n); sunset = rng.integers(3600, 86400, n)
+    batt = (cap * np.clip(0.06 + 0.08 * np.sin(now / 13750.0 + rng.uniform(0, 6.3, n)) + rng.normal(0, 0.01, (T, n)), 0.0, 1.0)).astype(np.float32)
+    ga, gf, gc = flight(2, batt, clocks=(now, sunrise_h, sunset), load=load, cap=cap)
+    for e in range(n):
+      oa, osr, oss, op = oracle.power_safety_trace(actions[:, e], now[:, e], batt[:, e].astype(np.float64), sunrise_h[e], sunset[e], 0, load, cap)
+      np.testing.assert_array_equal(ga[:, e], oa); np.testing.assert_array_equal(gf[:, e], op)
+      np.testing.assert_array_equal(gc[:, e, 1], osr); np.testing.assert_array_equal(gc[:, e, 2], oss)
+    assert gf.max() == 1 and gf.min() == 0 and (ga != actions).any()
+
+  # argument checks: an unknown layer, the altitude layer without alpha, the power layer without clocks
+  a = _dev(actions[0], np.uint8); v = _dev(sp[0], np.float32); fsm = torch.zeros(n, dtype=torch.uint8).cuda(); eff = torch.empty_like(fsm)
+  for args in ((3, a.data_ptr(), v.data_ptr(), None, None), (0, a.data_ptr(), v.data_ptr(), None, None), (2, a.data_ptr(), v.data_ptr(), None, None)):
+    assert lib.ble_probe_safety_f32(*args, 183.7, 3058.56, fsm.data_ptr(), eff.data_ptr(), fl.data_ptr(), n, None) == -1      # BLE_E_INVALID_ARG
+
+
 def test_power_table_exact(ble):
   from balloon_learning_environment_amd import _lib
   lib = _lib.lib()

@@ -1,5 +1,5 @@
 """The reference's own unit tests, written against this package's mirror of the reference modules
-(env/balloon/{standard_atmosphere, solar, thermal, acs, stable_init}.py) -- same calls, same literals
+(env/balloon/{standard_atmosphere, solar, thermal, acs, stable_init, altitude_safety, envelope_safety, power_safety}.py) -- same calls, same literals
 (tests/golden/reference_known_answers.json: the inline known answers of the reference's *_test.py files, as data) --
 with every call landing in the device functions of the transition (`ble_probe_*`, `ble_reset_f32`)."""
 import datetime as dt
@@ -153,3 +153,53 @@ def test_thermal_and_stable_init_like_the_reference(mods):
                                                        b.state.ambient_temperature, b.state.pressure, el, flux,
                                                        b.state.upwelling_infrared)
     assert d_internal_temp < 1e-3
+
+
+def test_safety_layers_like_the_reference(mods):
+  """envelope_safety_test.py:29-116, altitude_safety_test.py:29-133, power_safety_test.py:37-93: a fresh layer per case,
+  the reference's calls and literals."""
+  from balloon_learning_environment_amd.env.balloon import altitude_safety, control, envelope_safety, power_safety
+  cmd = control.AltitudeControlCommand
+  for sp, action, expected in KA['envelope_safety']['cases']:
+    layer = envelope_safety.EnvelopeSafetyLayer(max_superpressure=2380.0)
+    assert layer.get_action(cmd(action), sp) == cmd(expected), (sp, action)
+    assert layer.navigation_is_paused == (not 300.0 <= sp < 2080.0)
+  with pytest.raises(NotImplementedError):
+    envelope_safety.EnvelopeSafetyLayer(max_superpressure=2000.0)       # the device layer's envelope is a kernel constant
+
+  alt = KA['altitude_safety']
+  atmosphere = mods['atm'].Atmosphere(np.array([0, 0], np.uint32))      # altitude_safety_test.py:31 (jax key 0)
+  pressure = {k: atmosphere.at_height(units.Distance(feet=v)).pressure for k, v in alt['altitudes_ft'].items()}
+  for name, action, expected in alt['action_cases']:
+    assert altitude_safety.AltitudeSafetyLayer().get_action(cmd(action), atmosphere, pressure[name]) == cmd(expected), name
+  for name, paused in alt['paused_cases']:
+    layer = altitude_safety.AltitudeSafetyLayer()
+    layer.get_action(cmd.DOWN, atmosphere, pressure[name])
+    assert layer.navigation_is_paused == paused, name
+  for sequence, paused in alt['hysteresis']:
+    layer = altitude_safety.AltitudeSafetyLayer()
+    for name in sequence:
+      layer.get_action(cmd.DOWN, atmosphere, pressure[name])
+    assert layer.navigation_is_paused == paused, sequence
+  with pytest.raises(AssertionError):
+    altitude_safety.AltitudeSafetyLayer().get_action(cmd.DOWN, atmosphere, 150000.0)     # outside the atmosphere model
+
+  latlng = mods['balloon'].LatLng.from_degrees(0.0, 0.0)
+  for c in KA['power_safety']['cases']:
+    start = dt.datetime.fromisoformat(c['start']).replace(tzinfo=dt.timezone.utc)
+    layer = power_safety.PowerSafetyLayer(latlng, start)
+    got = layer.get_action(cmd.DOWN, start, units.Power(watts=c['load_w']), units.Energy(watt_hours=c['batt_wh']),
+                           units.Energy(watt_hours=c['cap_wh']))
+    assert got == cmd(c['expected']), c
+    assert layer.navigation_is_paused == (c['expected'] == 1)
+  # hysteresis over a night and a morning: paused at night stays paused until the battery is above 5 % after sunrise
+  start = dt.datetime(2021, 6, 1, 0, 0, tzinfo=dt.timezone.utc)
+  layer = power_safety.PowerSafetyLayer(latlng, start)
+  load, cap = units.Power(watts=183.7), units.Energy(watt_hours=2000.0)
+  assert layer.get_action(cmd.DOWN, start, load, units.Energy(watt_hours=200.0), cap) == cmd.STAY and layer.navigation_is_paused
+  assert layer.get_action(cmd.UP, start + dt.timedelta(hours=1), load, units.Energy(watt_hours=1900.0), cap) == cmd.UP    # still paused
+  assert layer.navigation_is_paused
+  noon = start + dt.timedelta(hours=12)
+  assert layer.get_action(cmd.DOWN, noon, load, units.Energy(watt_hours=90.0), cap) == cmd.STAY and layer.navigation_is_paused
+  assert layer.get_action(cmd.DOWN, noon, load, units.Energy(watt_hours=110.0), cap) == cmd.DOWN and not layer.navigation_is_paused
+  assert power_safety.PowerSafetyLayer.get_paused_action(cmd.DOWN) == cmd.STAY
