@@ -1,0 +1,36 @@
+"""utils/test_helpers.py:37-130 of the reference, the part its hot-path tests use: START_DATE_TIME, create_arena and
+create_balloon (a hand-built balloon, optionally moved to the cold-start solution of its pressure).  gin binding and the
+renderer belong to the control plane and are not mirrored."""
+import datetime as dt
+import functools
+from typing import Optional
+
+from balloon_learning_environment_amd.env import balloon_arena, features, wind_field
+from balloon_learning_environment_amd.env.balloon import balloon, stable_init
+from balloon_learning_environment_amd.utils import units
+
+START_DATE_TIME = units.datetime(2013, 3, 25, 9, 25, 32)          # :37
+
+create_arena = functools.partial(balloon_arena.BalloonArena, features.PerciatelliFeatureConstructor,
+                                 wind_field.SimpleStaticWindField())              # :40-43
+
+
+def create_balloon(x: units.Distance = units.Distance(m=0.0), y: units.Distance = units.Distance(m=0.0), center_lat: float = 0.0,
+                   center_lng: float = 0.0, pressure: float = 7_000.0, power_percent: float = 0.95,
+                   date_time: Optional[dt.datetime] = None, time_elapsed: Optional[dt.timedelta] = None,
+                   power_safety_layer_enabled: bool = True, use_stable_init: bool = True, upwelling_infrared: float = 250.0,
+                   atmosphere=None) -> balloon.Balloon:                            # :96-130
+  """Creates a balloon object for easy testing."""
+  if not power_safety_layer_enabled:
+    raise NotImplementedError('the transition always runs the power safety layer (balloon.py:304-306 with the default flag)')
+  date_time = date_time if date_time is not None else START_DATE_TIME
+  time_elapsed = time_elapsed if time_elapsed is not None else dt.timedelta()
+  b = balloon.Balloon(balloon.BalloonState(center_latlng=balloon.LatLng.from_degrees(center_lat, center_lng), x=x, y=y,
+                                           pressure=pressure, date_time=date_time, time_elapsed=time_elapsed,
+                                           upwelling_infrared=upwelling_infrared))
+  b.state.battery_charge = b.state.battery_capacity * power_percent
+  if use_stable_init:
+    if atmosphere is None:
+      raise ValueError('Must supply an Atmosphere object if using stable init.')
+    stable_init.cold_start_to_stable_params(b.state, atmosphere)
+  return b

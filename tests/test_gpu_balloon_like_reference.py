@@ -1,0 +1,130 @@
+"""env/balloon/balloon_test.py:36-212 of the reference, test by test, on this package's `Balloon` -- whose simulate_step is
+ONE launch of the HIP transition (`ble_step_f32`) on a batch of one.  Same calls and literals through the mirror of
+utils/test_helpers.create_balloon; where the reference patches solar_calculator to 25 / -25 deg, the balloon is put under
+the real sun of noon / midnight instead (the device function cannot be patched, and should not be)."""
+import datetime as dt
+
+import numpy as np
+import pytest
+import torch
+
+from balloon_learning_environment_amd.utils import units
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rig():
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device; none visible')
+  from balloon_learning_environment_amd.env import wind_field
+  from balloon_learning_environment_amd.env.balloon import balloon, control, standard_atmosphere
+  from balloon_learning_environment_amd.utils import test_helpers
+  atmosphere = standard_atmosphere.Atmosphere(np.array([0, 0], np.uint32))          # balloon_test.py:41 (key 0)
+  atmosphere.alpha = 0.85       # (an alpha the reference's own draws cover; this package's key -> alpha map is Philox, not threefry)
+
+  class Rig:
+    wind_vector = wind_field.WindVector(units.Velocity(mps=3.0), units.Velocity(mps=-4.0))
+    fast_wind = wind_field.WindVector(units.Velocity(mps=10.0), units.Velocity(mps=12.0))
+    noon, midnight = units.datetime(2013, 3, 25, 12), units.datetime(2013, 3, 25, 0)
+    STAY, DOWN = control.AltitudeControlCommand.STAY, control.AltitudeControlCommand.DOWN
+
+    @staticmethod
+    def create_balloon(**kwargs):
+      return test_helpers.create_balloon(atmosphere=atmosphere, **kwargs)
+  Rig.atmosphere, Rig.balloon = atmosphere, balloon
+  return Rig
+
+
+def test_separate_state_from_functionality(rig):                     # :44-50
+  b = rig.create_balloon()
+  assert isinstance(b.state, rig.balloon.BalloonState) and not isinstance(b.state, rig.balloon.Balloon)
+
+
+def test_balloon_lat_lng_is_correctly_calculated(rig):               # :52-60
+  b = rig.create_balloon(x=units.Distance(km=111.0), y=units.Distance(km=111.0))
+  assert b.state.latlng.lat_deg == pytest.approx(1.0, abs=0.05) and b.state.latlng.lng_deg == pytest.approx(1.0, abs=0.05)
+
+
+@pytest.mark.parametrize('charge,hour,expected', [(1.0, 0, False), (0.5, 12, False), (1.0, 12, True)])
+def test_excess_energy_calculated_correctly(rig, charge, hour, expected):          # :62-83
+  assert rig.create_balloon(power_percent=charge, date_time=units.datetime(2021, 9, 9, hour)).state.excess_energy == expected
+
+
+@pytest.mark.parametrize('pressure,superpressure,expected_ratio', [(5235, 1234, 1.2357), (5235, -52, 1.0)])
+def test_pressure_ratio_calculated_correctly(rig, pressure, superpressure, expected_ratio):      # :85-91
+  state = rig.create_balloon().state
+  state.pressure, state.superpressure = pressure, superpressure
+  assert state.pressure_ratio == pytest.approx(expected_ratio, abs=5e-4)
+
+
+def test_balloon_goes_in_wind_direction(rig):                        # :93-104
+  b = rig.create_balloon()
+  assert b.state.x.meters == 0 and b.state.y.meters == 0
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.x.meters == pytest.approx(100.0) and b.state.y.meters == pytest.approx(120.0)
+
+
+def test_balloon_goes_up_when_low(rig):                              # :106-116
+  pressure0 = 20_123.0
+  b = rig.create_balloon(pressure=pressure0, use_stable_init=False)
+  b.simulate_step(rig.wind_vector, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.pressure < pressure0
+
+
+def test_balloon_goes_down_when_high(rig):                           # :118-128
+  pressure0 = 2345.0
+  b = rig.create_balloon(pressure=pressure0, use_stable_init=False)
+  b.simulate_step(rig.wind_vector, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.pressure > pressure0
+
+
+def test_balloon_charges_in_the_sun(rig):                            # :137-151
+  b = rig.create_balloon(power_percent=0.5, date_time=rig.noon)
+  soc0 = b.state.battery_soc
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.battery_soc > soc0 and b.state.solar_charging.watts > b.state.power_load.watts
+
+
+def test_balloon_doesnt_charge_in_the_night(rig):                    # :153-167
+  b = rig.create_balloon(power_percent=0.5, date_time=rig.midnight)
+  soc0 = b.state.battery_soc
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.battery_soc < soc0 and b.state.solar_charging.watts == 0.0
+
+
+def test_balloon_drains_hotel_load_at_night(rig):                    # :169-182
+  b = rig.create_balloon(date_time=rig.midnight)
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10))
+  assert b.state.power_load.watts == float(np.float32(b.state.nighttime_power_load.watts))        # (the state is float32: north_star)
+
+
+def test_balloon_drains_hotel_load_during_day(rig):                  # :184-197
+  b = rig.create_balloon(date_time=rig.noon)
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.STAY, dt.timedelta(seconds=10.0))
+  assert b.state.power_load.watts == float(np.float32(b.state.daytime_power_load.watts))
+
+
+def test_acs_contributes_to_power_load(rig):                         # :199-212
+  b = rig.create_balloon(date_time=rig.noon)
+  b.simulate_step(rig.fast_wind, rig.atmosphere, rig.DOWN, dt.timedelta(seconds=10.0))
+  assert b.state.power_load > b.state.daytime_power_load and b.state.acs_power.watts > 0.0
+
+
+def test_get_pressure_range_like_the_reference(rig):
+  """env/balloon/pressure_range_builder_test.py:36-66 (its three tests), plus the same range from the pinned oracle."""
+  import oracle
+  import features_oracle
+  from balloon_learning_environment_amd.env.balloon import altitude_safety, pressure_range_builder
+  for kwargs in ({}, dict(pressure=9_000.0, date_time=rig.midnight), dict(pressure=11_000.0, date_time=rig.noon, center_lat=7.0)):
+    b = rig.create_balloon(**kwargs)
+    pr = pressure_range_builder.get_pressure_range(b.state, rig.atmosphere)
+    assert isinstance(pr, pressure_range_builder.AccessiblePressureRange)
+    assert 1000.0 <= pr.min_pressure <= 100_000.0 and 1000.0 <= pr.max_pressure <= 100_000.0
+    assert pr.min_pressure < pr.max_pressure
+    assert pr.max_pressure <= rig.atmosphere.at_height(altitude_safety.MIN_ALTITUDE).pressure * (1 + 1e-12)
+    fo = features_oracle.FeatureOracle(np.zeros((21, 21, 10, 9, 2), np.float32), rig.atmosphere.alpha)
+    row = rig.balloon.row_from_state(b.state, rig.atmosphere.alpha)
+    fo.observe(row, (0.0, 0.0))
+    lo, hi = fo.pressure_range()
+    assert pr.min_pressure == pytest.approx(lo, rel=1e-9) and pr.max_pressure == pytest.approx(hi, rel=1e-9)
