@@ -34,3 +34,18 @@ def create_balloon(x: units.Distance = units.Distance(m=0.0), y: units.Distance 
       raise ValueError('Must supply an Atmosphere object if using stable init.')
     stable_init.cold_start_to_stable_params(b.state, atmosphere)
   return b
+
+
+def compare_balloon_states(b1: balloon.BalloonState, b2: balloon.BalloonState, check_not_equal=()) -> None:       # :134-175
+  """Every field of the two states equal -- or, with `check_not_equal`, exactly the named fields different (and nothing
+  else examined), as the reference's helper does.  The safety layers are skipped like there."""
+  import dataclasses
+  for field in dataclasses.fields(balloon.BalloonState):
+    key = field.name
+    if 'safety_layer' in key:
+      continue
+    x, y = getattr(b1, key), getattr(b2, key)
+    if key in check_not_equal:
+      assert x != y, f'{key}: {x} == {y}'
+    elif not check_not_equal:
+      assert x == y, f'{key}: {x} != {y}'
