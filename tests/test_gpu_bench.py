@@ -52,3 +52,43 @@ def test_bench_refuses_a_world_that_is_not_gpus():
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras'],
                      cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
   assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in r.stderr
+
+
+def test_rccl_collectives_of_the_sharded_path_on_one_rank():
+  """The exchanges of DESIGN section 7 through the real backend ("nccl" = RCCL) as far as one GPU allows: a single-rank
+  process group runs the grid broadcast, the packed reward / terminal gather on its side stream (dist.gather itself, not
+  the world == 1 shortcut), the observation gather, the MAX / SUM all-reduces of the timing and the barrier -- RCCL loads,
+  builds its communicator and moves the bytes.  (Several ranks on one GPU are refused by RCCL: the world-2 runs use gloo.)"""
+  code = r'''
+import os, socket, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from balloon_learning_environment_amd import distributed as bdist, vec_state
+s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+dist.init_process_group('nccl', device_id=dev)
+assert dist.get_backend() == 'nccl'
+grid = torch.randn(vec_state.GRID_SHAPE, device=dev); ref = grid.clone()
+dist.broadcast(grid, src=0); assert torch.equal(grid, ref)
+n, k = 8192, 20
+buf, r, t = bdist.packed_output_block(k, n, dev)
+r.copy_(torch.rand(k, n, device=dev)); t.copy_((torch.rand(k, n, device=dev) < 0.01).to(torch.uint8))
+out = torch.zeros(1, 5 * k * n, dtype=torch.uint8, device=dev)
+side = torch.cuda.Stream(device=dev)
+side.wait_stream(torch.cuda.current_stream(dev))
+with torch.cuda.stream(side):
+  dist.gather(buf, [out[0]], dst=0)
+torch.cuda.current_stream(dev).wait_stream(side)
+assert torch.equal(out[0], buf)
+obs = torch.randn(n, 1099, device=dev); got = torch.zeros(1, n, 1099, device=dev)
+dist.gather(obs, [got[0]], dst=0); assert torch.equal(got[0], obs)
+v = torch.tensor([3.25], dtype=torch.float64, device=dev)
+dist.all_reduce(v, op=dist.ReduceOp.MAX); dist.all_reduce(v, op=dist.ReduceOp.SUM); assert float(v.item()) == 3.25
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print('rccl ok')
+'''
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stderr[-2000:]
