@@ -74,3 +74,27 @@ def feature_row(g, j, i):
 def fixture_field(g):
   import numpy as np
   return (np.random.default_rng(int(g['field_seed'])).standard_normal((21, 21, 10, 9, 2)) * float(g['field_scale'])).astype(np.float32)
+
+
+def wide_domain_states(n, seed):
+  """ABI-typed initial states far outside the flight envelope the samplers draw (tests of the transition's robustness):
+  pressures 1 200 .. 40 000 Pa (above the 21 km window and below the troposphere's top), stations up to 60 deg of latitude,
+  balloons up to 850 km from the station (beyond the wind grid), up to 110 h into the episode (the boomeranged part of the
+  forecast, later table segments of everything time-based), any temperatures / infrared / battery, safety layers in any
+  state.  The envelope is consistent: a superpressure drawn in 20 .. 2 300 Pa fixes volume and air content."""
+  from balloon_learning_environment_amd import reset_host
+  rng = np.random.default_rng(seed)
+  init = reset_host.sample_initial_state(n, seed=seed)
+  init['pressure'][:] = np.exp(rng.uniform(np.log(1200.0), np.log(40000.0), n))
+  init['x'][:] = rng.uniform(-600e3, 600e3, n); init['y'][:] = rng.uniform(-600e3, 600e3, n)
+  init['center_lat_deg'][:] = rng.uniform(-60, 60, n); init['center_lng_deg'][:] = rng.uniform(-180, 180, n)
+  init['time_elapsed_s'][:] = rng.integers(0, 2200, n) * 180
+  init['upwelling_infrared'][:] = rng.uniform(150, 400, n)
+  init['battery_charge'][:] = rng.uniform(5, 3058, n)
+  init['internal_temperature'][:] = rng.uniform(180, 300, n); init['ambient_temperature'][:] = rng.uniform(180, 280, n)
+  sp = rng.uniform(20, 2300, n); vol = 1804.0 + 0.0199 * sp
+  p = init['pressure'].astype(np.float64); t_int = init['internal_temperature'].astype(np.float64)
+  init['mols_air'][:] = np.maximum((p + sp) * vol / (8.3144621 * t_int) - 6830.0, 0.0)
+  init['envelope_volume'][:] = vol; init['superpressure'][:] = sp
+  init['alt_fsm'][:] = rng.integers(0, 3, n); init['env_fsm'][:] = rng.integers(0, 5, n); init['power_paused'][:] = rng.integers(0, 2, n)
+  return init

@@ -176,3 +176,41 @@ def test_sampled_batch_every_env_within_1e_5_host_build():
       worst = max(worst, float(err_k.max()))
       assert err_k.max() <= 1e-5, f'step {s} {k}: {err_k.max():.3g} at env {err_k.argmax()}'
   print(f'host build, {n} envs x 3 steps: worst relative error {worst:.2e}')
+
+
+def test_wide_domain_states_host_build():
+  """helpers.wide_domain_states through the host build of the lane functions: the transition's arithmetic far outside the
+  flight envelope (above the 21 km atmosphere window, beyond the wind grid, later segments of the forecast's boomerang, any
+  safety-layer state) against the oracle, three steps, every environment."""
+  from helpers import wide_domain_states
+  e = _load_emul()
+  n = 2048
+  init = wide_domain_states(n, 3)
+  ost = oracle.new_state(n)
+  for f in oracle.FLOAT_FIELDS:
+    ost[f][:] = np.asarray(init[f], np.float64)
+  for f in oracle.U8_FIELDS:
+    ost[f][:] = init[f]
+  ost['start_unix'][:] = init['start_unix']; ost['time_elapsed_s'][:] = init['time_elapsed_s']
+  ost['sunrise_h'][:] = init['start_unix'] + init['sunrise_h_rel']; ost['sunset'][:] = init['start_unix'] + init['sunset_rel']
+  field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)
+  st = e.state_from_oracle(ost)
+  rng = np.random.default_rng(9)
+  stepped = 0
+  for s in range(3):
+    live = st['status'] == 0
+    o2 = e.oracle_from_state(st)
+    act = rng.integers(0, 3, n).astype(np.uint8)
+    r, t, eff, fl = e.step(st, act, field=field)
+    ro, to, eo, err = oracle.step(o2, act, field=field)
+    assert fl == 0 and (err & ~oracle.ERR_TERMINAL_STEP) == 0
+    for k in ('status', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+      np.testing.assert_array_equal(st[k][live], o2[k][live], err_msg=f'wide step {s} {k}')
+    for k in STATE_FLOATS:
+      err_k = rel_err(st[k], o2[k], FLOORS[k])[live]
+      if k == 'acs_mass_flow':
+        err_k = np.where(o2['status'][live] == 3, err_k * 0.05, err_k)      # sqrt(sp) at sp -> 0 on the deflating stride
+      assert err_k.max() <= 1e-5, f'wide step {s} {k}: {err_k.max():.3g}'
+    np.testing.assert_array_equal(eff[live], eo[live]); np.testing.assert_array_equal(t, to)
+    stepped += int(live.sum())
+  assert stepped > 3000 and (st['status'] != 0).mean() > 0.3
