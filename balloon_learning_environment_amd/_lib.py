@@ -25,7 +25,7 @@ _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 ABI_VERSION = 2
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
-FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH = 64, 128
+FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH, FLAG_DAY_CYCLE = 64, 128, 256
 OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
 NOISE_CACHE_ROWS = 53
 

@@ -72,6 +72,7 @@ constexpr double kGpNoise2 = 0.05;                  // wind_gp.py:37
 constexpr int kGpHorizonS = 6 * 3600;               // wind_gp.py:63
 constexpr uint32_t kFlagGpWindow = 64u;             // more than 120 observations inside 6 h
 constexpr uint32_t kFlagPressureSearch = 128u;      // pressure_range_builder raised ValueError
+constexpr uint32_t kFlagDayCycle = 256u;            // features.py:432-437 divides by zero (polar night: sunrise a day after sunset)
 
 struct GpHistory {
   float* xyp;          // [n][128][3]
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       // sunset to the sunrise.  In units of 180 s the quotients are those of the reference's seconds.
       const bool day = sunset < sunrise;
       const int prev = (day ? sunrise : sunset) - 480;
+      if ((day ? sunset : sunrise) == prev) flags |= kFlagDayCycle;     // the reference raises ZeroDivisionError here; the features are NaN
       const double frac = (double)(240 - prev) / (double)((day ? sunset : sunrise) - prev);
       const double cycle = day ? kPiD * frac : kPiD + kPiD * frac;
       double sc, cc;

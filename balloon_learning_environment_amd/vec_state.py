@@ -38,6 +38,8 @@ def raise_for_flags(flags: int) -> None:
     raise FloatingPointError('non-finite balloon state')
   if flags & _lib.FLAG_PRESSURE_SEARCH:
     raise ValueError('Unable to find safe pressure for balloon.')       # pressure_range_builder.py:180-182
+  if flags & _lib.FLAG_DAY_CYCLE:
+    raise ZeroDivisionError('float division by zero')                     # features.py:432-437 at a station in polar night
   if flags & _lib.FLAG_GP_WINDOW:
     raise OverflowError('WindGP window holds more than 120 observations (agent steps shorter than 180 s)')
 

@@ -52,6 +52,8 @@ extern "C" {
 #define BLE_FLAG_NONFINITE 32u     /* a state value became NaN/Inf (no reference analogue) */
 #define BLE_FLAG_GP_WINDOW 64u     /* > 120 observations inside the WindGP's 6 h window (steps < 180 s): oldest dropped */
 #define BLE_FLAG_PRESSURE_SEARCH 128u /* pressure_range_builder.py:104-108,180-182 ValueError */
+#define BLE_FLAG_DAY_CYCLE 256u    /* features.py:432-437 ZeroDivisionError: the next sunrise exactly one day after the next sunset
+                                      (polar night); the two day-cycle features of that environment are NaN */
 
 /* wind grid geometry: generative/vae.py:30-38,77-93 (FieldShape defaults) */
 #define BLE_GRID_NX 21 /* x (lat axis of the grid), -500..500 km step 50 */
