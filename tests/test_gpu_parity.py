@@ -760,6 +760,13 @@ def test_device_reset_derivation_matches_oracle(ble):
                 center_lng_deg=d['center_lng_deg'], upwelling_infrared=d['upwelling_infrared'], start_unix=d['unix_s']),
            {k: init[k] for k in ('alpha', 'x', 'y', 'pressure', 'center_lat_deg', 'center_lng_deg', 'upwelling_infrared',
                                  'start_unix')}]
+  # the same away from the sampler's +-10 deg: stations up to 85 deg of latitude in every season (the sunrise / sunset search
+  # through polar day and night), balloons up to 400 km from the station
+  polar = {k: init[k].copy() for k in cases[1]}
+  rng = np.random.default_rng(8)
+  polar['center_lat_deg'][:] = np.where(np.arange(4096) % 2 == 0, 1, -1) * rng.uniform(30, 85, 4096)
+  polar['x'][:] = rng.uniform(-400e3, 400e3, 4096); polar['y'][:] = rng.uniform(-400e3, 400e3, 4096)
+  cases.append(polar)
   for c in cases:
     n = c['x'].size
     sim = ble.VecSimulator(n)
