@@ -78,7 +78,8 @@ def fixture_field(g):
 
 def wide_domain_states(n, seed):
   """ABI-typed initial states far outside the flight envelope the samplers draw (tests of the transition's robustness):
-  pressures 1 200 .. 40 000 Pa (above the 21 km window and below the troposphere's top), stations up to 60 deg of latitude,
+  pressures 1 200 .. 40 000 Pa (above the 21 km window and below the troposphere's top), stations up to 85 deg of latitude
+  (polar day and night),
   balloons up to 850 km from the station (beyond the wind grid), up to 110 h into the episode (the boomeranged part of the
   forecast, later table segments of everything time-based), any temperatures / infrared / battery, safety layers in any
   state.  The envelope is consistent: a superpressure drawn in 20 .. 2 300 Pa fixes volume and air content."""
@@ -87,7 +88,7 @@ def wide_domain_states(n, seed):
   init = reset_host.sample_initial_state(n, seed=seed)
   init['pressure'][:] = np.exp(rng.uniform(np.log(1200.0), np.log(40000.0), n))
   init['x'][:] = rng.uniform(-600e3, 600e3, n); init['y'][:] = rng.uniform(-600e3, 600e3, n)
-  init['center_lat_deg'][:] = rng.uniform(-60, 60, n); init['center_lng_deg'][:] = rng.uniform(-180, 180, n)
+  init['center_lat_deg'][:] = rng.uniform(-85, 85, n); init['center_lng_deg'][:] = rng.uniform(-180, 180, n)
   init['time_elapsed_s'][:] = rng.integers(0, 2200, n) * 180
   init['upwelling_infrared'][:] = rng.uniform(150, 400, n)
   init['battery_charge'][:] = rng.uniform(5, 3058, n)

@@ -465,9 +465,9 @@ def _sampled_batch_parity(ble, n, steps, seed, threads, init=None):
       e = rel_err(got[k], o2[k], FLOORS[k])
       e[~live] = 0.0
       if wide and k == 'acs_mass_flow':
-        # the stride on which a venting balloon reaches zero superpressure: the valve flow is ~ sqrt(sp) at sp -> 0, where the
-        # 1e-9-relative agreement of the superpressure itself (on 2 000 Pa) is all of the value; 1e-7 kg/s on that last stride
-        e[o2['status'] == 3] *= 0.05
+        # a venting balloon at (or reaching) zero superpressure: the valve flow is ~ sqrt(sp) at sp -> 0, where the 1e-9-relative
+        # agreement of the superpressure itself (on 2 000 Pa) is all of the value; 1e-8 .. 1e-7 kg/s on such a stride
+        e[(o2['status'] == 3) | (o2['superpressure'] < 5.0)] *= 0.05
       bad |= e > RTOL
       worst = max(worst, float(e.max()))
     rew_err = np.abs(reward.cpu().numpy() - ro)
@@ -525,7 +525,7 @@ def test_long_rollout_checkpoints_match_oracle(ble):
 
 def test_wide_domain_states_every_env(ble):
   """16 385 environments drawn far outside the flight envelope (helpers.wide_domain_states): from 1 200 Pa (above the
-  atmosphere window's 21 km) to 40 000 Pa, 60 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers
+  atmosphere window's 21 km) to 40 000 Pa, 85 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers
   in any state; half of them burst, deflate or run out of power within three steps.  Same bar as everywhere: every
   environment, every field, 1e-5; discrete outputs and the terminal strides exact."""
   from helpers import wide_domain_states

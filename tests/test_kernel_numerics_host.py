@@ -209,7 +209,7 @@ def test_wide_domain_states_host_build():
     for k in STATE_FLOATS:
       err_k = rel_err(st[k], o2[k], FLOORS[k])[live]
       if k == 'acs_mass_flow':
-        err_k = np.where(o2['status'][live] == 3, err_k * 0.05, err_k)      # sqrt(sp) at sp -> 0 on the deflating stride
+        err_k = np.where((o2['status'][live] == 3) | (o2['superpressure'][live] < 5.0), err_k * 0.05, err_k)      # valve flow ~ sqrt(sp) at sp -> 0
       assert err_k.max() <= 1e-5, f'wide step {s} {k}: {err_k.max():.3g}'
     np.testing.assert_array_equal(eff[live], eo[live]); np.testing.assert_array_equal(t, to)
     stepped += int(live.sum())
