@@ -710,11 +710,14 @@ def test_fp64_primitives_on_device(ble):
   assert np.abs(run(7, a) - np.sin(a)).max() < 3e-16 and np.abs(run(8, a) - np.cos(a)).max() < 3e-16
 
 
-def test_fused_rollout_equals_single_steps(ble):
-  """ble_step_n_f32 (K steps in one launch, state in registers) == K x ble_step_f32, bit for bit."""
+@pytest.mark.parametrize('wide', [False, True])
+def test_fused_rollout_equals_single_steps(ble, wide):
+  """ble_step_n_f32 (K steps in one launch, state in registers) == K x ble_step_f32, bit for bit -- from sampled flight
+  states and from helpers.wide_domain_states (half of which end inside the rollout)."""
   from balloon_learning_environment_amd import reset_host
+  from helpers import wide_domain_states
   n, k = 4096, 7
-  init = reset_host.sample_initial_state(n, seed=5)
+  init = wide_domain_states(n, 5) if wide else reset_host.sample_initial_state(n, seed=5)
   # make a few environments terminate inside the rollout
   init['battery_charge'][:64] = 0.2
   field = (np.random.default_rng(1).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
