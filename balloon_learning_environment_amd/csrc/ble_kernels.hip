@@ -515,7 +515,7 @@ int ble_device_count(void) {
 int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                  const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action,
                  uint32_t* err_flags, unsigned long long* active_count, int64_t n, int substeps, void* stream) {
-  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 ||
+  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || substeps > BLE_MAX_SUBSTEPS ||
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
@@ -529,7 +529,7 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
 int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                    float* reward, uint8_t* terminal, uint32_t* err_flags, unsigned long long* active_count,
                    int64_t n, int substeps, int n_steps, void* stream) {
-  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || n_steps < 0 ||
+  if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || substeps > BLE_MAX_SUBSTEPS || n_steps < 0 ||
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;

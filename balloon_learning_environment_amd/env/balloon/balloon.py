@@ -201,6 +201,8 @@ class Balloon:
                                 f'multiple of the inner simulation stride (stride={stride})')   # balloon.py:316-319
     if inner != 10:
       raise NotImplementedError('the transition kernel integrates with the reference\'s default 10 s stride')
+    if outer // inner > 60:
+      raise NotImplementedError('one call integrates at most BLE_MAX_SUBSTEPS = 60 strides (10 minutes); the reference\'s agent step is 18')
     if self._sim is None:
       self._sim = vec_state.VecSimulator(1, self._device)
       self._sim.set_grid(np.zeros(vec_state.GRID_SHAPE, np.float32))

@@ -40,7 +40,7 @@ extern "C" {
 
 /* return codes */
 #define BLE_OK 0
-#define BLE_E_INVALID_ARG (-1) /* NULL required pointer, n < 0, substeps < 1 ... */
+#define BLE_E_INVALID_ARG (-1) /* NULL required pointer, n < 0, substeps outside 1 .. BLE_MAX_SUBSTEPS ... */
 #define BLE_E_LAUNCH (-2)      /* hipLaunchKernel / hipGetLastError failed */
 #define BLE_E_NO_DEVICE (-3)   /* no HIP device visible */
 
@@ -113,6 +113,7 @@ typedef struct ble_state_f32 {
   double* episode_cache;
 } ble_state_f32;
 #define BLE_EPISODE_CACHE_ROWS 7
+#define BLE_MAX_SUBSTEPS 60
 
 int ble_abi_version(void);
 
@@ -124,7 +125,10 @@ int ble_last_hip_error(void);
 int ble_device_count(void);
 
 /*
- * One agent step (180 s = `substeps` x 10 s) for n environments.
+ * One agent step (180 s = `substeps` x 10 s) for n environments.  `substeps` = time_delta / stride of
+ * Balloon.simulate_step, 1 .. BLE_MAX_SUBSTEPS: the reference's 18, and up to 10 minutes per step, are held to
+ * the parity bar (tests/test_gpu_parity.py); beyond that the per-step solar interpolation and the float32
+ * accumulators of the state drift past 1e-5 (measured at 120), so longer steps are refused, not approximated.
  * Replaces BalloonArena.step (env/balloon_arena.py:184-202) up to, not including, the
  * feature constructor:
  *     wind = WindField.get_ground_truth(x, y, pressure, time_elapsed)   wind_field.py:125-145

@@ -524,6 +524,37 @@ def test_long_rollout_checkpoints_match_oracle(ble):
   assert outliers == 0 and worst <= RTOL
 
 
+@pytest.mark.parametrize('substeps', [1, 7, 36, 60])
+def test_other_step_lengths_every_env(ble, substeps):
+  """Balloon.simulate_step takes any time_delta that is a multiple of the stride (balloon.py:316-319); the agent step is 18
+  strides.  1, 7, 36 and BLE_MAX_SUBSTEPS = 60 strides per step (10 s .. 10 min) on 4 096 sampled environments, four steps each:
+  every environment within 1e-5 of the oracle stepping with the same stride count; 61 is refused."""
+  from balloon_learning_environment_amd import reset_host
+  n = 4096
+  field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  sim = ble.VecSimulator(n); sim.set_state(reset_host.sample_initial_state(n, seed=substeps)); sim.set_grid(field)
+  rng = np.random.default_rng(substeps)
+  for s in range(4):
+    before = sim.get_state()
+    live = before['status'] == 0
+    o2 = oracle_state_from_abi(before)
+    act = rng.integers(0, 3, n).astype(np.uint8)
+    reward, terminal = sim.step(_dev(act, np.uint8), substeps=substeps)
+    torch.cuda.synchronize(); sim.check_errors()
+    ro, to, eo, err = oracle.step(o2, act, field=field, threads=16, substeps=substeps)
+    got = sim.get_state()
+    assert (got['time_elapsed_s'][live] - before['time_elapsed_s'][live] <= 10 * substeps).all()
+    for k in ('status', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+      np.testing.assert_array_equal(got[k][live], o2[k][live], err_msg=f'{substeps} strides, step {s}: {k}')
+    for k in STATE_FLOATS:
+      e = rel_err(got[k], o2[k], FLOORS[k])[live]
+      assert e.max() <= RTOL, f'{substeps} strides, step {s}: {k} {e.max():.3g}'
+    np.testing.assert_array_equal(terminal.cpu().numpy(), to)
+    np.testing.assert_allclose(reward.cpu().numpy()[live], ro[live], rtol=0, atol=2e-5)
+  with pytest.raises(Exception):
+    sim.step(_dev(act, np.uint8), substeps=61)
+
+
 def test_wide_domain_states_every_env(ble):
   """16 385 environments drawn far outside the flight envelope (helpers.wide_domain_states): from 1 200 Pa (above the
   atmosphere window's 21 km) to 40 000 Pa, 85 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers
