@@ -533,12 +533,13 @@ def test_long_flight_at_full_size_carried_equals_refit(vec_state):
   assert 'beyond 1e-5: 0 ' in line
 
 
-@pytest.mark.parametrize('lat_lo,lat_hi', [(35.0, 64.5), (60.0, 85.0)])
-def test_observe_high_latitude_stations_match_oracle(vec_state, lat_lo, lat_hi):
+@pytest.mark.parametrize('lat_lo,lat_hi,far', [(35.0, 64.5, False), (60.0, 85.0, False), (0.0, 85.0, True)])
+def test_observe_high_latitude_stations_match_oracle(vec_state, lat_lo, lat_hi, far):
   """Stations far outside the sampler's +-10 deg of latitude, polar day and polar night included: the sunrise / sunset
   searches behind the day-cycle features (solar.py:258-483) walk their table through days without a sunrise, the cold
   starts of the reachable-pressure search see a sun that never sets.  32 environments reset on the device at their sites,
-  flown 12 steps; every observation against the oracle (which follows the reference's decisions whatever they find)."""
+  flown 12 steps; every observation against the oracle (which follows the reference's decisions whatever they find).
+  `far`: also hundreds of kilometres off the wind grid, outside the feature's pressure band, days into the episode."""
   import features_oracle
   from balloon_learning_environment_amd import reset_host
   n, steps = 32, 12
@@ -549,9 +550,14 @@ def test_observe_high_latitude_stations_match_oracle(vec_state, lat_lo, lat_hi):
   init = reset_host.sample_initial_state(n, seed=4)
   init['center_lat_deg'][:] = np.where(np.arange(n) % 2 == 0, 1, -1) * rng.uniform(lat_lo, lat_hi, n)
   init['start_unix'][:] = rng.integers(1293840000, 1419984000, n)          # all seasons
+  if far:      # up to 850 km from the station (beyond the wind grid: clamped lookups) and up to 110 h into the episode (boomerang)
+    init['x'][:] = rng.uniform(-600e3, 600e3, n); init['y'][:] = rng.uniform(-600e3, 600e3, n)
+    init['pressure'][:] = rng.uniform(4500, 15000, n)
   sim.set_state(init)
   sim.reset_device(seed=0, sample=False)
   sim.check_errors()
+  if far:
+    sim.state['time_elapsed_s'].copy_(torch.from_numpy((rng.integers(0, 2200, n) * 180).astype(np.int32)).cuda())
   alpha = sim.state['alpha'].cpu().numpy().astype(np.float64)
   oracles = [features_oracle.FeatureOracle(field, alpha[j]) for j in range(n)]
   worst, compared, refused = 0.0, 0, 0
