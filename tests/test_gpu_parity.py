@@ -1002,3 +1002,31 @@ def test_episode_cache_is_transparent(ble):
     assert bool(((keys >> 31) & 1)[live].all())              # every live lane's entry is valid after a step
     ir_bits = sim_a.state['upwelling_infrared'].view(torch.int32).to(torch.int64) & 0xffffffff
     assert torch.equal(((keys >> 32) & 0xffffffff)[live], ir_bits[live])     # ... and belongs to the CURRENT constants
+
+
+def test_integration_md_binding_runs_as_written(ble):
+  """The ctypes binding INTEGRATION.md section 2 shows a reference maintainer (`HipBalloons`), executed as written (only the
+  library path is filled in): one step of 1 000 sampled environments through it equals VecSimulator.step bit for bit."""
+  import os, re
+  from balloon_learning_environment_amd import _lib, reset_host
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  text = open(os.path.join(root, 'INTEGRATION.md')).read()
+  block = re.search(r'```python\n(# balloon_learning_environment/env/hip_backend\.py.*?)```', text, re.S).group(1)
+  scope = {}
+  exec(block.replace("ctypes.CDLL('libble_hip.so')", f'ctypes.CDLL({_lib.LIB_PATH!r})'), scope)
+  n = 1000
+  init = reset_host.sample_initial_state(n, seed=21)
+  field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  grid = torch.from_numpy(field).cuda()
+  act = _dev(np.random.default_rng(4).integers(0, 3, n), np.uint8)
+  hip = scope['HipBalloons'](n)
+  for k, t in hip.t.items():
+    t.copy_(torch.from_numpy(np.asarray(init[k]).astype(t.cpu().numpy().dtype)))
+  reward, terminal = hip.step(act, grid)
+  sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(grid)
+  r2, t2 = sim.step(act)
+  torch.cuda.synchronize()
+  assert int(hip.flags.item()) == 0
+  assert torch.equal(reward, r2) and torch.equal(terminal, t2)
+  for k, t in hip.t.items():
+    assert torch.equal(t, sim.state[k]), k
