@@ -339,22 +339,59 @@ __global__ __launch_bounds__(256) void probe_safety_kernel(int layer, const uint
 // 23 x 23 (jax.image.resize 'linear': triangle kernel, edge weights renormalised == clamped
 // taps) -> central differences u = d psi / dy, v = -d psi / dx on the interior 21 x 21 ->
 // the wind grid [n][21][21][10][9][2] the step kernel reads (grid_env_stride = 79 380).
-// One thread per (i, j, field): 16 cached reads, one 8-byte store; the 90 x 2 floats of an
-// (i, j) cell are contiguous, so both sides are coalesced.  HBM-bound: 317.5 KB written per env.
-__global__ __launch_bounds__(256) void ble_decode_flow_kernel(const float* __restrict__ flow, float* __restrict__ grid,
-                                                              int64_t n) {
+// HBM-write-bound: 317.5 KB written per env against 17.6 KB read.  One workgroup = one environment, 4 groups of 90 threads
+// (one per flow field; 24 idle): psi (17.6 KB) is staged in LDS, resized along the second axis once (P[7][23][90], 58 KB: the
+// `lo` / `hi` of decode_resized, which depend on the source row alone), and every output row is then produced with the
+// first-axis interpolation on the fly, the middle row's lattice points sliding through registers: 6 LDS reads per output and
+// no integer division in the loops, against the 16 cached global loads + 4 divisions of the one-thread-per-output form (bound
+// by its load issue rate at 1.6 TB/s of writes).  Stores: 720 contiguous bytes per 90 threads.  Same arithmetic, bit for bit.
+#ifndef BLE_DECODE_GROUPS
+#define BLE_DECODE_GROUPS 6          // (A/B knob of profiles/decode_ab.py: 4 .. 11 groups measured, 6 is the fastest)
+#endif
+constexpr int kDecodeGroups = BLE_DECODE_GROUPS, kDecodeThreads = (90 * kDecodeGroups + 63) / 64 * 64;
+__global__ __launch_bounds__(kDecodeThreads) void ble_decode_flow_kernel(const float* __restrict__ flow, float* __restrict__ grid,
+                                                                         int64_t n) {
+  __shared__ float psi[7 * 7 * 90];
+  __shared__ float part[7 * 23 * 90];        // psi resized along its second axis
   __shared__ int tap0[23];
   __shared__ float w1[23];
+  const int64_t env = blockIdx.x;
   if (threadIdx.x < 23) resize_tap((int)threadIdx.x, &tap0[threadIdx.x], &w1[threadIdx.x]);
+  for (int t = threadIdx.x; t < 7 * 7 * 90; t += kDecodeThreads) psi[t] = flow[env * (7 * 7 * 90) + t];
   __syncthreads();
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int64_t env = blockIdx.y;
-  if (idx >= 21 * 21 * 90 || env >= n) return;
-  const int f = idx % 90, ij = idx / 90, i = ij / 21, j = ij % 21;
-  float u, v;
-  decode_flow_point(flow + env * (7 * 7 * 90) + f, i, j, tap0, w1, &u, &v);
-  float2* out = reinterpret_cast<float2*>(grid + env * (int64_t)(21 * 21 * 90 * 2)) + idx;
-  *out = make_float2(u, v);
+  const int f = (int)threadIdx.x % 90, g = (int)threadIdx.x / 90;
+  if (g >= kDecodeGroups) return;            // (no barrier below is reached by a subset: the last one follows)
+  for (int rb = g; rb < 7 * 23; rb += kDecodeGroups) {
+    const int r = rb / 23, b = rb - 23 * r;
+    const int b0 = tap0[b], b_lo = b0 < 0 ? 0 : b0, b_hi = b0 + 1 > 6 ? 6 : b0 + 1;
+    const float lo = psi[(r * 7 + b_lo) * 90 + f];
+    part[rb * 90 + f] = f_fma(w1[b], psi[(r * 7 + b_hi) * 90 + f] - lo, lo);
+  }
+  __syncthreads();
+  float2* out = reinterpret_cast<float2*>(grid + env * (int64_t)(21 * 21 * 90 * 2)) + f;
+  for (int i = g; i < 21; i += kDecodeGroups) {
+    // first-axis taps of the lattice rows i, i + 1, i + 2
+    int lo_row[3], hi_row[3]; float wa[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int a0 = tap0[i + k];
+      lo_row[k] = (a0 < 0 ? 0 : a0) * (23 * 90) + f; hi_row[k] = (a0 + 1 > 6 ? 6 : a0 + 1) * (23 * 90) + f; wa[k] = w1[i + k];
+    }
+    auto point = [&](int k, int b) {           // decode_resized's last line on the staged lo / hi
+      const float lo = part[lo_row[k] + b * 90];
+      return f_fma(wa[k], part[hi_row[k] + b * 90] - lo, lo);
+    };
+    float mid0 = point(1, 0), mid1 = point(1, 1);
+    float2* row = out + (int64_t)i * (21 * 90);
+#pragma unroll 3
+    for (int j = 0; j < 21; ++j) {
+      const float mid2 = point(1, j + 2);
+      float u, v;
+      decode_flow_from_lattice(point(2, j + 1), point(0, j + 1), mid2, mid0, &u, &v);
+      row[j * 90] = make_float2(u, v);          // (non-temporal stores measured: 3.8 ms against 3.0 for 32 768 grids)
+      mid0 = mid1; mid1 = mid2;
+    }
+  }
 }
 
 // mode 0: the wind noise (u, v) of every environment at its (x, y, pressure, elapsed);
@@ -582,10 +619,9 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
 }
 
 int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream) {
-  if (!flow || !wind_grid || n < 0 || n > 65535) return BLE_E_INVALID_ARG;     // gridDim.y limit; call in slices
+  if (!flow || !wind_grid || n < 0 || n > 2147483647LL) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  BLE_LAUNCH(ble_decode_flow_kernel, dim3((21 * 21 * 90 + 255) / 256, (unsigned)n), dim3(256), 0, (hipStream_t)stream, flow,
-             wind_grid, n);
+  BLE_LAUNCH(ble_decode_flow_kernel, dim3((unsigned)n), dim3(kDecodeThreads), 0, (hipStream_t)stream, flow, wind_grid, n);
   return launch_status();
 }
 

@@ -249,7 +249,7 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
  * last Dense layer): n sets of 7 x 7 x 90 flow fields -> half-pixel linear resize to 23 x 23
  * -> central differences -> n wind grids [21][21][10][9][2] (grid_env_stride = 79 380 floats).
  * The four Dense layers before it are plain GEMMs (rocBLAS/hipBLASLt through torch.matmul).
- * n <= 65535 per call.
+ * n < 2^31 per call (one workgroup per grid).
  */
 int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream);
 
