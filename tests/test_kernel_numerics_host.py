@@ -216,3 +216,54 @@ def test_wide_domain_states_host_build():
     np.testing.assert_array_equal(eff[live], eo[live]); np.testing.assert_array_equal(t, to)
     stepped += int(live.sum())
   assert stepped > 3000 and (st['status'] != 0).mean() > 0.3
+
+
+def test_dates_outside_the_samplers_range_and_the_reference_julian_day_quirk():
+  """The transition turns unix seconds into the Julian date by the exact identity JD = 2440587.5 + unix / 86400 (32-bit
+  fast path for 1970 .. 2106, 64-bit otherwise); the reference goes through year / month / day (solar.py:70-76).  Episodes
+  starting in 1931 .. 1969 (negative unix time) and in 2101 .. 2199 (beyond 32 bits): every environment within 1e-5.
+  The one place the two differ is a quirk of the reference's formula -- its `(month - 9.0) / 7.0` is not truncated, so the
+  century correction of the non-leap years 2100, 2200, 2300 arrives in September instead of March: from March to August of
+  those years the reference's Julian day is one day late (the oracle, pinned to it, reproduces that; shown below)."""
+  import datetime as dt
+  from balloon_learning_environment_amd import reset_host
+  e = _load_emul()
+  n = 1024
+  field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)
+  unix = lambda *a: int(dt.datetime(*a, tzinfo=dt.timezone.utc).timestamp())
+  for lo, hi in ((unix(1931, 1, 1), unix(1969, 12, 30)), (unix(2101, 1, 1), unix(2199, 12, 30))):
+    rng = np.random.default_rng(5)
+    init = reset_host.sample_initial_state(n, seed=9)
+    init['start_unix'][:] = rng.integers(lo, hi, n)
+    lat, lng = reset_host.latlng_from_offset(np.radians(init['center_lat_deg'].astype(np.float64)), np.radians(init['center_lng_deg'].astype(np.float64)),
+                                             init['x'].astype(np.float64), init['y'].astype(np.float64))
+    sunrise, sunset = oracle.next_sunrise_sunset(lat, lng, init['start_unix'])
+    ost = oracle.new_state(n)
+    for f in oracle.FLOAT_FIELDS:
+      ost[f][:] = np.asarray(init[f], np.float64)
+    for f in oracle.U8_FIELDS:
+      ost[f][:] = init[f]
+    ost['start_unix'][:] = init['start_unix']; ost['time_elapsed_s'][:] = 0
+    ost['sunrise_h'][:] = sunrise + 1800; ost['sunset'][:] = sunset
+    st = e.state_from_oracle(ost)
+    for s in range(3):
+      live = st['status'] == 0
+      o2 = e.oracle_from_state(st)
+      act = rng.integers(0, 3, n).astype(np.uint8)
+      r, t, eff, fl = e.step(st, act, field=field)
+      ro, to, eo, err = oracle.step(o2, act, field=field)
+      assert fl == 0
+      _compare({k: v[live] for k, v in st.items()}, {k: v[live] for k, v in o2.items()}, f'dates {lo} .. {hi}, step {s}')
+  # the quirk: noon of 2200-05-01 and of 2200-10-01 at (0, 0); the declination the reference sees in May is that of May 2nd
+  zero = np.zeros(1)
+  for when, off_by_a_day in ((unix(2200, 5, 1, 12), True), (unix(2200, 10, 1, 12), False), (unix(2100, 2, 20, 12), False), (unix(2100, 3, 2, 12), True)):
+    el_ref = oracle.solar_calculator(zero, zero, np.array([when], np.int64))[0][0]
+    el_next_day = oracle.solar_calculator(zero, zero, np.array([when + 86400], np.int64))[0][0]
+    # the device's elevation (exact Julian date) through the host build of its solar probe
+    import ctypes
+    t = np.array([when], np.int64); f32 = lambda v: np.array([v], np.float32)
+    el = np.empty(1, np.float32); fx = np.empty(1, np.float32)
+    args = [f32(0), f32(0), f32(0), f32(0), t, el, fx]
+    e.lib().emul_solar(ctypes.c_int64(1), *[a.ctypes.data_as(ctypes.c_void_p) for a in args])
+    day_shift = abs(el_next_day - el_ref)                       # what one day of declination is worth at this date
+    assert (abs(float(el[0]) - el_ref) > 0.3 * day_shift) == off_by_a_day, (when, el[0], el_ref, day_shift)
