@@ -138,7 +138,9 @@ int ble_device_count(void);
  * perciatelli_reward_function :44-102).
  *
  *   st            state, mutated in place
- *   action        n bytes, 0/1/2
+ *   action        n bytes, 0 DOWN / 1 STAY / 2 UP (control.py:22-26).  Not range-checked on the device (the reference's
+ *                 AltitudeControlCommand(3) raises on the host, and so does this package's single-environment facade):
+ *                 any other value flies like STAY and is stored in last_command as given
  *   wind_grid     BLE_GRID_FLOATS floats, row-major (x, y, pressure, time, uv) = the
  *                 reference's `field` ndarray (21,21,10,9,2)
  *   grid_env_stride  0: one grid shared by all envs; otherwise env i reads
