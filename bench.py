@@ -62,7 +62,13 @@ sys.path.insert(0, ROOT)
 ALGORITHMIC_BYTES_PER_ENV_STEP = 280      # 152 B state + 128 B grid gather
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6                   # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
+# Agent steps per launch = per exchange.  One rank: 32 (the per-launch fixed cost, ~9 us, is paid once per 32 steps and there
+# is nothing to exchange).  Several ranks: every launch's reward / terminal rows go to rank 0 on a side stream while the NEXT
+# launch computes, so only the last gather of a region is exposed -- 8-step launches keep that tail short (5 B x 65 536 x 8 =
+# 2.6 MB per rank over its own xGMI link) at three launches' fixed cost per 20-step region instead of one; with 32 the
+# driver's 20-step region would end with an unoverlapped 6.5 MB-per-rank exchange (BLE_STEPS_PER_GATHER overrides).
 GATHER_EVERY = 32
+GATHER_EVERY_SHARDED = 8
 PRESETS = {1: 'configs[1]: 4 096 vectorised envs, random policy, one decoded wind field, 1xMI355X',
            2: 'configs[2]: 65 536 vectorised envs per GPU, random policy, one decoded wind grid (headline)',
            3: 'configs[3]: 65 536 envs sharded across the GPUs, wind field RCCL-broadcast, rewards/terminals gathered',
@@ -460,6 +466,9 @@ def main():
       dist.init_process_group('nccl', device_id=device)
     else:
       dist.init_process_group(backend)
+  global GATHER_EVERY
+  if world > 1:
+    GATHER_EVERY = max(1, min(32, int(os.environ.get('BLE_STEPS_PER_GATHER', GATHER_EVERY_SHARDED))))
   n_joined = bdist.joined_ranks(device)                  # counted, not read from the command line
   assert n_joined == args.gpus, f'{n_joined} ranks joined, --gpus {args.gpus}'
   if args.config == 3:
