@@ -9,13 +9,14 @@
 
 One "step" = one agent step (180 s = 18 x 10 s substeps + wind lookup + 3 safety layers +
 reward/terminal) of every environment of the rank.  The random policy's actions are known up front, so
-ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (state in registers).
+ble_step_n_f32 runs up to 32 consecutive steps per launch of ble_step_kernel (state in registers; 8 when N > 1, see GATHER_EVERY).
 
 Presets (`--config i` = BASELINE.json configs[i]; the default, 2, is the headline):
   1  4 096 envs, one decoded wind grid, 1 GPU
   2  65 536 envs PER GPU, one decoded wind grid (weak scaling when N > 1: grid broadcast once over RCCL; the reward /
-     terminal rows of EVERY launch -- 32 steps, or fewer for the last launch of a region -- are gathered to rank 0 on a
-     side stream, inside the timed region: `config.exchanges` counts them)
+     terminal rows of EVERY launch -- 8 steps per launch when sharded, so that each exchange overlaps the next launch, or
+     fewer for the last launch of a region -- are gathered to rank 0 on a side stream, inside the timed region:
+     `config.exchanges` counts them)
   3  65 536 envs GLOBAL, sharded contiguously over the N ranks (strong scaling), same exchanges
   4  32 768 envs per GPU (262 144 on 8), every env flies in its own forecast decoded on the device by the
      VAE-decoder restatement (synthetic weights); no broadcast
@@ -25,7 +26,7 @@ torch.cuda.synchronize() on both sides, MAX over ranks.  That K-step region is r
 (default 31) from the same post-warm-up state -- a single 20-step region is one 0.5 ms kernel launch, far too
 short for one sample -- and the MEDIAN repetition is the reported value (min / max / first beside it).
 The wall-clock repetitions launch through argument views built beforehand and carry no event records; the kernel's own
-duration (roofline) comes from 9 more, event-bracketed repetitions of the same region.
+AVERAGE duration (roofline.achieved) comes from 9 more, event-bracketed repetitions of the same region.
 Terminated environments are frozen by the kernel and are NOT counted.
 
 `n_gpus` is the number of ranks that actually joined (an all-reduce), and must equal --gpus.
