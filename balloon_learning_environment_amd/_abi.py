@@ -51,3 +51,8 @@ class BleGpHistoryF32(ctypes.Structure):
               ('err_uv', ctypes.POINTER(ctypes.c_float)), ('count', ctypes.POINTER(ctypes.c_int32)),
               ('chol', ctypes.POINTER(ctypes.c_double)), ('n_chol', ctypes.POINTER(ctypes.c_int32)),
               ('chol_stride', ctypes.c_int64)]
+
+
+class BleNoiseGen(ctypes.Structure):
+  """struct ble_noise_gen: the wind-noise generator of a fused rollout (ble_step_n_f32, ABI 3)."""
+  _fields_ = [('seed', ctypes.c_uint64), ('episode', ctypes.c_void_p), ('harmonic_cache', ctypes.c_void_p)]

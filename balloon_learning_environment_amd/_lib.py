@@ -22,7 +22,7 @@ _SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_
                                                           'ble_observe.h', 'ble_noise.h', 'ble_decode.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH, FLAG_DAY_CYCLE = 64, 128, 256
@@ -81,7 +81,7 @@ def lib():
     raise BleLibraryError('ABI version mismatch between libble_hip.so and the Python mirror')
   st = ctypes.POINTER(_abi.BleStateF32)
   l.ble_step_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]
-  l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
+  l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, ctypes.POINTER(_abi.BleNoiseGen), _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
   l.ble_reset_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
   l.ble_observe_f32.argtypes = [st, _vp, _i64, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
   l.ble_decode_flow_fields_f32.argtypes = [_vp, _vp, _i64, _vp]

@@ -51,6 +51,12 @@ __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags
 // written.  n_steps == 1 is the plain BalloonArena.step; n_steps > 1 serves ble_step_n_f32
 // (rollouts whose actions are known up front, e.g. the random policy of the headline config).
 // action / reward / terminal are [n_steps][n]; active_count is [n_steps][BLE_COUNT_SLOTS].
+// kNoise (ble_step_n_f32 with a noise generator, ABI 3): the SimplexWindNoise term of WindField.get_ground_truth
+// (wind_field.py:125-145) is evaluated IN the kernel at every step's pre-step position -- the same lane function as
+// ble_wind_noise_f32 (wind_noise_cached), hence the same bits as ble_wind_noise_f32 + ble_step_f32 step by step.  A
+// separate instantiation: the noise-free rollout keeps its register allocation.
+struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* harmonic_cache; };
+template <bool kNoise>
 __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
                                                           int64_t grid_env_stride,
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
                                                           uint8_t* __restrict__ terminal,
                                                           uint8_t* __restrict__ effective_action,
                                                           uint32_t* err_flags, unsigned long long* active_count,
-                                                          int64_t n, int substeps, int lanes, int n_steps) {
+                                                          int64_t n, int substeps, int lanes, int n_steps, StepNoise gen) {
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   __shared__ double acs_poly[kAcsPolyDoubles];
@@ -115,7 +121,13 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       WindCorners corners;
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
       float nu = 0.0f, nv = 0.0f;
-      if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
+      if (kNoise) {
+        const uint32_t ep = gen.episode ? gen.episode[i] : 0u;
+        if (gen.harmonic_cache != nullptr)
+          wind_noise_cached(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, gen.harmonic_cache, n, &nu, &nv);
+        else
+          wind_noise(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, &nu, &nv);
+      } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
       const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, &r, &flags);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
@@ -557,24 +569,30 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   const int lanes = env_lanes();
-  BLE_LAUNCH(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+  BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
-                     active_count, n, substeps, lanes, 1);
+                     active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr});
   return launch_status();
 }
 
 int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
-                   float* reward, uint8_t* terminal, uint32_t* err_flags, unsigned long long* active_count,
-                   int64_t n, int substeps, int n_steps, void* stream) {
+                   const ble_noise_gen* noise, float* reward, uint8_t* terminal, uint32_t* err_flags,
+                   unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream) {
   if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || substeps > BLE_MAX_SUBSTEPS || n_steps < 0 ||
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   if (n_steps == 0) return BLE_OK;
   const int lanes = env_lanes();
-  BLE_LAUNCH(ble_step_kernel, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
-                     wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
-                     active_count, n, substeps, lanes, n_steps);
+  if (noise != nullptr) {
+    BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+               wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
+               active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache});
+  } else {
+    BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+               wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
+               active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr});
+  }
   return launch_status();
 }
 

@@ -177,13 +177,23 @@ class VecSimulator:
 
   @_on_own_device
   def load_state_dict(self, d: dict) -> None:
-    """Restores a state_dict() of a simulator of the same size (in place: device pointers handed out before stay valid)."""
+    """Restores a state_dict() of a simulator of the same size IN PLACE: every tensor, the wind grid included, keeps its
+    address, so launches prepared by prepare_step_n and captured HIP graphs stay valid.  Only a checkpoint whose grid
+    has another layout (shared vs per-environment) replaces the grid tensor; launches prepared before must then be
+    prepared again."""
     assert int(d['n']) == self.n, f"checkpoint of {d['n']} environments, simulator of {self.n}"
     for k, t in self.state.items():
       t.copy_(d['state'][k])
     self.episode.copy_(d['episode']); self.active_slots.copy_(d['active_slots']); self.err_flags.copy_(d['err_flags'])
     if d['grid'] is not None:
-      self.set_grid(d['grid'].clone(), per_env=int(d['grid_env_stride']) != 0)
+      # in place whenever the layout matches: launch closures (prepare_step_n) and captured HIP graphs hold the grid's
+      # ADDRESS, so a replaced tensor would leave them reading freed memory; and no second transient copy of a
+      # per-environment grid set (10 GB at 32 768 environments)
+      if (self.grid is not None and self.grid.shape == d['grid'].shape and
+          self.grid_env_stride == int(d['grid_env_stride'])):
+        self.grid.copy_(d['grid'])
+      else:     # another layout: a new tensor -- prepared launches and graphs of the old one must be rebuilt
+        self.set_grid(d['grid'].clone(), per_env=int(d['grid_env_stride']) != 0)
     if d['gp'] is None:
       self._gp, self._obs_reset = None, None
     else:
@@ -237,10 +247,21 @@ class VecSimulator:
     _lib.check(code, 'ble_step_f32')
     return self.reward, self.terminal
 
+  def _noise_gen(self, noise_seed: Optional[int]):
+    """The ble_noise_gen of a fused rollout that flies in the ground-truth wind (forecast + SimplexWindNoise evaluated
+    inside the kernel), or None for the forecast alone.  Same generator as wind_noise(seed): same (seed, env, episode)."""
+    if noise_seed is None:
+      return None
+    if self._noise_cache is None:
+      with torch.cuda.device(self.device):
+        self._noise_cache = torch.zeros(_lib.NOISE_CACHE_ROWS, self.n, dtype=torch.int32, device=self.device)
+    return _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr())
+
   @_on_own_device
   def step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
-             active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS) -> None:
-    """`actions` [K, n] uint8 -> K agent steps enqueued by one library call."""
+             active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS, noise_seed: Optional[int] = None) -> None:
+    """`actions` [K, n] uint8 -> K agent steps enqueued by one library call.  noise_seed: fly in the ground-truth wind
+    (WindField.get_ground_truth: the noise of wind_noise(noise_seed) evaluated in the kernel before every step)."""
     k = actions.shape[0]
     assert actions.dtype == torch.uint8 and actions.is_contiguous() and tuple(actions.shape) == (k, self.n)
     assert rewards.dtype == torch.float32 and tuple(rewards.shape) == (k, self.n) and rewards.is_contiguous()
@@ -248,14 +269,15 @@ class VecSimulator:
     if active_counts is not None:
       assert active_counts.dtype == torch.int64 and tuple(active_counts.shape) == (k, COUNT_SLOTS)
       assert active_counts.is_contiguous()
+    gen = self._noise_gen(noise_seed)
     code = self.lib.ble_step_n_f32(ctypes.byref(self._struct), actions.data_ptr(), self.grid.data_ptr(),
-                                   self.grid_env_stride, rewards.data_ptr(), terminals.data_ptr(),
-                                   self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k,
+                                   self.grid_env_stride, None if gen is None else ctypes.byref(gen), rewards.data_ptr(),
+                                   terminals.data_ptr(), self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k,
                                    dev.stream_ptr(self.device))
     _lib.check(code, 'ble_step_n_f32')
 
   def prepare_step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
-                     active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS):
+                     active_counts: Optional[torch.Tensor] = None, substeps: int = SUBSTEPS, noise_seed: Optional[int] = None):
     """step_n with everything but the launch done NOW: the checks run once and the arguments are marshalled once;
     the returned callable enqueues the K agent steps on the stream that is current when IT is called (~3 us of host
     time instead of ~10).  For loops that launch the same buffers again and again (rollouts, the benchmark); the
@@ -269,8 +291,10 @@ class VecSimulator:
       assert active_counts.is_contiguous()
     assert self.grid is not None, 'Must call set_grid (reset) before step.'
     fn, struct = self.lib.ble_step_n_f32, ctypes.byref(self._struct)
-    args = (struct, actions.data_ptr(), self.grid.data_ptr(), self.grid_env_stride, rewards.data_ptr(),
-            terminals.data_ptr(), self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k)
+    gen = self._noise_gen(noise_seed)            # (kept alive by the closure)
+    grid = self.grid                             # the closure reads THIS tensor: load_state_dict restores it in place
+    args = (struct, actions.data_ptr(), grid.data_ptr(), self.grid_env_stride, None if gen is None else ctypes.byref(gen),
+            rewards.data_ptr(), terminals.data_ptr(), self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k)
     device, index = self.device, self.device.index
 
     def launch():

@@ -36,7 +36,8 @@ extern "C" {
 
 /* 2: ble_state_f32 gained the optional episode_cache; ble_wind_noise_f32 the optional harmonic_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
  *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
-#define BLE_ABI_VERSION 2
+/* 3: ble_step_n_f32 gained `noise` (ble_noise_gen: the wind-noise generator evaluated inside the fused rollout). */
+#define BLE_ABI_VERSION 3
 
 /* return codes */
 #define BLE_OK 0
@@ -68,8 +69,12 @@ extern "C" {
  * Replaces: BalloonState (env/balloon/balloon.py:73-250), the three safety-layer
  * objects it owns (altitude_safety.py:63-111, envelope_safety.py:93-157,
  * power_safety.py:26-126) and Atmosphere's per-episode alpha
- * (standard_atmosphere.py:76-87).  Flight-vehicle constants (balloon.py:156-173) are
- * compile-time constants of the kernel.
+ * (standard_atmosphere.py:76-87).
+ * The flight-vehicle parameters, which are dataclass fields with defaults in the reference (balloon.py:156-173: envelope
+ * volume base / dV/dp, envelope mass, maximum superpressure, drag coefficient, lift-gas mols, payload mass, battery
+ * capacity, day / night loads), are COMPILE-TIME constants of the kernels (csrc/ble_physics.h), fixed at those defaults --
+ * the values every BASELINE configuration flies.  A vehicle with other parameters needs a rebuild; the Python mirrors
+ * raise NotImplementedError for non-default values instead of silently flying the default balloon.
  */
 typedef struct ble_state_f32 {
   /* mutable, read+written by ble_step_f32 (balloon.py:175-195) */
@@ -163,15 +168,30 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
                  int64_t n, int substeps, void* stream);
 
 /*
+ * The wind-noise generator of a fused rollout: the arguments of ble_wind_noise_f32 (below) that do not change from
+ * step to step.  One noise field per (seed, environment index, episode[i]).
+ */
+typedef struct ble_noise_gen {
+  unsigned long long seed;
+  const uint32_t* episode;  /* optional device uint32[n]: the per-environment episode counters ble_reset_f32 maintains (NULL = 0) */
+  uint32_t* harmonic_cache; /* optional, as for ble_wind_noise_f32: [BLE_NOISE_CACHE_ROWS][n] words */
+} ble_noise_gen;
+
+/*
  * `n_steps` consecutive agent steps in ONE kernel launch: the state stays in registers
  * between the steps (loaded once, stored once); per step only the action is read and
  * reward / terminal are written.  action / reward / terminal are [n_steps][n] row-major;
  * active_count, if given, is [n_steps][BLE_COUNT_SLOTS].  Same semantics per step as
  * ble_step_f32.
+ *   noise   NULL: every step flies in the forecast (WindField.get_forecast; noise term 0, SURVEY 8(d)'s bench
+ *           definition).  Otherwise the reference's WindField.get_ground_truth (wind_field.py:125-145): at every
+ *           step the SimplexWindNoise term is evaluated inside the kernel at the pre-step (x, y, pressure, elapsed)
+ *           with the generator `noise` describes -- bit for bit what n_steps rounds of ble_wind_noise_f32(mode 0)
+ *           followed by ble_step_f32(noise_uv) produce (tests/test_gpu_parity.py).
  */
 int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* wind_grid,
-                   int64_t grid_env_stride, float* reward, uint8_t* terminal, uint32_t* err_flags,
-                   unsigned long long* active_count, int64_t n, int substeps, int n_steps,
+                   int64_t grid_env_stride, const ble_noise_gen* noise, float* reward, uint8_t* terminal,
+                   uint32_t* err_flags, unsigned long long* active_count, int64_t n, int substeps, int n_steps,
                    void* stream);
 
 /*
@@ -238,9 +258,11 @@ typedef struct ble_gp_history_f32 {
                          per-step refit of the reference (wind_gp.py:186-188) becomes an O(n^2) slide;
                          opaque to the caller; NULL = refit in LDS every call */
   int32_t* n_chol;    /* [n] rows of `chol` in use (required when chol != NULL), zero-initialised */
-  int64_t chol_stride; /* doubles between the slabs of consecutive environments in `chol`: >= BLE_GP_CHOL_STRIDE when
-                          chol != NULL (a smaller value is rejected with BLE_E_INVALID_ARG: the kernel would write
-                          past the caller's allocation); ignored when chol == NULL */
+  int64_t chol_stride; /* doubles between the slabs of consecutive environments in `chol`: >= BLE_GP_CHOL_STRIDE AND EVEN
+                          when chol != NULL (the kernel moves the slab as 16-byte double2 pairs, so every slab must start
+                          16-byte aligned: `chol` itself 16-byte aligned, the stride a multiple of two doubles).  A smaller
+                          or odd value is rejected with BLE_E_INVALID_ARG -- the kernel would write past the caller's
+                          allocation or fault on a misaligned pair; ignored when chol == NULL */
 } ble_gp_history_f32;
 int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
                     const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,

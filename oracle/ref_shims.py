@@ -7,10 +7,23 @@ is absent (the GPU box): ``available()`` returns False and ``install()`` raises.
 
 What is shimmed: only *container / decorator / value-type*
 third-party modules that are not installed here (s2sphere.LatLng, absl.logging,
-gin.configurable, jax name stubs, transitions.Machine first-match dispatch,
-opensimplex placeholder) and SciPy's removed ``interp2d`` (regular-grid linear
-case, the migration recipe SciPy documents).  Every reference ``.py`` file is
-imported unmodified from ``/root/reference``; no reference source is copied.
+gin.configurable, jax name stubs, transitions.Machine first-match dispatch) and SciPy's
+removed ``interp2d`` (regular-grid linear case, the migration recipe SciPy documents).
+Every reference ``.py`` file is imported unmodified from ``/root/reference``; no reference
+source is copied.
+
+Round 4, for fixtures F14 / F15 (the reference's own Python AROUND two absent third-party pieces):
+  * ``opensimplex.OpenSimplex(seed).noise4d`` -> the kernel's own primitive restated in NumPy
+    (oracle/noise_oracle.py::simplex4).  NOT opensimplex 0.3's values: the fixture pins what the
+    reference does with the primitive, not the primitive.
+  * ``jax.random.split / choice / uniform / normal`` -> recorded draws (NumPy SeedSequence of the key):
+    the JAX threefry streams are not reproduced; the drawn seeds / offsets / latents are stored in
+    the fixture.
+  * ``flax.linen`` Module / Dense / relu / compact -> a 40-line functional stand-in (parameters looked up as
+    flax names them: Dense_0 ... in call order; float64 accumulation).
+  * ``jax.image.resize(method='linear')`` -> torch.nn.functional.interpolate(mode='bilinear',
+    align_corners=False), an independent implementation of half-pixel linear resampling
+    (upsampling: jax's antialias has no effect).  This operator is the stated ASSUMPTION of F15.
 """
 import math
 import os
@@ -116,6 +129,85 @@ def _make_interp2d():
   return interp2d
 
 
+class _StandInSimplex:
+  """opensimplex.OpenSimplex stand-in for fixture F14: noise4d = oracle/noise_oracle.py::simplex4 (the kernel's primitive)."""
+
+  def __init__(self, seed=0):
+    self.seed = int(seed)
+
+  def noise4d(self, x, y, z, w):
+    import noise_oracle
+    return float(noise_oracle.simplex4(np.float64(x), np.float64(y), np.float64(z), np.float64(w), self.seed & 0xFFFFFFFF))
+
+
+def key_rng(key, salt):
+  """The recorded stream behind a stand-in PRNG key (any integer array)."""
+  words = [int(v) & 0xFFFFFFFF for v in np.asarray(key).ravel()]
+  return np.random.default_rng(np.random.SeedSequence(words + [int(salt)]))
+
+
+def _install_jax_random(jrandom):
+  def split(key, num=2):
+    return key_rng(key, 1).integers(0, 2 ** 32, size=(num, 2), dtype=np.uint32)
+
+  def choice(key, a):
+    return np.int64(key_rng(key, 2).integers(0, int(a)))
+
+  def uniform(key, shape=()):
+    # float32 VALUES (jax's default dtype) in a float64 container: under the reference's pinned NumPy 1.x a float32
+    # scalar combined with a Python float is promoted to float64 (value-based casting), which NumPy 2 no longer does
+    return key_rng(key, 3).random(shape).astype(np.float32).astype(np.float64)
+
+  def normal(key, shape=()):
+    return key_rng(key, 4).standard_normal(shape).astype(np.float32)
+  jrandom.split, jrandom.choice, jrandom.uniform, jrandom.normal = split, choice, uniform, normal
+  jrandom.PRNGKey = lambda seed: np.array([0, int(seed) & 0xFFFFFFFF], np.uint32)
+
+
+def _resize_linear(image, shape, method='linear'):
+  """jax.image.resize(method='linear') of an (h, w, c) array: see the module docstring (the assumption of F15)."""
+  import torch
+  assert method == 'linear' and len(shape) == 3 and shape[2] == np.shape(image)[2]
+  t = torch.from_numpy(np.ascontiguousarray(np.asarray(image, np.float64))).permute(2, 0, 1)[None]
+  r = torch.nn.functional.interpolate(t, size=(int(shape[0]), int(shape[1])), mode='bilinear', align_corners=False)
+  return r[0].permute(1, 2, 0).numpy()
+
+
+class _LinenScope:
+  params = None
+  counters = None
+
+
+class _LinenDense:
+  """flax.linen.Dense stand-in: y = x @ kernel + bias with the parameters flax would bind (Dense_<k> in call order)."""
+
+  def __init__(self, features, name=None):
+    self.features, self.name = int(features), name
+
+  def __call__(self, x):
+    name = self.name
+    if name is None:
+      k = _LinenScope.counters.get('Dense', 0)
+      _LinenScope.counters['Dense'] = k + 1
+      name = f'Dense_{k}'
+    p = _LinenScope.params[name]
+    kernel, bias = np.asarray(p['kernel'], np.float64), np.asarray(p['bias'], np.float64)
+    assert kernel.shape[1] == self.features
+    return np.asarray(x, np.float64) @ kernel + bias
+
+
+class _LinenModule:
+  """flax.linen.Module stand-in: dataclass-style fields stay class attributes; apply() binds {'params': {...}}."""
+
+  def apply(self, variables, *args, **kwargs):
+    prev = (_LinenScope.params, _LinenScope.counters)
+    _LinenScope.params, _LinenScope.counters = variables['params'], {}
+    try:
+      return self(*args, **kwargs)
+    finally:
+      _LinenScope.params, _LinenScope.counters = prev
+
+
 def install() -> None:
   """Installs the shims.  Call before importing any reference module."""
   if not available():
@@ -168,8 +260,14 @@ def install() -> None:
   sys.modules.update({'jax': jax, 'jax.numpy': jnp, 'jax.random': jrandom})
 
   osx = types.ModuleType('opensimplex')
-  osx.OpenSimplex = None  # noise is unavailable (dependency absent, parity unpinned)
+  osx.OpenSimplex = _StandInSimplex   # NOT opensimplex 0.3 (absent, unpinned): the kernel's primitive, see the module docstring
   sys.modules['opensimplex'] = osx
+  _install_jax_random(jrandom)
+  jnp.roll, jnp.stack, jnp.sign, jnp.abs = np.roll, np.stack, np.sign, np.abs
+  jimage = types.ModuleType('jax.image')
+  jimage.resize = _resize_linear
+  jax.image = jimage
+  sys.modules['jax.image'] = jimage
 
   tr = types.ModuleType('transitions')
   tr.Machine = _Machine
@@ -205,12 +303,10 @@ def install() -> None:
   flax = types.ModuleType('flax')
   linen = types.ModuleType('flax.linen')
 
-  class Module:
-    pass
-  linen.Module = Module
+  linen.Module = _LinenModule
   linen.compact = lambda f: f
-  linen.Dense = object
-  linen.relu = lambda x: x
+  linen.Dense = _LinenDense
+  linen.relu = lambda x: np.maximum(x, 0.0)
   flax.linen = linen
   sys.modules['flax'] = flax
   sys.modules['flax.linen'] = linen

@@ -21,7 +21,7 @@ dbg = torch.zeros((waves, 64), dtype=torch.int64, device='cuda')
 
 
 def launch(k):
-  code = sim.lib.ble_step_n_f32(ctypes.byref(sim._struct), acts.data_ptr(), sim.grid.data_ptr(), 0, rew.data_ptr(), term.data_ptr(),
+  code = sim.lib.ble_step_n_f32(ctypes.byref(sim._struct), acts.data_ptr(), sim.grid.data_ptr(), 0, None, rew.data_ptr(), term.data_ptr(),
                                 sim.err_flags.data_ptr(), dbg.data_ptr(), n, 18, k, dev.stream_ptr(sim.device))
   assert code == 0
 

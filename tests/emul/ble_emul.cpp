@@ -124,6 +124,14 @@ extern "C" void emul_wind_noise(int64_t n, const float* x_m, const float* y_m, c
     wind_noise(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, &noise_uv[2 * i],
                &noise_uv[2 * i + 1]);
 }
+// the kernel's cached form: `cache` [kNoiseCacheRows][n] words holds the harmonics' seeds / offsets (fixture F14 writes recorded ones)
+extern "C" void emul_wind_noise_cached(int64_t n, const float* x_m, const float* y_m, const float* pressure,
+                                       const int32_t* elapsed_s, uint64_t seed, const uint32_t* episode, uint32_t* cache,
+                                       float* noise_uv) {
+  for (int64_t i = 0; i < n; ++i)
+    wind_noise_cached(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, cache, n,
+                      &noise_uv[2 * i], &noise_uv[2 * i + 1]);
+}
 extern "C" void emul_decode_flow(int64_t n, const float* flow, float* grid) {
   int tap0[23]; float w1[23];
   for (int a = 0; a < 23; ++a) resize_tap(a, &tap0[a], &w1[a]);

@@ -595,6 +595,74 @@ def f13_station_seeker_episode(n_steps=960):
        start_unix=np.array([su], np.int64), **consts, **cols)
 
 
+# ----------------------------------------------------------------------------- F14
+def f14_wind_noise(n_points=192):
+  """The reference's wind-noise COMPOSITION (env/simplex_wind_noise.py:82-211, env/wind_field.py:113-145,187-218) around a
+  stand-in primitive: `opensimplex.OpenSimplex` is oracle/ref_shims.py::_StandInSimplex (the kernel's simplex4, NOT
+  opensimplex 0.3), the jax.random draws of NoisyWindHarmonic.reset are recorded.  Stored: the seeds / offsets the
+  reference's own reset() put into its harmonics, and get_wind_noise / get_ground_truth at seeded points.  Pins the
+  harmonic tables, spacings, offsets, NOISE_MAGNITUDE and the variance adjustment; the primitive stays unpinned."""
+  from balloon_learning_environment.env import simplex_wind_noise
+  rng = np.random.default_rng(14)
+  episodes = 3
+  x = rng.uniform(-4e5, 4e5, (episodes, n_points)); y = rng.uniform(-4e5, 4e5, (episodes, n_points))
+  p = rng.uniform(5000.0, 14000.0, (episodes, n_points)); t = rng.integers(0, 60 * 3600, (episodes, n_points))
+  x[:, 0] = 0.0; y[:, 0] = 0.0; t[:, 0] = 0
+  seeds = np.zeros((episodes, 2, 5), np.int64); offsets = np.zeros((episodes, 2, 5, 4)); noise = np.zeros((episodes, n_points, 2))
+  truth = np.zeros((episodes, n_points, 2)); forecast = np.zeros((episodes, n_points, 2))
+  field = make_field()
+  for e in range(episodes):
+    wf = ref_shims.make_grid_wind_field(field)
+    wf._noise_model = wind_field.SimplexWindNoise()
+    wf._noise_model.reset_wind_noise(np.array([14, e], np.uint32), None)
+    for c, comp in enumerate((wf._noise_model.noise_u, wf._noise_model.noise_v)):
+      for h, harm in enumerate(comp._harmonics):
+        seeds[e, c, h] = harm._simplex_generator.seed
+        offsets[e, c, h] = (harm._offsets.x, harm._offsets.y, harm._offsets.pressure, harm._offsets.time)
+    for i in range(n_points):
+      args = (units.Distance(meters=float(x[e, i])), units.Distance(meters=float(y[e, i])), float(p[e, i]), dt.timedelta(seconds=int(t[e, i])))
+      w = wf._noise_model.get_wind_noise(*args)
+      noise[e, i] = (w.u.meters_per_second, w.v.meters_per_second)
+      g = wf.get_ground_truth(*args); f = wf.get_forecast(*args)
+      truth[e, i] = (g.u.meters_per_second, g.v.meters_per_second); forecast[e, i] = (f.u.meters_per_second, f.v.meters_per_second)
+  assert seeds.max() < 1634753849 and np.abs(offsets).max() <= 1.0
+  save('f14_wind_noise', x=x, y=y, pressure=p, elapsed_s=t.astype(np.int64), seeds=seeds, offsets=offsets, noise=noise,
+       ground_truth=truth, forecast=forecast, field_seed=np.int64(0), field_scale=np.float64(5.0),
+       noise_magnitude=np.float64(simplex_wind_noise.NOISE_MAGNITUDE))
+
+
+# ----------------------------------------------------------------------------- F15
+def f15_decoder(n_samples=2):
+  """The reference's VAE decoder (generative/vae.py:140-186) and GenerativeWindFieldSampler.sample_field
+  (env/generative_wind_field.py:49-62), imported unmodified, on synthetic weights (tests/helpers.py::
+  hashed_decoder_params(seed 15); the trained ones are absent) with the flax / jax stand-ins of oracle/ref_shims.py.  Pins
+  the layer order and activations, the (7, 7, 90) reshape, the roll / slice order of the central differences, u = d psi /
+  d axis0, v = -d psi / d axis1, the (21, 21, 10, 9) reshape and the stack axis; the resize operator is the assumption."""
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+  from balloon_learning_environment.env import generative_wind_field as gwf
+  from balloon_learning_environment.generative import vae
+  params = helpers.hashed_decoder_params(seed=15)
+  variables = {'params': {f'Dense_{k}': {'kernel': w, 'bias': b} for k, (w, b) in enumerate(params)}}
+  sampler = gwf.GenerativeWindFieldSampler.__new__(gwf.GenerativeWindFieldSampler)
+  sampler.params = variables
+  import jax
+  latents = np.zeros((n_samples, 64), np.float32); fields = np.zeros((n_samples, 21, 21, 10, 9, 2)); flow = np.zeros((n_samples, 4410))
+  for i in range(n_samples):
+    key = np.array([15, i], np.uint32)
+    latents[i] = jax.random.normal(key, shape=(64,))
+    fields[i] = sampler.sample_field(key, None)
+    z = np.asarray(latents[i], np.float64)                       # the MLP output alone (vae.py:145-148), for a per-stage check
+    for k, (w, b) in enumerate(params):
+      z = z @ np.asarray(w, np.float64) + np.asarray(b, np.float64)
+      if k < 3:
+        z = np.maximum(z, 0.0)
+    flow[i] = z
+  assert fields.shape[1:] == vae.FieldShape().grid_shape() and np.isfinite(fields).all()
+  print(f'f15: |wind| max {np.abs(fields).max():.2f} m/s, rms {np.sqrt((fields ** 2).mean()):.2f}')
+  save('f15_decoder', param_seed=np.int64(15), latents=latents, flow=flow, fields=fields.astype(np.float32))
+
+
 if __name__ == '__main__':
   which = sys.argv[1:] or ['all']
   if 'all' in which:
@@ -602,3 +670,7 @@ if __name__ == '__main__':
     f8_trajectories(); f9_arena(); f10_reset(); f11_features(); f12_features_long()
   if 'all' in which or 'f13' in which:
     f13_station_seeker_episode()
+  if 'all' in which or 'f14' in which:
+    f14_wind_noise()
+  if 'all' in which or 'f15' in which:
+    f15_decoder()

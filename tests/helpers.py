@@ -99,3 +99,40 @@ def wide_domain_states(n, seed):
   init['envelope_volume'][:] = vol; init['superpressure'][:] = sp
   init['alt_fsm'][:] = rng.integers(0, 3, n); init['env_fsm'][:] = rng.integers(0, 5, n); init['power_paused'][:] = rng.integers(0, 2, n)
   return init
+
+
+def hashed_decoder_params(seed=0, hidden=1000, output_gain=30.0):
+  """Synthetic weights of the wind-field VAE decoder (generative/vae.py:140-148: 64 -> hidden x 3 -> 4410, ReLU) for
+  fixture F15: [(kernel [in, out] float32, bias [out] float32)] x 4.  A pure integer hash of (layer, row, column, seed)
+  -> uniform(-1, 1) scaled like LeCun initialisation, NON-zero biases -- no dependence on any library's random streams,
+  so the generator (build container) and the test (GPU box) always rebuild the same numbers."""
+  dims = [64, hidden, hidden, hidden, 7 * 7 * 90]
+  out = []
+  for layer, (a, b) in enumerate(zip(dims, dims[1:])):
+    def unit(rows, cols, salt):
+      with np.errstate(over='ignore'):
+        h = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(0x9E3779B97F4A7C15) +
+             np.arange(cols, dtype=np.uint64)[None, :] * np.uint64(0xC2B2AE3D27D4EB4F) +
+             np.uint64((seed * 1000003 + layer * 7919 + salt) & 0xFFFFFFFF))
+        h ^= h >> np.uint64(29); h *= np.uint64(0xBF58476D1CE4E5B9); h ^= h >> np.uint64(32)
+        h *= np.uint64(0x94D049BB133111EB); h ^= h >> np.uint64(29)
+      return (h >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0      # uniform [-1, 1)
+    gain = output_gain if layer == 3 else np.sqrt(2.0)
+    kernel = (unit(a, b, 1) * np.sqrt(3.0 / a) * gain).astype(np.float32)
+    bias = (unit(1, b, 2)[0] * (0.5 if layer == 3 else 0.05)).astype(np.float32)
+    out.append((kernel, bias))
+  return out
+
+
+def noise_cache_from_draws(seeds, offsets, n, seed, episode=0):
+  """The `harmonic_cache` of ble_wind_noise_f32 / ble_noise_gen ([53][n] 32-bit words) holding GIVEN generator seeds
+  [2][5] and offsets [2][5][4] for all n environments -- as if they had been drawn for (seed, episode): rows 5 k .. 5 k + 4 =
+  (seed, ox, oy, op, ot) of harmonic k = 5 comp + h, rows 50 .. 52 the key (episode + 1, seed lo, seed hi)."""
+  c = np.zeros((53, n), np.uint32)
+  for comp in range(2):
+    for h in range(5):
+      k = 5 * comp + h
+      c[5 * k] = np.uint32(int(seeds[comp][h]) & 0xFFFFFFFF)
+      c[5 * k + 1:5 * k + 5] = np.asarray(offsets[comp][h], np.float32).view(np.uint32)[:, None]
+  c[50] = np.uint32(episode + 1); c[51] = np.uint32(seed & 0xFFFFFFFF); c[52] = np.uint32((seed >> 32) & 0xFFFFFFFF)
+  return c

@@ -142,3 +142,38 @@ def test_device_noise_equals_host_build(lib):
   assert torch.equal(cache[50], epd2 + 1)
   both(2 ** 40 + 5, epd2)
   assert int(cache[52][0]) == 2 ** 8 and int(cache[51][0]) == 5
+
+
+def test_f14_device_noise_matches_reference_composition(lib):
+  """ble_wind_noise_f32 (mode 0) fed the fixture's recorded generator seeds / offsets through its harmonic cache == the
+  reference's SimplexWindNoise.get_wind_noise (wind_field.py:187-218, simplex_wind_noise.py:82-211; tests/golden/
+  f14_wind_noise.npz: the reference's own code around the stand-in primitive) times the ratio of the two variance
+  normalisations (oracle/noise_oracle.py): harmonic tables, spacings, offsets, magnitude and variance adjustment are the
+  reference's.  Bound as in the CPU twin (tests/test_oracle_golden.py): 1e-5 + the float32 sensitivities, computed here; the
+  device equals the float32 oracle to 1e-5 outright.  And the in-kernel generator of the fused rollout reads the same cache."""
+  import helpers
+  import noise_oracle
+  d = helpers.golden('f14_wind_noise')
+  seed = 77
+  for e in range(d['x'].shape[0]):
+    n = d['x'].shape[1]
+    cache_h = helpers.noise_cache_from_draws(d['seeds'][e], d['offsets'][e], n, seed=seed, episode=e)
+    cache = torch.from_numpy(cache_h.view(np.int32)).cuda()
+    xs, ys, ps = (np.ascontiguousarray(d[k][e], np.float32) for k in ('x', 'y', 'pressure'))
+    ts = np.ascontiguousarray(d['elapsed_s'][e], np.int32)
+    dx, dy, dp, dt_ = (torch.from_numpy(a).cuda() for a in (xs, ys, ps, ts))
+    ep = torch.full((n,), e, dtype=torch.int32, device='cuda')
+    out = torch.empty(n, 2, device='cuda')
+    assert lib.ble_wind_noise_f32(dx.data_ptr(), dy.data_ptr(), dp.data_ptr(), dt_.data_ptr(), seed, ep.data_ptr(), 0, cache.data_ptr(),
+                                  out.data_ptr(), n, 0) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(cache.cpu().numpy().view(np.uint32), cache_h)          # key matched: nothing was redrawn
+    got = out.cpu().numpy().astype(np.float64)
+    want = d['noise'][e] * noise_oracle.MAGNITUDE_RATIO
+    o32 = noise_oracle.wind_noise(xs, ys, ps, ts, d['seeds'][e], d['offsets'][e], np.float32)
+    o64 = noise_oracle.wind_noise(xs.astype(np.float64), ys.astype(np.float64), ps.astype(np.float64), ts, d['seeds'][e], d['offsets'][e], np.float64)
+    bound = 1e-5 + np.abs(o32 - o64) + np.abs(o64 - want)
+    err = np.abs(got - want)
+    assert (err <= bound).all(), (err.max(), bound.max())
+    assert np.abs(got - o32).max() < 1e-5
+    print(f'F14 episode {e}: device vs reference x ratio {err.max():.2e}, vs float32 oracle {np.abs(got - o32).max():.2e}')

@@ -402,7 +402,7 @@ def test_invalid_arguments_return_codes(ble):
   # ABI 2: the carried WindGP slab is 7 620 doubles per environment; a caller that still allocates version 1's 7 260 is
   # refused instead of being overrun
   from balloon_learning_environment_amd import _abi
-  assert lib.ble_abi_version() == 2
+  assert lib.ble_abi_version() == 3
   gp = dict(xyp=torch.zeros(4, 128, 3).cuda(), elapsed_s=torch.zeros(4, 128, dtype=torch.int32).cuda(), err_uv=torch.zeros(4, 128, 2).cuda(),
             count=torch.zeros(4, dtype=torch.int32).cuda(), chol=torch.zeros(4, 7620, dtype=torch.float64).cuda(),
             n_chol=torch.zeros(4, dtype=torch.int32).cuda())
@@ -783,6 +783,51 @@ def test_fused_rollout_equals_single_steps(ble, wide):
     np.testing.assert_array_equal(sa[name], sc[name], err_msg=name)
   np.testing.assert_array_equal(rew.cpu().numpy(), rew_c.cpu().numpy())
   np.testing.assert_array_equal(term.cpu().numpy(), term_c.cpu().numpy())
+
+
+@pytest.mark.parametrize('with_cache', [True, False])
+def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, with_cache):
+  """ABI 3: ble_step_n_f32 with a noise generator flies every step in WindField.get_ground_truth = forecast + SimplexWindNoise
+  (wind_field.py:125-145), the noise evaluated INSIDE the kernel at the pre-step position.  Bit for bit what K rounds of
+  ble_wind_noise_f32 followed by ble_step_f32(noise_uv) give -- state, rewards, terminals -- for environments in different
+  episodes (the generator is keyed by (seed, env, episode)), with and without the harmonic cache; and it is NOT the forecast
+  flight."""
+  import ctypes
+  from balloon_learning_environment_amd import _abi, _lib, device as dev, reset_host
+  n, k, seed = 4096, 6, 20240917
+  init = reset_host.sample_initial_state(n, seed=15)
+  init['battery_charge'][:48] = 0.2                 # a few environments end inside the rollout
+  field = (np.random.default_rng(1).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(2).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  episodes = torch.from_numpy(np.random.default_rng(3).integers(0, 5, n).astype(np.int32)).cuda()
+  sims = []
+  for _ in range(3):
+    s = ble.VecSimulator(n); s.set_state(init); s.set_grid(field); s.episode.copy_(episodes); sims.append(s)
+  a, b, c = sims
+  rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
+  if with_cache:
+    a.step_n(acts, rew, term, noise_seed=seed)
+  else:                                              # harmonic_cache NULL: the draws are redone by every step
+    gen = _abi.BleNoiseGen(seed, a.episode.data_ptr(), None)
+    _lib.check(a.lib.ble_step_n_f32(ctypes.byref(a._struct), acts.data_ptr(), a.grid.data_ptr(), 0, ctypes.byref(gen), rew.data_ptr(),
+                                    term.data_ptr(), a.err_flags.data_ptr(), None, n, 18, k, dev.stream_ptr(a.device)), 'ble_step_n_f32')
+  rb, tb = [], []
+  for j in range(k):
+    noise = b.wind_noise(seed)
+    r, t = b.step(acts[j].contiguous(), noise)
+    rb.append(r.clone()); tb.append(t.clone())
+  rew_c = torch.zeros_like(rew); term_c = torch.zeros_like(term)
+  c.step_n(acts, rew_c, term_c)                     # the forecast flight
+  torch.cuda.synchronize()
+  a.check_errors(); b.check_errors()
+  sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+  for name in sa:
+    np.testing.assert_array_equal(sa[name], sb[name], err_msg=name)
+  np.testing.assert_array_equal(rew.cpu().numpy(), torch.stack(rb).cpu().numpy())
+  np.testing.assert_array_equal(term.cpu().numpy(), torch.stack(tb).cpu().numpy())
+  assert (sa['status'] != 0).sum() >= 48
+  moved = np.hypot(sa['x'] - sc['x'], sa['y'] - sc['y'])
+  assert np.median(moved) > 100.0                   # ~1 m/s of noise over 18 minutes
 
 
 # ---------------------------------------------------------------- device reset (SURVEY 8f #2)

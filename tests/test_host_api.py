@@ -45,7 +45,7 @@ def test_gp_history_struct_matches_header_order():
   names = re.findall(r'(?:\*|int64_t)\s*(\w+);', body)       # the pointer members, then the int64 slab stride (ABI 2)
   assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_] and names[-1] == 'chol_stride'
   assert ctypes.sizeof(_abi.BleGpHistoryF32) == 8 * len(names)
-  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 2
+  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 3
   assert int(re.search(r'#define BLE_OBS_DIM (\d+)', header).group(1)) == _lib.OBS_DIM
   assert int(re.search(r'#define BLE_GP_CAPACITY (\d+)', header).group(1)) == _lib.GP_CAPACITY
   assert int(re.search(r'#define BLE_GP_CHOL_STRIDE (\d+)', header).group(1)) == _lib.GP_CHOL_STRIDE

@@ -426,3 +426,85 @@ def test_f13_feature_oracle_closed_loop():
         np.testing.assert_allclose(f, g['features'][0, i], rtol=0, atol=1e-6, err_msg=f'step {i}')
       if i < n:
         assert sso.pick_action(f.astype(np.float32)) == g['actions'][0, i], i
+
+
+# ---------------------------------------------------------------- wind noise composition (F14) and VAE decoder (F15)
+def test_f14_noise_composition_oracle_matches_reference():
+  """oracle/noise_oracle.py::wind_noise == the reference's SimplexWindNoise.get_wind_noise (wind_field.py:187-218,
+  simplex_wind_noise.py:82-211) on the recorded seeds / offsets, both around the same stand-in primitive: pins the harmonic
+  tables, spacings, offsets, NOISE_MAGNITUDE and the variance adjustment.  (The primitive itself is not opensimplex 0.3.)"""
+  import math
+  import noise_oracle
+  d = golden('f14_wind_noise')
+  assert d['noise_magnitude'] == math.sqrt(1.02 / 0.0569) == noise_oracle.REFERENCE_MAGNITUDE     # simplex_wind_noise.py:76
+  for e in range(d['x'].shape[0]):
+    got = noise_oracle.wind_noise(d['x'][e], d['y'][e], d['pressure'][e], d['elapsed_s'][e], d['seeds'][e], d['offsets'][e],
+                                  np.float64, magnitude=noise_oracle.REFERENCE_MAGNITUDE)
+    np.testing.assert_allclose(got, d['noise'][e], rtol=0, atol=1e-12)
+    # WindField.get_ground_truth = get_forecast + noise (wind_field.py:125-145)
+    np.testing.assert_allclose(d['ground_truth'][e], d['forecast'][e] + d['noise'][e], rtol=0, atol=1e-12)
+  assert np.abs(d['noise']).max() > 1.0 and 0 < d['seeds'].min() and d['seeds'].max() < 1634753849
+  assert len(np.unique(d['seeds'])) == d['seeds'].size
+
+
+def test_f14_kernel_source_host_build_matches_reference_composition():
+  """The kernel's own noise source (csrc/ble_noise.h::wind_noise_cached, host build) fed the recorded seeds / offsets
+  through its harmonic cache == the reference's output scaled by the ratio of the two variance normalisations
+  (noise_oracle.MAGNITUDE_RATIO: the reference divides by the variance of opensimplex, 0.0569; the kernel by its own
+  primitive's, 0.088392 -- both aim at 1.02 (m/s)^2).  Tolerance: 1e-5 + the float32-vs-float64 sensitivity of the noise to
+  its coordinates, computed here with the oracle in both precisions (pressure / 66.553 has an ulp of 1.5e-5 in float32)."""
+  import ctypes
+  import noise_oracle
+  from emul import emul
+  d = golden('f14_wind_noise')
+  worst = 0.0
+  for e in range(d['x'].shape[0]):
+    n = d['x'].shape[1]
+    cache = np.ascontiguousarray(helpers.noise_cache_from_draws(d['seeds'][e], d['offsets'][e], n, seed=77, episode=e))
+    xs, ys, ps = (np.ascontiguousarray(d[k][e], np.float32) for k in ('x', 'y', 'pressure'))
+    ts = np.ascontiguousarray(d['elapsed_s'][e], np.int32); ep = np.full(n, e, np.uint32)
+    out = np.zeros((n, 2), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    emul.lib().emul_wind_noise_cached(ctypes.c_int64(n), vp(xs), vp(ys), vp(ps), vp(ts), ctypes.c_uint64(77), vp(ep), vp(cache), vp(out))
+    assert np.array_equal(cache, helpers.noise_cache_from_draws(d['seeds'][e], d['offsets'][e], n, seed=77, episode=e))   # key matched: not redrawn
+    want = d['noise'][e] * noise_oracle.MAGNITUDE_RATIO
+    o32 = noise_oracle.wind_noise(xs, ys, ps, ts, d['seeds'][e], d['offsets'][e], np.float32)
+    o64 = noise_oracle.wind_noise(xs.astype(np.float64), ys.astype(np.float64), ps.astype(np.float64), ts, d['seeds'][e], d['offsets'][e], np.float64)
+    # |o64 - want|: what rounding the fixture's float64 positions to the ABI's float32 does to the REFERENCE'S value;
+    # |o32 - o64|: float32 coordinate arithmetic (the kernel's) against float64 on the same float32 inputs
+    bound = 1e-5 + np.abs(o32 - o64) + np.abs(o64 - want)
+    err = np.abs(out.astype(np.float64) - want)
+    assert (err <= bound).all(), (err.max(), bound.max())
+    assert np.abs(o64 - want).max() < 2e-4 and np.abs(o32 - o64).max() < 2e-4     # (and neither sensitivity is large)
+    assert np.abs(out - o32).max() < 1e-5                             # kernel source == float32 oracle up to fma / op order
+    worst = max(worst, err.max())
+  print(f'F14 host build vs reference x ratio: worst {worst:.2e}')
+
+
+def test_f15_decoder_oracle_matches_reference():
+  """oracle/vae_oracle.py == the reference's Decoder.__call__ / GenerativeWindFieldSampler.sample_field (generative/vae.py:140-186,
+  env/generative_wind_field.py:49-62) on synthetic weights: layer order, ReLUs, (7, 7, 90) reshape, roll / slice order, signs,
+  (21, 21, 10, 9) reshape, stack axis.  The resize operator is the fixture's stated assumption."""
+  import vae_oracle
+  d = golden('f15_decoder')
+  params = helpers.hashed_decoder_params(int(d['param_seed']))
+  flow = vae_oracle.mlp(d['latents'], params)
+  np.testing.assert_allclose(flow, d['flow'], rtol=1e-12, atol=1e-12)
+  fields = vae_oracle.decode_flow(d['flow'])
+  scale = np.abs(d['fields']).max()
+  assert np.abs(fields - d['fields']).max() <= 2e-7 * scale           # the fixture stores float32
+  # it would notice: u / v swapped, a sign, the transposed reshape
+  assert np.abs(fields[..., ::-1] - d['fields']).max() > 0.1 * scale
+  assert np.abs(vae_oracle.decode_flow(d['flow'].reshape(-1, 90, 49).transpose(0, 2, 1).reshape(-1, 4410)) - d['fields']).max() > 0.1 * scale
+
+
+def test_f15_kernel_tail_host_build_matches_reference():
+  """The decoder tail's own source (csrc/ble_decode.h, host build) on the fixture's MLP output == the reference's fields."""
+  import ctypes
+  from emul import emul
+  d = golden('f15_decoder')
+  flow = np.ascontiguousarray(d['flow'], np.float32)
+  grid = np.empty((flow.shape[0], 21, 21, 10, 9, 2), np.float32)
+  emul.lib().emul_decode_flow(ctypes.c_int64(flow.shape[0]), flow.ctypes.data_as(ctypes.c_void_p), grid.ctypes.data_as(ctypes.c_void_p))
+  scale = np.abs(d['fields']).max()
+  assert np.abs(grid - d['fields']).max() <= 2e-6 * scale
