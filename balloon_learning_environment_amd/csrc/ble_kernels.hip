@@ -372,8 +372,10 @@ __global__ __launch_bounds__(kDecodeThreads) void ble_decode_flow_kernel(const f
   for (int t = threadIdx.x; t < 7 * 7 * 90; t += kDecodeThreads) psi[t] = flow[env * (7 * 7 * 90) + t];
   __syncthreads();
   const int f = (int)threadIdx.x % 90, g = (int)threadIdx.x / 90;
-  if (g >= kDecodeGroups) return;            // (no barrier below is reached by a subset: the last one follows)
-  for (int rb = g; rb < 7 * 23; rb += kDecodeGroups) {
+  // the threads beyond the last group of 90 (kDecodeThreads rounds up to whole waves) run neither loop but DO reach the
+  // barrier: their loops start at the end, there is no early return
+  const int g_step = g < kDecodeGroups ? kDecodeGroups : 1;
+  for (int rb = g < kDecodeGroups ? g : 7 * 23; rb < 7 * 23; rb += g_step) {
     const int r = rb / 23, b = rb - 23 * r;
     const int b0 = tap0[b], b_lo = b0 < 0 ? 0 : b0, b_hi = b0 + 1 > 6 ? 6 : b0 + 1;
     const float lo = psi[(r * 7 + b_lo) * 90 + f];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kDecodeThreads) void ble_decode_flow_kernel(const f
   }
   __syncthreads();
   float2* out = reinterpret_cast<float2*>(grid + env * (int64_t)(21 * 21 * 90 * 2)) + f;
-  for (int i = g; i < 21; i += kDecodeGroups) {
+  for (int i = g < kDecodeGroups ? g : 21; i < 21; i += g_step) {
     // first-axis taps of the lattice rows i, i + 1, i + 2
     int lo_row[3], hi_row[3]; float wa[3];
 #pragma unroll

@@ -59,7 +59,10 @@ class OutputGatherer:
   waiting for the producer so that it overlaps the following steps.
   """
 
-  def __init__(self, k: int, n_local: int, device, world: Optional[int] = None, dst: int = 0):
+  def __init__(self, k: int, n_local: int, device, world: Optional[int] = None, dst: int = 0, slots: int = 1):
+    """slots: receive slots of gather_packed on rank `dst`, used round-robin.  A region of L launches issues its L gathers
+    back to back on the side stream; with slots >= L every launch's rows are still there when wait() returns (one slot
+    would keep only the last launch's)."""
     initialized = dist.is_available() and dist.is_initialized()
     self.world = world if world is not None else (dist.get_world_size() if initialized else 1)
     self.rank = dist.get_rank() if initialized else 0
@@ -71,7 +74,11 @@ class OutputGatherer:
     self.reward = torch.zeros((rows, k, n_local), dtype=torch.float32, device=device)
     self.terminal = torch.zeros((rows, k, n_local), dtype=torch.uint8, device=device)
     self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
-    self.packed = None          # [world, 5 k n_local] uint8 on rank dst: the packed blocks of gather_packed
+    self.slots = max(1, int(slots))
+    # a rank's row of a slot starts 16-byte aligned whatever k and n_local are (unpack() views it as float32)
+    self.row_bytes = -(-5 * k * n_local // 16) * 16
+    self.packed = None          # [slots, world, row_bytes] uint8 on rank dst: the packed blocks of gather_packed
+    self.packed_gathers = 0     # gather_packed calls so far: call g went to slot g % slots
     self.gathers = 0            # exchanges issued by this rank
     self.rows_gathered = 0      # agent steps they carried
 
@@ -100,22 +107,25 @@ class OutputGatherer:
     else:
       self._gather(reward_block, terminal_block, c)
 
-  def gather_packed(self, block: torch.Tensor, c: int) -> None:
+  def gather_packed(self, block: torch.Tensor, c: int) -> int:
     """ONE exchange per launch instead of two: `block` is the launch's packed output (packed_output_block: the [c, n_local]
     float32 rewards followed by the [c, n_local] uint8 terminals, 5 c n_local bytes); rank `dst` finds rank r's copy in
-    packed[r][:5 c n_local] (unpack()).  Fewer, larger messages: every point-to-point gather costs its latency once."""
+    slot (call number % slots) of `packed` (unpack(r, c, slot)).  Fewer, larger messages: every point-to-point gather costs
+    its latency once.  Returns the slot."""
     nbytes = int(block.numel())
     assert block.dtype == torch.uint8 and block.is_contiguous() and nbytes == 5 * int(c) * self.n_local and 0 < int(c) <= self.k
     if self.packed is None:
       rows = self.world if self.is_dst else 0
-      self.packed = torch.zeros((rows, 5 * self.k * self.n_local), dtype=torch.uint8, device=block.device)
+      self.packed = torch.zeros((self.slots, rows, self.row_bytes), dtype=torch.uint8, device=block.device)
+    slot = self.packed_gathers % self.slots
+    self.packed_gathers += 1
     self.gathers += 1; self.rows_gathered += int(c)
     if self.world == 1:
-      self.packed[0][:nbytes].copy_(block)
-      return
+      self.packed[slot][0][:nbytes].copy_(block)
+      return slot
 
     def go():
-      dist.gather(block, [self.packed[r][:nbytes] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
+      dist.gather(block, [self.packed[slot][r][:nbytes] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
     if self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream(block.device))
       with torch.cuda.stream(self.stream):
@@ -123,11 +133,15 @@ class OutputGatherer:
         block.record_stream(self.stream)
     else:
       go()
+    return slot
 
-  def unpack(self, r: int, c: int):
-    """(reward [c, n_local] float32, terminal [c, n_local] uint8) views of rank r's last packed block (rank `dst` only)."""
+  def unpack(self, r: int, c: int, slot: Optional[int] = None):
+    """(reward [c, n_local] float32, terminal [c, n_local] uint8) views of rank r's packed block in `slot` (default: the
+    slot of the most recent gather_packed); rank `dst` only, after wait()."""
     n = self.n_local
-    row = self.packed[r]
+    if slot is None:
+      slot = (self.packed_gathers - 1) % self.slots
+    row = self.packed[slot][r]
     return row[:4 * c * n].view(torch.float32).view(c, n), row[4 * c * n:5 * c * n].view(c, n)
 
   def wait(self) -> None:
@@ -159,28 +173,78 @@ def run_region(launches, gatherer: Optional['OutputGatherer']) -> None:
     gatherer.wait()
 
 
-class ObservationGatherer:
-  """Collects the [n_local, 1099] observation blocks of every rank on rank `dst` (the learner):
-  one point-to-point `gather` per observation launch (4 396 B per env; 288 MB per exchange
-  for 65 536 envs per GPU), on a side stream like OutputGatherer.  Double-buffered on the
-  producer side: the kernel of step t+1 may overwrite its output while step t is in flight."""
+XGMI_LINK_GBS = 153.0      # one direction of one xGMI link between two GPUs of a node (MI355X_MICROARCH.md); 7 links per GPU
+OBSERVATION_MODES = ('gather', 'all_to_all', 'local')
 
-  def __init__(self, n_local: int, obs_dim: int, device, world: Optional[int] = None, dst: int = 0):
+
+def observation_exchange_model(mode: str, n_local: int, obs_dim: int, world: int) -> dict:
+  """Bytes and the link-bound time of one observation exchange (arithmetic, not a measurement: DESIGN.md section 7).
+  The GPUs of a node are fully connected by point-to-point xGMI links, so transfers to / from DIFFERENT peers run in parallel:
+    gather      every rank sends its whole block to the learner rank: each of the learner's world - 1 links carries one block
+                (n_local x obs_dim x 4 B = 288 MB at 65 536 environments) -- the links work in parallel, the exchange takes one
+                block's time (1.9 ms); the learner ingests (world - 1) blocks (2.0 GB at 8 GPUs: 0.25 ms of its HBM).
+    all_to_all  every rank keeps 1 / world of its block and sends 1 / world to each peer (a data-parallel learner: rank r
+                consumes rows r of every block): each link carries block / world (36 MB: 0.24 ms at 8 GPUs).
+    local       the consumer of a rank's observations lives on that rank (a policy replica per GPU): nothing moves."""
+  block = n_local * obs_dim * 4
+  if world <= 1 or mode == 'local':
+    per_link, sent, received = 0, 0, 0
+  elif mode == 'gather':
+    per_link, sent, received = block, block, (world - 1) * block       # (sent: by every rank but the learner; received: by the learner)
+  elif mode == 'all_to_all':
+    per_link = block // world
+    sent = received = (world - 1) * per_link
+  else:
+    raise ValueError(mode)
+  return {'mode': mode, 'block_bytes_per_rank': block, 'bytes_per_link': per_link, 'bytes_sent_per_rank': sent,
+          'bytes_received_max_per_rank': received, 'expected_ms_link_bound': 1e3 * per_link / (XGMI_LINK_GBS * 1e9),
+          'link_gbs_assumed': XGMI_LINK_GBS}
+
+
+class ObservationGatherer:
+  """Hands the [n_local, 1099] observation block of every rank to whoever consumes it, on a side stream like
+  OutputGatherer (4 396 B per env; 288 MB per block for 65 536 envs per GPU).  Three consumers (`mode`):
+    'gather'      one learner on rank `dst`: a point-to-point `gather`; rank dst finds rank r's block in obs[r]
+    'all_to_all'  a data-parallel learner: rank r receives rows [r n_local / world, (r + 1) n_local / world) of EVERY
+                  rank's block (`all_to_all_single`); it finds the slice that came from rank q in obs[q]
+                  ([world, n_local / world, obs_dim] on every rank); 1 / world of the gather's bytes per link
+    'local'       the consumer is on the producing rank (a policy replica per GPU): no exchange; obs[0] IS the block
+  observation_exchange_model() gives the bytes and the link-bound time of each.  Double-buffered on the producer side: the
+  kernel of step t + 1 may overwrite its output while step t is in flight."""
+
+  def __init__(self, n_local: int, obs_dim: int, device, world: Optional[int] = None, dst: int = 0, mode: str = 'gather'):
     initialized = dist.is_available() and dist.is_initialized()
     self.world = world if world is not None else (dist.get_world_size() if initialized else 1)
     self.rank = dist.get_rank() if initialized else 0
     self.dst, self.is_dst = dst, self.rank == dst
-    rows = self.world if self.is_dst else 0
-    self.obs = torch.zeros((rows, n_local, obs_dim), dtype=torch.float32, device=device)
+    assert mode in OBSERVATION_MODES, mode
+    self.mode, self.n_local, self.obs_dim = mode, n_local, obs_dim
+    if mode == 'gather':
+      rows = self.world if self.is_dst else 0
+      self.obs = torch.zeros((rows, n_local, obs_dim), dtype=torch.float32, device=device)
+    elif mode == 'all_to_all':
+      assert n_local % self.world == 0, 'all_to_all re-partitions the block into world equal row slices'
+      self.obs = torch.zeros((self.world, n_local // self.world, obs_dim), dtype=torch.float32, device=device)
+    else:
+      self.obs = None              # gather() points it at the producer's own block
     self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+    self.exchanges = 0
+    self.model = observation_exchange_model(mode, n_local, obs_dim, self.world)
 
   def gather(self, block: torch.Tensor) -> None:
+    self.exchanges += 1
+    if self.mode == 'local':
+      self.obs = block[None]
+      return
     if self.world == 1:
-      self.obs[0].copy_(block)
+      self.obs.view(-1, self.obs_dim).copy_(block)
       return
 
     def go():
-      dist.gather(block, [self.obs[r] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
+      if self.mode == 'gather':
+        dist.gather(block, [self.obs[r] for r in range(self.world)] if self.is_dst else None, dst=self.dst)
+      else:
+        dist.all_to_all_single(self.obs.view(-1, self.obs_dim), block)
     if self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream(block.device))
       with torch.cuda.stream(self.stream):
@@ -190,7 +254,7 @@ class ObservationGatherer:
       go()
 
   def wait(self) -> None:
-    if self.stream is not None:
+    if self.stream is not None and self.mode != 'local':
       torch.cuda.current_stream(self.obs.device).wait_stream(self.stream)
 
 

@@ -41,6 +41,9 @@ Besides `value`, the default run reports (rank 0; every leg is the same code pat
   `configs`      env-steps/s of configs[1], [3]'s per-GPU shard (8 192 envs; the real sharded run when N > 1)
                  and [4]'s per-GPU share (32 768 envs with per-env grids), and the single-env facade
                  (configs[0]'s counterpart: BalloonEnv.step with the device observation)
+  `config.ground_truth_wind`  the headline rollout flown in WindField.get_ground_truth (noise generated in-kernel, ABI 3)
+  `roofline.instruction_issue`  SQ issue counters of the headline launch shape measured IN THIS RUN (a third --pmc pass);
+                 `roofline.valu_issue_frac` is the fraction of the bound that actually applies
   `observe`      the closed-loop cost: step + wind noise + the 1099-feature observation (ble_observe_f32)
                  with a full WindGP window, its own roofline and measured traffic
   `cpu_baseline` the fp64 C oracle on this box's host cores (N = 1 only)
@@ -139,7 +142,7 @@ class Rollout:
   """One preset's workload on this rank: state + grid resident in HBM, `time_reps` runs the timed region."""
 
   def __init__(self, n, device, rank, world, *, per_env_grids=False, shared_field=None, seed_base=1000,
-               steps=192, warmup=32, substeps=18):
+               steps=192, warmup=32, substeps=18, noise_seed=None):
     import numpy as np
     import torch
     from balloon_learning_environment_amd import distributed as bdist
@@ -148,6 +151,7 @@ class Rollout:
     self.torch, self.bdist, self.np = torch, bdist, np
     self.n, self.device, self.rank, self.world = n, device, rank, world
     self.steps, self.warmup, self.substeps = steps, warmup, substeps
+    self.noise_seed = noise_seed          # None: forecast wind; else WindField.get_ground_truth, noise generated in-kernel
     k_total = steps + warmup
     # synthetic inputs (host, seeded; env i of the GLOBAL batch always gets the same draw), resident in HBM
     self.host_state = reset_host.sample_initial_state(n, seed=seed_base + rank)
@@ -169,8 +173,9 @@ class Rollout:
       self.sim.set_grid(shared_field)
     gen = torch.Generator(device=device); gen.manual_seed(7 + rank)
     self.actions = torch.randint(0, 3, (k_total, n), dtype=torch.uint8, device=device, generator=gen)
-    self.gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world) if world > 1 else None
     self.launches_per_region = -(-steps // GATHER_EVERY)
+    # one receive slot per launch of a region: when the region's wait() returns, rank 0 holds EVERY launch's rows
+    self.gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world, slots=self.launches_per_region) if world > 1 else None
 
   def plan(self, k0, k1):
     """The launches of steps k0 .. k1 - 1, prepared once (VecSimulator.prepare_step_n: checks and argument marshalling
@@ -181,7 +186,7 @@ class Rollout:
     while k < k1:
       c = min(GATHER_EVERY, k1 - k)
       buf, r, t = self.bdist.packed_output_block(c, self.n, self.device)
-      out.append((self.sim.prepare_step_n(self.actions[k:k + c], r, t, None, substeps=self.substeps), buf, r, t))
+      out.append((self.sim.prepare_step_n(self.actions[k:k + c], r, t, None, substeps=self.substeps, noise_seed=self.noise_seed), buf, r, t))
       k += c
     return out
 
@@ -262,7 +267,7 @@ def observe_leg(roll, pairs, world, measure=False):
   sim.set_state(roll.host_state)                         # fresh episodes
   obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
   sim.reset_observation_history()
-  obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world) if world > 1 else None
+  obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world, mode='gather') if world > 1 else None
   fill = 121                                            # 6 h window = 120 observations; 121st call slides it
   # forecast != truth: the additive wind noise (ble_wind_noise_f32) is evaluated at the balloons once
   # per step -- it is both the next step's ground-truth term and this observation's error term
@@ -282,6 +287,28 @@ def observe_leg(roll, pairs, world, measure=False):
     e2.record()
     torch.cuda.synchronize()
     t_obs.append(e1.elapsed_time(e2)); t_pair.append(e0.elapsed_time(e2))
+  # N > 1: the same pair with each consumer of the observation blocks (distributed.ObservationGatherer): one learner on
+  # rank 0 (gather: timed above), a data-parallel learner (all_to_all), a policy replica per rank (local: no exchange).
+  # MAX over ranks of the mean pair time; bytes and link-bound time of each from observation_exchange_model (arithmetic).
+  exchange_modes = None
+  if world > 1:
+    exchange_modes = {'gather': dict(obs_gatherer.model, ms_per_step_plus_observation=bdist.max_over_ranks(statistics.fmean(t_pair), device),
+                                     ms_observation_plus_exchange=bdist.max_over_ranks(statistics.fmean(t_obs), device))}
+    for mode in ('all_to_all', 'local'):
+      if mode == 'all_to_all' and n % world != 0:
+        continue
+      og = bdist.ObservationGatherer(n, 1099, device, world, mode=mode)
+      tp, to = [], []
+      for i in range(pairs):
+        e0.record(); sim.step(roll.actions[(fill + pairs + i) % k_total], noise); sim.wind_noise(seed=1234, out=noise)
+        e1.record(); sim.observe(noise, out=obs)
+        og.gather(obs); og.wait()
+        e2.record()
+        torch.cuda.synchronize()
+        to.append(e1.elapsed_time(e2)); tp.append(e0.elapsed_time(e2))
+      exchange_modes[mode] = dict(og.model, ms_per_step_plus_observation=bdist.max_over_ranks(statistics.fmean(tp), device),
+                                  ms_observation_plus_exchange=bdist.max_over_ranks(statistics.fmean(to), device))
+      del og
   sim.check_errors()
   live = float((sim.state['status'] == 0).sum().item())
   ms_obs, ms_pair = statistics.fmean(t_obs), statistics.fmean(t_pair)      # the average launch duration (HIP events), as for the headline
@@ -307,7 +334,7 @@ def observe_leg(roll, pairs, world, measure=False):
           'ms_per_step_plus_observation': ms_pair,
           'env_observations_per_s': n / (ms_obs * 1e-3), 'env_steps_per_s_with_observation': n / (ms_pair * 1e-3),
           'window_observations': 120, 'obs_bytes_per_env': 4396, 'live_env_fraction': live / n,
-          'includes_gather_to_rank0': world > 1,
+          'includes_gather_to_rank0': world > 1, 'exchange_modes': exchange_modes,
           'kernel': 'ble_observe_kernel (fp64 WindGP: factor carried in HBM and slid with a stored drop vector, MFMA forward substitution)',
           'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP64_PEAK_TFLOPS, 'achieved': tf, 'frac': tf / FP64_PEAK_TFLOPS,
                        'traffic': traffic, 'traffic_detail': traffic_detail, 'traffic_note': traffic_note,
@@ -352,19 +379,30 @@ def policy_in_the_loop_leg(roll, launches=256):
                   'finish dispersion) is paid every step; the fused headline (ble_step_n_f32) pays it once per 32 steps'}
 
 
-def _pmc_pass(counter, cmd, workdir, timeout_s):
-  """One rocprofv3 --pmc pass (kernel trace only, as MI355X_MICROARCH.md prescribes) of `cmd`; returns the rows of the
-  counter-collection CSV."""
-  out_dir = os.path.join(workdir, counter)
-  full = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '-o', 'p', '--'] + cmd
+PMC_BUDGET_S = [240.0]      # wall-clock budget of ALL nested profiler passes of one bench.py run (--pmc-budget-s)
+
+
+def _pmc_pass(counters, cmd, workdir, timeout_s):
+  """One rocprofv3 --pmc pass (kernel trace only, as MI355X_MICROARCH.md prescribes) of `cmd` collecting `counters` (a
+  name or a list that fits one pass); returns the rows of the counter-collection CSV."""
+  counters = [counters] if isinstance(counters, str) else list(counters)
+  timeout_s = min(timeout_s, PMC_BUDGET_S[0])
+  if timeout_s < 20:
+    raise TimeoutError('profiler budget of this run spent (--pmc-budget-s)')
+  out_dir = os.path.join(workdir, counters[0])
+  full = ['rocprofv3', '--kernel-trace', '--pmc'] + counters + ['--output-format', 'csv', '-d', out_dir, '-o', 'p', '--'] + cmd
   env = dict(os.environ, TMPDIR='/tmp')
-  subprocess.run(full, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+  t0 = time.perf_counter()
+  try:
+    subprocess.run(full, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+  finally:
+    PMC_BUDGET_S[0] -= time.perf_counter() - t0
   rows = []
   for base, _, files in os.walk(out_dir):
     for f in files:
       if f.endswith('counter_collection.csv'):
         with open(os.path.join(base, f)) as fh:
-          rows += [r for r in csv.DictReader(fh) if r['Counter_Name'] == counter]
+          rows += [r for r in csv.DictReader(fh) if r['Counter_Name'] in counters]
   return rows
 
 
@@ -402,6 +440,46 @@ def measure_traffic(kernel, cmd, launches_per_group, groups, timeout_s=100):
     shutil.rmtree(work, ignore_errors=True)
 
 
+ISSUE_COUNTERS = ('SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAIT_ANY')
+
+
+def measure_issue(kernel, cmd, launches_per_group, groups, agent_steps_per_launch, timeout_s=100):
+  """Where the kernel's time goes when HBM is not the bound, measured now: ONE more rocprofv3 --pmc pass (SQ counters only,
+  kernel trace only) of `cmd`, averaged over the last groups x launches_per_group dispatches of `kernel`.
+  wave_issue_utilisation = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (cycles a wave had an instruction in flight / cycles it was
+  resident); valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; instruction counts per wave and agent step."""
+  if shutil.which('rocprofv3') is None:
+    return None, 'rocprofv3 not on PATH'
+  if being_profiled():
+    return None, 'this run is itself under a profiler: nested PMC pass skipped'
+  work = tempfile.mkdtemp(prefix='ble_pmc_', dir='/tmp')
+  try:
+    rows = [r for r in _pmc_pass(list(ISSUE_COUNTERS), cmd, work, timeout_s) if kernel in r['Kernel_Name']]
+    ids = sorted({int(r['Dispatch_Id']) for r in rows})
+    take = set(ids[-groups * launches_per_group:])
+    if len(take) < launches_per_group:
+      return None, f'only {len(ids)} dispatches of {kernel} found'
+    tot = {c: 0.0 for c in ISSUE_COUNTERS}
+    for r in rows:
+      if int(r['Dispatch_Id']) in take:
+        tot[r['Counter_Name']] += float(r['Counter_Value'])
+    if tot['SQ_WAVES'] <= 0 or tot['SQ_WAVE_CYCLES'] <= 0:
+      return None, 'SQ counters came back empty'
+    waves = tot['SQ_WAVES']
+    per = float(agent_steps_per_launch)
+    return {'wave_issue_utilisation': tot['SQ_ACTIVE_INST_ANY'] / tot['SQ_WAVE_CYCLES'],
+            'valu_issue_frac': tot['SQ_ACTIVE_INST_VALU'] / tot['SQ_WAVE_CYCLES'],
+            'wait_frac': tot['SQ_WAIT_ANY'] / tot['SQ_WAVE_CYCLES'],
+            'valu_insts_per_env_step': tot['SQ_INSTS_VALU'] / waves / per, 'salu_insts_per_env_step': tot['SQ_INSTS_SALU'] / waves / per,
+            'wave_quad_cycles_per_env_step': tot['SQ_WAVE_CYCLES'] / waves / per,
+            'waves_per_launch': waves / len(take), 'dispatches_averaged': len(take), 'agent_steps_per_launch': per,
+            'source': 'measured in this run: rocprofv3 --kernel-trace --pmc ' + ' '.join(ISSUE_COUNTERS) + ' (one pass; per wave = 64 environments)'}, None
+  except Exception as e:
+    return None, f'PMC pass failed: {e!r}'[:300]
+  finally:
+    shutil.rmtree(work, ignore_errors=True)
+
+
 def facade_leg(steps=150):
   """BASELINE configs[0]'s counterpart on this framework: the single-env gym facade (BalloonEnv.step ->
   ble_step_f32 + ble_observe_f32 on one environment, host-synchronous like the reference's API)."""
@@ -434,8 +512,15 @@ def main():
   ap.add_argument('--observe', type=int, default=8, metavar='N',
                   help='timed step+observation pairs of the observation leg (0 = skip)')
   ap.add_argument('--traffic', choices=('auto', 'off'), default='auto',
-                  help='auto: measure roofline.traffic in this run with two rocprofv3 --pmc passes (N = 1, full run only)')
+                  help='auto: measure roofline.traffic and roofline.instruction_issue in this run with nested rocprofv3 --pmc passes '
+                       '(N = 1, full run only; three of the headline, two of the observation leg)')
+  ap.add_argument('--pmc-budget-s', type=float, default=240.0,
+                  help='wall-clock budget of all nested profiler passes together; passes that no longer fit are skipped and say so')
+  ap.add_argument('--noise-seed', type=int, default=None,
+                  help='fly the HEADLINE in the ground-truth wind (noise generated in-kernel) instead of the forecast; the default '
+                       'run reports both (config.ground_truth_wind)')
   args = ap.parse_args()
+  PMC_BUDGET_S[0] = args.pmc_budget_s
 
   # ---- `python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and hand the
   # result line of rank 0 through.  (Under torch.distributed.run WORLD_SIZE is set and this branch is not taken.)
@@ -486,13 +571,14 @@ def main():
   def preset_size(cfg):
     return bdist.preset_layout(cfg, rank, world)['n_local']
 
-  def make(cfg, n=None, steps=None, warmup=None):
+  def make(cfg, n=None, steps=None, warmup=None, noise_seed=None):
     n = n if n is not None else preset_size(cfg)
     return Rollout(n, device, rank, world, per_env_grids=(cfg == 4 or args.per_env_grids), shared_field=grid,
-                   steps=steps or args.steps, warmup=args.warmup if warmup is None else warmup, substeps=args.substeps)
+                   steps=steps or args.steps, warmup=args.warmup if warmup is None else warmup, substeps=args.substeps,
+                   noise_seed=noise_seed)
 
   # ---- headline leg
-  head = make(args.config, n=args.envs_per_gpu)
+  head = make(args.config, n=args.envs_per_gpu, noise_seed=args.noise_seed)
   hs = head.summary(args.reps)
   n = head.n
   bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (hs['live_env_steps_per_repetition'] / world / head.launches_per_region)
@@ -506,23 +592,32 @@ def main():
       child += ['--envs-per-gpu', str(args.envs_per_gpu)]
     if args.per_env_grids:
       child += ['--per-env-grids']
+    if args.noise_seed is not None:
+      child += ['--noise-seed', str(args.noise_seed)]
     traffic_detail, traffic_note = measure_traffic('ble_step_kernel', child, head.launches_per_region, groups=6)
     traffic = traffic_detail['bytes'] if traffic_detail else None
   else:
     traffic_note = 'not measured in this run (N > 1, --no-extras or --traffic off)'
-  issue = None
-  for tag in ('r03', 'r02', 'r01'):
-    try:
-      d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
-      per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)
-      issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
-               'valu_insts_per_env_step': d['valu_insts_per_wave'] / per, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / per,
-               'source': f'profiles/{tag}_summary.json (rocprofv3 --pmc, per {int(per)}-step launch)'}
-      break
-    except Exception:
-      continue
+  # the bound that actually applies (instruction issue at one wave per SIMD): a third PMC pass of the same child run
+  issue, issue_note = None, None
+  if world == 1 and args.traffic == 'auto' and not args.no_extras:
+    issue, issue_note = measure_issue('ble_step_kernel', child, head.launches_per_region, groups=3,
+                                      agent_steps_per_launch=args.steps / head.launches_per_region)
+  if issue is None:            # labelled fallback: the committed profile of an earlier build, NOT this run
+    for tag in ('r04', 'r03', 'r02', 'r01'):
+      try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
+        per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)
+        issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
+                 'valu_insts_per_env_step': d['valu_insts_per_wave'] / per, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / per,
+                 'source': f'NOT measured in this run ({issue_note or "N > 1, --no-extras or --traffic off"}): profiles/{tag}_summary.json '
+                           f'(rocprofv3 --pmc, per {int(per)}-step launch)'}
+        break
+      except Exception:
+        continue
 
   # ---- the other 1-GPU legs (same code path, fewer repetitions)
+  ground_truth = None
   configs = {f'configs[{args.config}]': {k: hs[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step')}}
   observe = None
   policy = None
@@ -533,6 +628,16 @@ def main():
       configs[f'configs[{args.config}] one launch per step'] = {'env_steps_per_s': policy['env_steps_per_s'], 'envs_per_gpu': head.n,
                                                                'us_per_launch_event_median': policy['us_per_launch_event_median'],
                                                                'us_per_step_back_to_back': policy['us_per_step_back_to_back']}
+    if args.noise_seed is None and not (args.config == 4 or args.per_env_grids):
+      # the same rollout in the reference's OWN wind: WindField.get_ground_truth = forecast + noise (wind_field.py:125-145),
+      # the noise generated inside ble_step_kernel at every step (ABI 3); SURVEY 8(d) defines the headline with the term off
+      rn = make(args.config, n=args.envs_per_gpu, noise_seed=20240917)
+      sn = rn.summary(extra_reps)
+      ground_truth = {k: sn[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'ms_per_step', 'kernel_ms_mean', 'envs_per_gpu', 'global_envs')}
+      ground_truth['what'] = ('the headline rollout flown in WindField.get_ground_truth: 10 harmonics of 4-D simplex noise per env-step '
+                              'evaluated inside ble_step_kernel<noise> (same launch shape, exchanges and counting as the headline)')
+      configs[f'configs[{args.config}] in the ground-truth wind (noise in-kernel)'] = ground_truth
+      del rn
     if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
       observe = observe_leg(head, args.observe, world, measure=(args.traffic == 'auto'))
     del head
@@ -568,6 +673,8 @@ def main():
         'config': {'workload': PRESETS[args.config] + (' [per-env grids]' if args.per_env_grids and args.config != 4 else ''),
                    'preset': f'configs[{args.config}]', 'envs_per_gpu': n, 'global_envs': hs['global_envs'],
                    'substeps_per_step': args.substeps, 'live_env_fraction_end': hs['live_env_fraction_end'],
+                   'wind': 'forecast (noise term 0: SURVEY 8(d))' if args.noise_seed is None else 'ground truth = forecast + in-kernel noise',
+                   'ground_truth_wind': ground_truth,
                    'per_env_grids': bool(args.config == 4 or args.per_env_grids), 'decode_ms': hs['decode_ms'],
                    'parallelism': f'env-sharded x{world}, ' + ('no broadcast (per-rank decode)' if args.config == 4 else 'grid broadcast once') +
                                   (f', reward + terminal rows of every launch (<= {GATHER_EVERY} steps) gathered to rank 0 as ONE packed message on a side stream' if world > 1
@@ -588,6 +695,8 @@ def main():
                      'note': 'frac is the SURVEY 8(d) formal fraction (algorithmic bytes / time / peak); the measured HBM traffic '
                              '(`traffic`, bytes per launch) is a few % of the algorithmic bytes because the state stays in registers for 32 '
                              'steps and the grid gather is served by L2: the kernel is fp64/fp32 VALU-issue bound (DESIGN.md 3)',
+                     'valu_issue_frac': (issue or {}).get('valu_issue_frac'),
+                     'wave_issue_utilisation': (issue or {}).get('wave_issue_utilisation'),
                      'instruction_issue': issue},
         'configs': configs,
     }

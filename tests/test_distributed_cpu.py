@@ -241,3 +241,95 @@ def test_spawn_local_ranks_starts_one_process_per_rank(tmp_path):
   # a failing rank is reported and the others are stopped
   bad = 'import os, sys, time\nsys.exit(3) if os.environ["RANK"] == "1" else time.sleep(60)\n'
   assert bdist.spawn_local_ranks([sys.executable, '-c', bad], 2, timeout=120) == 3
+
+
+def _slots_worker(rank, world, port, out_dir):
+  """A WHOLE region of several launches run as bench.py runs it -- all gathers issued back to back, one wait at the end --
+  with one receive slot per launch; n_local and the launch length chosen so that 5 k n_local is not a multiple of 4."""
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    n_local, every, steps = 1003, 7, 20             # launches of 7 + 7 + 6 steps; 5 * 7 * 1003 = 35 105 bytes per rank
+    lo = rank * n_local
+    launches = -(-steps // every)
+    g = bdist.OutputGatherer(every, n_local, 'cpu', world, slots=launches)
+    assert g.row_bytes % 16 == 0 and g.row_bytes >= 5 * every * n_local
+    plan, k = [], 0
+    while k < steps:
+      c = min(every, steps - k)
+      buf, r, t = bdist.packed_output_block(c, n_local, 'cpu')
+
+      def launch(k0=k, c=c, r=r, t=t):
+        r.copy_(torch.arange(lo, lo + n_local, dtype=torch.float32)[None, :] + 1e5 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None])
+        t.copy_(((torch.arange(lo, lo + n_local)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 3 == 0).to(torch.uint8))
+      plan.append((launch, buf, r, t))
+      k += c
+    out = {}
+    for region in range(2):                         # the second region reuses the slots
+      bdist.run_region(plan, g)
+      if rank == 0:
+        out[region] = [[tuple(v.clone() for v in g.unpack(q, item[2].shape[0], slot)) for q in range(world)]
+                       for slot, item in enumerate(plan)]
+    out['gathers'] = g.gathers
+    torch.save(out, os.path.join(out_dir, f's{rank}.pt'))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_every_launch_of_a_region_is_kept_on_the_learner_rank_world2(tmp_path):
+  world = 2
+  mp.spawn(_slots_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  o = torch.load(os.path.join(tmp_path, 's0.pt'))
+  assert o['gathers'] == 6
+  for region in range(2):
+    k0 = 0
+    for per_rank in o[region]:
+      c = per_rank[0][0].shape[0]
+      rew = torch.cat([per_rank[q][0] for q in range(world)], dim=1); term = torch.cat([per_rank[q][1] for q in range(world)], dim=1)
+      assert torch.equal(rew, torch.arange(2006, dtype=torch.float32)[None, :] + 1e5 * torch.arange(k0, k0 + c, dtype=torch.float32)[:, None])
+      assert torch.equal(term, ((torch.arange(2006)[None, :] + torch.arange(k0, k0 + c)[:, None]) % 3 == 0).to(torch.uint8))
+      k0 += c
+    assert k0 == 20
+
+
+def _obs_modes_worker(rank, world, port, out_dir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    n_local, dim = 8, 1099
+    ids = torch.arange(rank * n_local, (rank + 1) * n_local, dtype=torch.float32)
+    block = (ids[:, None] + torch.arange(dim, dtype=torch.float32)[None, :] / 2048).contiguous()
+    out = {}
+    for mode in bdist.OBSERVATION_MODES:
+      og = bdist.ObservationGatherer(n_local, dim, 'cpu', world, mode=mode)
+      og.gather(block); og.wait()
+      out[mode] = (og.obs.clone(), og.model)
+    torch.save(out, os.path.join(out_dir, f'o{rank}.pt'))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_observation_exchange_modes_world2(tmp_path):
+  """The three consumers of the observation blocks: one learner (gather), a data-parallel learner (all_to_all: rank r gets
+  rows r of every block), a policy replica per rank (local: nothing moves) -- and the byte model each one reports."""
+  world, n_local, dim = 2, 8, 1099
+  mp.spawn(_obs_modes_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  outs = [torch.load(os.path.join(tmp_path, f'o{r}.pt')) for r in range(world)]
+  want = torch.arange(world * n_local, dtype=torch.float32)[:, None] + torch.arange(dim, dtype=torch.float32)[None, :] / 2048
+  g0, m = outs[0]['gather']
+  assert torch.equal(g0.reshape(-1, dim), want) and outs[1]['gather'][0].numel() == 0
+  assert m['bytes_per_link'] == n_local * dim * 4 and m['bytes_received_max_per_rank'] == (world - 1) * n_local * dim * 4
+  half = n_local // world
+  for r in range(world):
+    a, m = outs[r]['all_to_all']
+    assert tuple(a.shape) == (world, half, dim)
+    for q in range(world):                                 # the slice that came from rank q: rows [r half, (r + 1) half) of ITS block
+      assert torch.equal(a[q], want[q * n_local + r * half:q * n_local + (r + 1) * half])
+    assert m['bytes_per_link'] == n_local * dim * 4 // world
+    l, m = outs[r]['local']
+    assert torch.equal(l[0], want[r * n_local:(r + 1) * n_local]) and m['bytes_per_link'] == 0 and m['expected_ms_link_bound'] == 0.0
+  # DESIGN section 7's arithmetic for 8 x 65 536 environments
+  big = bdist.observation_exchange_model('gather', 65536, 1099, 8)
+  assert big['block_bytes_per_rank'] == 288096256 and big['bytes_received_max_per_rank'] == 7 * 288096256
+  assert 1.8 < big['expected_ms_link_bound'] < 2.0
+  assert 0.22 < bdist.observation_exchange_model('all_to_all', 65536, 1099, 8)['expected_ms_link_bound'] < 0.25

