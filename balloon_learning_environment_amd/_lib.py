@@ -19,7 +19,7 @@ from balloon_learning_environment_amd import _abi
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BLE_HIP_LIB') or os.path.join(_PKG_DIR, 'libble_hip.so')   # override: experiments only
 _SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_step_core.h', 'ble_physics.h', 'ble_intrinsics.h', 'ble_reset.h',
-                                                          'ble_observe.h', 'ble_noise.h', 'ble_decode.h')]
+                                                          'ble_observe.h', 'ble_noise.h', 'ble_decode.h', 'ble_step_split.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
 ABI_VERSION = 3

@@ -9,6 +9,7 @@
 // Target: gfx950 only (hipcc --offload-arch=gfx950); no other backend, no shims.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 // Instrumentation hooks of ble_step_kernel: empty in the product build.  A profiling build
 // (profiles/build_variant.sh ... -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
@@ -26,6 +27,7 @@
 #include "../../include/ble_abi.h"
 #include "ble_reset.h"
 #include "ble_step_core.h"
+#include "ble_step_split.h"
 #include "ble_observe.h"
 #include "ble_noise.h"
 #include "ble_decode.h"
@@ -164,6 +166,13 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   }
   BLE_STEP_INSTR_END();
   report_flags(flags, err_flags);
+}
+
+// The same transition for small batches: one environment on the four wavefronts of a 256-thread workgroup (ble_step_split.h).
+__global__ __launch_bounds__(kSplitWaves * kSplitLanes) void ble_step_split_kernel(SplitArgs a) {
+  __shared__ SplitShared sh;
+  const uint32_t flags = split_agent_steps(a, sh);
+  report_flags(flags, a.err_flags);
 }
 
 __global__ __launch_bounds__(256) void ble_forecast_kernel(const float* __restrict__ wind_grid,
@@ -525,6 +534,17 @@ __global__ __launch_bounds__(256) void probe_f64_kernel(const double* x, double*
 }
 namespace {
 inline int env_lanes() { return kBlock; }   // one environment per lane, all 64 lanes (32 was measured: slower)
+// Below BLE_SPLIT_MAX_ENVS environments the one-lane kernel leaves most SIMDs idle (n / 64 waves on 1 024 SIMDs) and the
+// four-wave kernel still fits one wave per SIMD: it is the faster one (bit-identical results).  BLE_STEP_SPLIT=0 / 1 in the
+// environment forces one or the other (A/B runs and the parity test).
+inline bool use_split(int64_t n) {
+  const char* e = getenv("BLE_STEP_SPLIT");
+  if (e != nullptr && (e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
+  return n <= BLE_SPLIT_MAX_ENVS;
+}
+inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
+                        const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream);
 // hipGetLastError is per-thread and sticky: an error left behind by an unrelated runtime call
 // of the host application (torch probes pointers / peers at start-up) must not be reported as
 // ours, so every launch first drains it, and the launch's own status is kept for
@@ -541,6 +561,16 @@ inline int launch_status() {
     hipLaunchKernelGGL(__VA_ARGS__); \
   } while (0)
 inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
+                        const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream) {
+  SplitArgs a;
+  a.st = *st; a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
+  a.reward = reward; a.terminal = terminal; a.effective_action = effective_action; a.err_flags = err_flags;
+  a.active_count = active_count; a.n = n; a.substeps = substeps; a.n_steps = n_steps;
+  BLE_LAUNCH(ble_step_split_kernel, dim3(blocks(n, kSplitLanes)), dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
 inline bool state_ok(const ble_state_f32* st) {
   if (!st) return false;
   const void* const* p = reinterpret_cast<const void* const*>(st);
@@ -570,6 +600,9 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
+  if (use_split(n))
+    return launch_split(st, action, wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags, active_count, n,
+                        substeps, 1, stream);
   const int lanes = env_lanes();
   BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
@@ -590,6 +623,9 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
     BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
                active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache});
+  } else if (use_split(n)) {
+    return launch_split(st, action, wind_grid, grid_env_stride, nullptr, reward, terminal, nullptr, err_flags, active_count, n, substeps,
+                        n_steps, stream);
   } else {
     BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,

@@ -91,6 +91,86 @@ BLE_FN EnvHoisted hoisted_from_cache(const EpisodeCacheRow& r, const EnvConst& c
   return h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The right-hand sides of one 10 s stride (balloon.py:356-549), one function per group of state variables.  Every one of
+// them reads the OLD state only (balloon.py:322-325 commits after all of them), so they are independent inside a stride:
+// agent_step below evaluates them one after the other on one lane; ble_step_split.h evaluates them on four wavefronts.
+// Both call these very functions -- the two kernels agree bit for bit (tests/test_gpu_parity.py).
+
+// V^(-1/3): 1/drag = 4 V^(-2/3) of the vertical dynamics and the radius of the thermal model; fp32 seed + one Newton step
+// y <- y (4 - V y^3) / 3
+BLE_FN double inv_cbrt_volume(double vol) {
+  double yc = (double)f_exp2((-1.0f / 3.0f) * f_log2((float)vol));              // fp32 seed
+  return yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
+}
+// the layer of the atmosphere window that holds p, carried from stride to stride
+struct LayerCursor {
+  int lay;                 // -1, 0, +1 relative to the window's centre layer
+  double lapse_cur;        // its lapse rate
+  double cur_hi, cur_lo;   // the transition pressures that bound it (+-inf beyond the window)
+};
+// step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float equilibrium
+// d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error in the increment itself is amplified past the
+// parity bar within a few substeps.  rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
+BLE_FN double stride_pressure(const AtmWindow& win, const LayerCursor& lc, double p, double rp, double vol, double n_air,
+                              double t_amb, double t_at_p, double yc) {
+  const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
+  const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
+  const double dir = num >= 0.0 ? 1.0 : -1.0;
+  // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
+  const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
+  const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
+  const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p);
+  return d_fma(inv_dh * dh_dt, 10.0, p);                                  // dir * dir == 1
+}
+// step 3: internal temperature (balloon.py:451-467)
+BLE_FN double stride_internal_temperature(double vol, double yc, double t_int, double t_amb, double p, float flux, float att,
+                                          double q_earth) {
+  return t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth);
+}
+// step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the mass flow changes rho V - m by
+// ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified like the thermal increment's.
+BLE_FN void stride_acs(const double* acs_poly, int eff, double sp, double p, double rp, double t_int, float* acs_w, double* mdot_d) {
+  constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
+  // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
+  const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
+  const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
+  const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
+  double w_down, mdot_down;
+  acs_down_poly(acs_poly, prm1, &w_down, &mdot_down);
+  *acs_w = eff == kDown ? (float)w_down : 0.0f;
+  *mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
+}
+BLE_FN double stride_mols_air(double n_air, double mdot_d) {
+  return d_max(d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air), 0.0);
+}
+// step 6: power (balloon.py:524-542)
+BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* charge, float* load, float* batt) {
+  const bool is_day = sun.day;
+  *charge = is_day ? solar_power(sun, att) : 0.0f;
+  *load = (is_day ? kDayLoad : kNightLoad) + acs_w;
+  *batt = f_clamp(f_fma(*charge - *load, kStride / 3600.0f, *batt), 0.0f, kBatteryCapacity);
+}
+// T(p_new) for the next stride: advance inside the layer; if a transition was crossed (cold branch) re-anchor at it first --
+// no transcendental either way (see AtmWindow).  Updates the cursor.
+BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, double p, double rp, double t_at_p, double p_new) {
+  const double kInf = (double)__builtin_huge_valf();
+  double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
+  if (__builtin_expect(p_new > lc.cur_hi || !(p_new > lc.cur_lo), 0)) {
+    BLE_STEP_EVENT(1);
+    const int lay_new = atm_window_layer(win, p_new);
+    const bool low_pair = (lc.lay + lay_new) < 0;            // crossing pb (else pt)
+    anchor_p = low_pair ? win.pb : win.pt;
+    anchor_rp = low_pair ? win.r_pb : win.r_pt;
+    anchor_t = low_pair ? win.tb : win.tt;
+    lc.lay = lay_new;
+    lc.lapse_cur = pick3(lay_new, win.lapse_m1, win.lapse_0, win.lapse_p1);
+    lc.cur_hi = lay_new < 0 ? kInf : (lay_new == 0 ? win.pb : win.pt);
+    lc.cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
+  }
+  return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.lapse_cur);
+}
+
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
 // The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
@@ -105,11 +185,8 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   const AtmWindow win = atm_window_from(hc.atm, (double)c.alpha, p, flags);
   double altitude, t_at_p;
   atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
-  int lay = 0;                                   // p is in the window's centre layer by construction
-  const double lapse_m1 = win.lapse_m1, lapse_c0 = win.lapse_0, lapse_p1 = win.lapse_p1;
-  const double kInf = (double)__builtin_huge_valf();
-  double lapse_cur = lapse_c0;                   // lapse rate of the layer holding p
-  double cur_hi = win.pb, cur_lo = win.pt;       // transition pressures bounding that layer
+  LayerCursor lc;                                // p is in the window's centre layer by construction
+  lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
   int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
@@ -196,32 +273,20 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   int k = 0;
 #pragma unroll 1
   for (; k < substeps; ++k) {
-    const float pf = (float)p, volf = (float)vol;
+    const float pf = (float)p;
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
     const float fk = (float)k;
     const SunState sun = sun_at(k);
     const float flux = f_fma(fk, dfl, fl0);
 
-    // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float
-    // equilibrium d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error
-    // in the increment itself is amplified past the parity bar within a few substeps.
-    // rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
-    const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
-    const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
-    const double dir = num >= 0.0 ? 1.0 : -1.0;
-    // 1/drag = 4 V^(-2/3): V^(-1/3) by one Newton step  y <- y (4 - V y^3) / 3  from an fp32 seed
-    double yc = (double)f_exp2((-1.0f / 3.0f) * f_log2(volf));              // fp32 seed
-    yc = yc * d_fma(-vol * yc, yc * yc, 4.0) * (1.0 / 3.0);
-    // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
-    const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
-    const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
-    const double inv_dh = atm_inv_delta_height_f64(win, lay, lapse_cur, cur_hi, cur_lo, p, rp, dir, t_at_p);
-    const double p_new = d_fma(inv_dh * dh_dt, 10.0, p);                    // dir * dir == 1
+    // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445)
+    const double yc = inv_cbrt_volume(vol);
+    const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-    const double t_int_new = t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth);
+    const double t_int_new = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth);
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
@@ -229,54 +294,21 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     // balloon.py:479-482: burst above 2 380 Pa, zero pressure at <= 0 (the status code is formed after the loop)
     bool terminal = !(sp_new <= 2380.0) || sp_new <= 0.0;
 
-    // ---- step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the
-    // mass flow changes rho V - m by ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified
-    // like the thermal increment's.
+    // ---- step 5: ACS (balloon.py:487-519)
     double mdot_d;
-    {
-      constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
-      // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
-      const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
-      const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
-      const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
-      double w_down, mdot_down;
-      acs_down_poly(acs_poly, prm1, &w_down, &mdot_down);
-      acs_w = eff == kDown ? (float)w_down : 0.0f;
-      mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
-      mdot = (float)mdot_d;
-    }
-    double n_air_new = d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air);
-    n_air_new = d_max(n_air_new, 0.0);
+    stride_acs(acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
+    mdot = (float)mdot_d;
+    const double n_air_new = stride_mols_air(n_air, mdot_d);
 
     // ---- step 6: power (balloon.py:524-542)
-    const bool is_day = sun.day;
-    charge = is_day ? solar_power(sun, att) : 0.0f;
-    load = (is_day ? kDayLoad : kNightLoad) + acs_w;
-    batt = f_clamp(f_fma(charge - load, kStride / 3600.0f, batt), 0.0f, kBatteryCapacity);
+    stride_power(sun, att, acs_w, &charge, &load, &batt);
     terminal = terminal || batt <= 0.0f;          // balloon.py:541-542
 
     // ---- commit (balloon.py:322-325): every RHS above used the old state
     x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
     y = f_fma(v, kStride, y);
     t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
-    // T(p_new) for the next substep: advance inside the layer; if a transition was crossed
-    // (cold branch) re-anchor at it first -- no transcendental either way (see AtmWindow)
-    {
-      double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
-      if (__builtin_expect(p_new > cur_hi || !(p_new > cur_lo), 0)) {
-        BLE_STEP_EVENT(1);
-        const int lay_new = atm_window_layer(win, p_new);
-        const bool low_pair = (lay + lay_new) < 0;            // crossing pb (else pt)
-        anchor_p = low_pair ? win.pb : win.pt;
-        anchor_rp = low_pair ? win.r_pb : win.r_pt;
-        anchor_t = low_pair ? win.tb : win.tt;
-        lay = lay_new;
-        lapse_cur = pick3(lay_new, lapse_m1, lapse_c0, lapse_p1);
-        cur_hi = lay_new < 0 ? kInf : (lay_new == 0 ? win.pb : win.pt);
-        cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
-      }
-      t_at_p = atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lapse_cur);
-    }
+    t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new);
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (terminal) { ++k; break; }          // balloon.py:327-328
   }

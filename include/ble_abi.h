@@ -119,6 +119,10 @@ typedef struct ble_state_f32 {
 } ble_state_f32;
 #define BLE_EPISODE_CACHE_ROWS 7
 #define BLE_MAX_SUBSTEPS 60
+/* Up to this many environments ble_step_f32 / ble_step_n_f32 (without a noise generator) run the four-wavefronts-per-
+ * environment form of the transition (csrc/ble_step_split.h: 4 x n / 64 waves, still at most one per SIMD), above it the
+ * one-lane-per-environment kernel.  The two are bit-identical; BLE_STEP_SPLIT=0 / 1 in the process environment forces one. */
+#define BLE_SPLIT_MAX_ENVS 16384
 
 int ble_abi_version(void);
 

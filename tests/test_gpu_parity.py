@@ -830,6 +830,57 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
   assert np.median(moved) > 100.0                   # ~1 m/s of noise over 18 minutes
 
 
+@pytest.mark.parametrize('wide', [False, True])
+def test_split_kernel_equals_one_lane_kernel(ble, wide):
+  """The small-batch form of the transition -- one environment on FOUR wavefronts (csrc/ble_step_split.h: vertical dynamics |
+  thermal model | sun + power | envelope + ACS, exchanging through LDS once per stride), which ble_step_f32 / ble_step_n_f32
+  select up to BLE_SPLIT_MAX_ENVS environments -- against the one-lane-per-environment kernel, forced with BLE_STEP_SPLIT:
+  every state array, reward, terminal, effective action, the live counters and the error word, BIT FOR BIT; fused launches
+  and single steps with a noise term, action bytes outside 0 .. 2, environments that end inside the rollout (early in a
+  step, so that their lane stops while its neighbours go on), a batch that does not fill its last workgroup."""
+  import os
+  from balloon_learning_environment_amd import reset_host
+  from helpers import wide_domain_states
+  n, k = 4096 - 37, 9
+  init = wide_domain_states(n, 8) if wide else reset_host.sample_initial_state(n, seed=8)
+  init['battery_charge'][:96] = np.linspace(0.01, 0.6, 96).astype(np.float32)      # out of power after a few strides / steps
+  init['superpressure'][96:128] = 2379.0                                             # about to burst
+  init['status'][128:136] = 2                                                        # already terminal on entry
+  field = (np.random.default_rng(1).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts_h = np.random.default_rng(2).integers(0, 3, (k, n)).astype(np.uint8)
+  acts_h[:, 200:232] = np.random.default_rng(3).integers(3, 256, (k, 32)).astype(np.uint8)   # fly like STAY, handed on as given
+  acts = torch.from_numpy(acts_h).cuda()
+  noise = torch.from_numpy((np.random.default_rng(4).standard_normal((n, 2)) * 1.5).astype(np.float32)).cuda()
+
+  def fly(split):
+    os.environ['BLE_STEP_SPLIT'] = '1' if split else '0'
+    try:
+      sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(field)
+      rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
+      cnt = torch.zeros((k, ble.COUNT_SLOTS), dtype=torch.int64).cuda()
+      sim.step_n(acts, rew, term, cnt)                               # a fused launch ...
+      singles = []
+      for j in range(3):                                             # ... then single steps in a noisy wind
+        r, t = sim.step(acts[j].contiguous(), noise)
+        singles.append((r.clone(), t.clone(), sim.effective_action.clone()))
+      torch.cuda.synchronize()
+      flags = int(sim.err_flags.item()); sim.err_flags.zero_()
+      return sim.get_state(), rew.cpu().numpy(), term.cpu().numpy(), cnt.cpu().numpy(), singles, flags, int(sim.active_count.item())
+    finally:
+      del os.environ['BLE_STEP_SPLIT']
+  a, b = fly(True), fly(False)
+  for name in a[0]:
+    np.testing.assert_array_equal(a[0][name], b[0][name], err_msg=name)
+  np.testing.assert_array_equal(a[1], b[1]); np.testing.assert_array_equal(a[2], b[2])
+  np.testing.assert_array_equal(a[3].sum(axis=1), b[3].sum(axis=1))
+  for (ra, ta, ea), (rb, tb, eb) in zip(a[4], b[4]):
+    assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ea, eb)
+  assert a[5] == b[5] and a[6] == b[6]
+  ended = (a[0]['status'] != 0).sum()
+  assert ended >= 8 + 32 and (a[0]['status'] == 1).sum() > 0 and (a[0]['status'] == 2).sum() >= 8
+  assert a[2][0].sum() < ended                                        # some ended in later steps, not all in the first
+
+
 # ---------------------------------------------------------------- device reset (SURVEY 8f #2)
 def test_device_reset_derivation_matches_oracle(ble):
   """sample=0: cold start + sunrise search on given inputs (golden F10 + sampled) vs the oracle."""
