@@ -171,7 +171,13 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
 // The same transition for small batches: one environment on the four wavefronts of a 256-thread workgroup (ble_step_split.h).
 __global__ __launch_bounds__(kSplitWaves * kSplitLanes) void ble_step_split_kernel(SplitArgs a) {
   __shared__ SplitShared sh;
-  const uint32_t flags = split_agent_steps(a, sh);
+  uint32_t flags;
+  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {       // (scalar: one role per wave)
+    case 0: flags = split_agent_steps<0>(a, sh); break;
+    case 1: flags = split_agent_steps<1>(a, sh); break;
+    case 2: flags = split_agent_steps<2>(a, sh); break;
+    default: flags = split_agent_steps<3>(a, sh); break;
+  }
   report_flags(flags, a.err_flags);
 }
 

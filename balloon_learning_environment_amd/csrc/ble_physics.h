@@ -978,14 +978,19 @@ BLE_FN float solar_attenuation(float sin_el, float pressure, bool day) {
   return day ? att : 0.0f;
 }
 // solar_power (solar.py:515-536) with balloon_shadow (:212-236) folded in.
-BLE_FN float solar_power(const SunState& sun, float attenuation) {
+// the part that depends on the sun alone: projected, shadowed panel area per unit (ble_step_split.h evaluates it a stride ahead)
+BLE_FN float solar_panel_factor(const SunState& sun) {
   const float kCos35 = 0.81915204429f, kSin35 = 0.57357643635f;
   const float kCos65 = 0.42261826174f, kSin65 = 0.90630778704f;
   float sh33 = sun.sh33 ? 0.4392f : 1.0f;
   float sh27 = sun.sh27 ? 0.4392f : 1.0f;
   float c35 = f_fma(sun.cos_el, kCos35, sun.sin_el * kSin35);
   float c65 = f_fma(sun.cos_el, kCos65, sun.sin_el * kSin65);
-  return 210.0f * attenuation * f_fma(4.0f * c35, sh33, 2.0f * c65 * sh27);
+  return f_fma(4.0f * c35, sh33, 2.0f * c65 * sh27);
+}
+BLE_FN float solar_power_from_factor(float panel_factor, float attenuation) { return 210.0f * attenuation * panel_factor; }
+BLE_FN float solar_power(const SunState& sun, float attenuation) {
+  return solar_power_from_factor(solar_panel_factor(sun), attenuation);
 }
 
 // ---------------------------------------------------------------- thermal

@@ -145,11 +145,13 @@ BLE_FN double stride_mols_air(double n_air, double mdot_d) {
   return d_max(d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air), 0.0);
 }
 // step 6: power (balloon.py:524-542)
-BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* charge, float* load, float* batt) {
-  const bool is_day = sun.day;
-  *charge = is_day ? solar_power(sun, att) : 0.0f;
+BLE_FN void stride_power_from_factor(bool is_day, float panel_factor, float att, float acs_w, float* charge, float* load, float* batt) {
+  *charge = is_day ? solar_power_from_factor(panel_factor, att) : 0.0f;
   *load = (is_day ? kDayLoad : kNightLoad) + acs_w;
   *batt = f_clamp(f_fma(*charge - *load, kStride / 3600.0f, *batt), 0.0f, kBatteryCapacity);
+}
+BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* charge, float* load, float* batt) {
+  stride_power_from_factor(sun.day, solar_panel_factor(sun), att, acs_w, charge, load, batt);
 }
 // T(p_new) for the next stride: advance inside the layer; if a transition was crossed (cold branch) re-anchor at it first --
 // no transcendental either way (see AtmWindow).  Updates the cursor.
@@ -169,6 +171,82 @@ BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, doub
     lc.cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
   }
   return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.lapse_cur);
+}
+
+// Solar geometry of one agent step: 1 - sin(el_uncorrected) at stride indices 0, n/2, n in fp64 (sun_one_minus_sin_f64), then a
+// quadratic in the stride index evaluated in fp32 inside the loop.  The time-only half (hour-angle base and declination at the
+// three nodes) and the site half are separate so that ble_step_split.h can evaluate them on different wavefronts.
+struct SolarNodes {
+  double sb0, cb0, sb1, cb1, sb2, cb2;     // (sin, cos) of the hour-angle base b = 360 frac_day + eot/4 + lng0 at the three nodes
+  double sd0, cd0, hsd, hcd;               // declination (sin, cos) at node 0 and its change per half step
+};
+BLE_FN SolarNodes solar_nodes_time(const Ephemeris& e0, int64_t t0, float lng0_deg, float step_s) {
+  SolarNodes n;
+  // hour-angle base B = 360 frac_day + eot/4 + lng0  [deg]  (solar.py:113-116)
+  double sod;
+  if (__builtin_expect(t0 >= 0 && t0 < 4294967296LL, 1)) sod = (double)((uint32_t)t0 % 86400u);
+  else { int64_t m = t0 % 86400; sod = (double)(m < 0 ? m + 86400 : m); }
+  const double b0 = sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)lng0_deg;
+  const double half_db = 0.5 * ((double)step_s * (1.0 / 240.0) + 0.25 * (double)(e0.eot_min_rate * step_s));  // deg
+  double sb0, cb0;
+  sincos_f64(b0 * (kPiD / 180.0), &sb0, &cb0);
+  // rotate by the half-step angle (0.375 deg): Taylor
+  const double hr = half_db * (kPiD / 180.0), h2 = hr * hr;
+  const double sh = hr * d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+  const double ch = d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+  const double sb1 = sb0 * ch + cb0 * sh, cb1 = cb0 * ch - sb0 * sh;
+  const double sb2 = sb1 * ch + cb1 * sh, cb2 = cb1 * ch - sb1 * sh;
+  n.sb0 = sb0; n.cb0 = cb0; n.sb1 = sb1; n.cb1 = cb1; n.sb2 = sb2; n.cb2 = cb2;
+  // (sin, cos) of the declination as an exactly normalised fp64 pair: with the fp32 pair
+  // (|sd^2 + cd^2 - 1| ~ 6e-8) the error of 1 - sin(el) near the zenith (el > 89.8 deg, 1 - sin(el)
+  // < 1e-6) was ~10 % and cos(el) -- hence the panel power -- was off by 2e-5
+  const double sd0 = (double)e0.sin_decl, cd0 = d_sqrt_fast(d_fma(-sd0, sd0, 1.0));
+  const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = -(sd0 * d_rcp(cd0)) * hsd;
+  n.sd0 = sd0; n.cd0 = cd0; n.hsd = hsd; n.hcd = hcd;
+  return n;
+}
+BLE_FN void solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps,
+                             float* oms_c0, float* oms_c1, float* oms_c2) {
+  const double x0 = (double)x_m, y0 = (double)y_m;
+  const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
+  const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, n.sb0, n.cb0, n.sd0, n.cd0);
+  const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, n.sb1, n.cb1, n.sd0 + n.hsd, n.cd0 + n.hcd);
+  const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, n.sb2, n.cb2, n.sd0 + 2.0 * n.hsd, n.cd0 + 2.0 * n.hcd);
+  const double m = 0.5 * (double)substeps;
+  *oms_c0 = (float)f0;
+  *oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
+  *oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+}
+// Sun at stride kk of a step: the quadratic through the three fp64 nodes, fp32; the reference's own fp64 chain on the (rare)
+// strides where a solar threshold is within the fp32 floor.  (x_start, y_start, t_start: position and time at the START of the step.)
+BLE_FN SunState sun_at_stride(int kk, float oms_c0, float oms_c1, float oms_c2, const EnvConst& c, float u, float v, float x_start,
+                              float y_start, int32_t t_start) {
+  const float fkk = (float)kk;
+  bool near;
+  SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
+  if (__builtin_expect(near, 0)) {
+    BLE_STEP_EVENT(0);
+    const double dk = 10.0 * (double)kk;
+    r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
+                  c.start_unix + (int64_t)(t_start + 10 * kk));
+  }
+  return r;
+}
+// perciatelli_reward_function (env/balloon_env.py:44-102) on the post-step state; `sun` = the sun at the end of the step
+// (only read when the raw action was DOWN: last_command is the RAW action, balloon.py:286)
+template <typename SunFn>
+BLE_FN float step_reward(int action, float x, float y, float p, float batt, float acs_power, SunFn sun_end) {
+  float r = reward_distance(x, y);
+  if (action == kDown) {
+    const SunState sun = sun_end();
+    const float pw = solar_power(sun, solar_attenuation(sun.sin_el, p, sun.day));
+    const bool excess = (pw > kDayLoad) && ((double)batt / 3058.56 > 0.99);   // balloon.py:231-238
+    if (!excess) {
+      const float scale = f_clamp((acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
+      r *= f_fma(-0.3f, scale, 0.95f);
+    }
+  }
+  return r;
 }
 
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
@@ -208,53 +286,15 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
   float oms_c0, oms_c1, oms_c2;
   {
-    // hour-angle base B = 360 frac_day + eot/4 + lng0  [deg]  (solar.py:113-116)
-    double sod;
-    if (__builtin_expect(t0 >= 0 && t0 < 4294967296LL, 1)) sod = (double)((uint32_t)t0 % 86400u);
-    else { int64_t m = t0 % 86400; sod = (double)(m < 0 ? m + 86400 : m); }
-    const double b0 = sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)c.lng0_deg;
-    const double half_db = 0.5 * ((double)step_s * (1.0 / 240.0) + 0.25 * (double)(e0.eot_min_rate * step_s));  // deg
-    double sb0, cb0;
-    sincos_f64(b0 * (kPiD / 180.0), &sb0, &cb0);
-    // rotate by the half-step angle (0.375 deg): Taylor
-    const double hr = half_db * (kPiD / 180.0), h2 = hr * hr;
-    const double sh = hr * d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
-    const double ch = d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
-    const double sb1 = sb0 * ch + cb0 * sh, cb1 = cb0 * ch - sb0 * sh;
-    const double sb2 = sb1 * ch + cb1 * sh, cb2 = cb1 * ch - sb1 * sh;
-    const double sl0 = hc.sin_lat0, cl0 = hc.cos_lat0;
-    const double x0 = (double)s.x, y0 = (double)s.y;
-    const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-    // (sin, cos) of the declination as an exactly normalised fp64 pair: with the fp32 pair
-    // (|sd^2 + cd^2 - 1| ~ 6e-8) the error of 1 - sin(el) near the zenith (el > 89.8 deg, 1 - sin(el)
-    // < 1e-6) was ~10 % and cos(el) -- hence the panel power -- was off by 2e-5
-    const double sd0 = (double)e0.sin_decl, cd0 = d_sqrt_fast(d_fma(-sd0, sd0, 1.0));
-    const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = -(sd0 * d_rcp(cd0)) * hsd;
-    const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, sb0, cb0, sd0, cd0);
-    const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, sb1, cb1, sd0 + hsd, cd0 + hcd);
-    const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, sb2, cb2, sd0 + 2.0 * hsd, cd0 + 2.0 * hcd);
-    const double m = 0.5 * (double)substeps;
-    oms_c0 = (float)f0;
-    oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
-    oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+    const SolarNodes nodes = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
+    solar_nodes_site(nodes, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps, &oms_c0, &oms_c1, &oms_c2);
   }
   BLE_STEP_TICK(4);
-  // Sun at stride k of this step: quadratic through the three fp64 nodes, fp32; the reference's
-  // own fp64 chain on the (rare) strides where a solar threshold is within the fp32 floor.
   // (position and time at the START of the step, by value: the reward below calls this after s has been advanced)
   const float x_start = s.x, y_start = s.y;
   const int32_t t_start = s.t_elapsed;
   auto sun_at = [&](int kk) -> SunState {
-    const float fkk = (float)kk;
-    bool near;
-    SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
-    if (__builtin_expect(near, 0)) {
-      BLE_STEP_EVENT(0);
-      const double dk = 10.0 * (double)kk;
-      r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
-                    c.start_unix + (int64_t)(t_start + 10 * kk));
-    }
-    return r;
+    return sun_at_stride(kk, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
   };
   const double q_earth = hc.q_earth;
   *flags |= hc.flags;
@@ -332,17 +372,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   *flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
 
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
-  float r = reward_distance(s.x, s.y);
-  if (action == kDown) {   // last_command is the RAW action (balloon.py:286)
-    const SunState sun = sun_at(k);
-    const float pw = solar_power(sun, solar_attenuation(sun.sin_el, s.p, sun.day));
-    const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
-    if (!excess) {
-      const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
-      r *= f_fma(-0.3f, scale, 0.95f);
-    }
-  }
-  *reward = r;
+  *reward = step_reward(action, s.x, s.y, s.p, s.batt, s.acs_power, [&]() { return sun_at(k); });
   BLE_STEP_TICK(6);
   return eff;
 }

@@ -3,21 +3,26 @@
 // ble_step_kernel (one lane per environment, one wave per workgroup) fills the chip at 65 536 environments = 1 024 waves =
 // one per SIMD; a shard of 4 096 or 8 192 environments (BASELINE configs[1], one GPU's share of configs[3]) is 64 or 128
 // waves on 1 024 SIMDs, and a lone wave issues one instruction per ~4.4 cycles whatever it is: the step takes the same
-// 18.8 us however few environments there are.  Every right-hand side of a 10 s stride reads the OLD state only
+// 18 us however few environments there are.  Every right-hand side of a 10 s stride reads the OLD state only
 // (balloon.py:322-325 commits afterwards), so the groups of state variables are independent inside a stride.  Here a
 // workgroup is 4 waves = the 4 SIMDs of a CU, lane l of EVERY wave is environment 64 b + l, and each wave advances one group:
 //
 //   wave 0  vertical dynamics: p, T(p), ambient temperature, position           (stride_pressure, stride_ambient_advance)
 //   wave 1  thermal model: internal temperature                                 (stride_internal_temperature)
-//   wave 2  sun, power, battery, position again, reward                         (sun_fast one stride ahead, stride_power)
-//   wave 3  envelope + ACS: volume, superpressure, mols of air                  (superpressure_volume_f64, stride_acs)
+//   wave 2  the sun, one stride AHEAD (it depends on the stride index only): sin el, panel factor, day -- the rare exact
+//           solar chain runs here, off everybody's critical path -- and the envelope: volume, superpressure
+//           (superpressure_volume_f64); per step: wind lookup, solar nodes, reward
+//   wave 3  ACS + power: mols of air, battery                                   (stride_acs, stride_power_from_factor)
 //
 // After every stride the waves publish what they own in LDS (double-buffered by stride parity), meet at ONE workgroup
-// barrier and read what they need: 6 doubles, 2 floats and 2 status words per lane.  The per-step part (atmosphere window +
-// altitude layer | ephemeris for the flux | ephemeris + solar nodes | power + envelope layers) is spread the same way; the
-// three safety layers publish their action MAPS (each layer is a function of the action alone once its state machine
-// has moved) and every wave composes them.  Between agent steps every exchanged value is rounded to float32, exactly
-// where ble_step_kernel stores its state as float32.
+// barrier and read what they need.  The per-step part is spread the same way (atmosphere window + altitude layer | ephemeris
+// + hour-angle nodes | wind lookup + solar nodes + the sun of stride 0 | power + envelope layers) around two barriers; the
+// safety layers publish their action MAPS (a layer is a function of the action alone once its state machine has moved).
+// Between agent steps every value goes through float32, exactly where ble_step_kernel keeps its state as float32.
+//
+// The stride loops are straight-line: a lane whose episode ended (or was over on entry) keeps computing on a shadow of its
+// state and only its LDS writes are masked, so nobody carries a divergent `break`; every final value of a step is fetched
+// from the LDS slot of the lane's own last stride.
 //
 // Same lane functions as agent_step (ble_step_core.h), same expressions around them: the results are bit for bit those of
 // ble_step_kernel (tests/test_gpu_parity.py::test_split_kernel_equals_one_lane_kernel).  Selected by the host entry
@@ -25,24 +30,43 @@
 #pragma once
 #include "ble_step_core.h"
 
+// Timing build (profiles/build_variant.sh split_timing -DBLE_SPLIT_TIMING): every wave adds the shader-clock cycles it spends in
+// the sections of a step to active_count[role * 8 + section] (used as a debug buffer: pass >= 32 zeroed uint64).  Sections:
+// 0 per-step part, 1 waits at the per-step barriers, 2 stride right-hand sides, 3 publish + wait at the stride barrier,
+// 4 reads after the barrier, 5 end of the step.  Empty in the product build.
+#ifdef BLE_SPLIT_TIMING
+#define BLE_SPLIT_T_DECL long long t_acc[6] = {0, 0, 0, 0, 0, 0}; long long t_last = (long long)__builtin_readcyclecounter()
+#define BLE_SPLIT_T(sec) do { const long long t_now = (long long)__builtin_readcyclecounter(); t_acc[sec] += t_now - t_last; t_last = t_now; } while (0)
+#define BLE_SPLIT_T_FLUSH(dbg, role) do { if ((dbg) != nullptr && lane == 0) { for (int q = 0; q < 6; ++q) atomicAdd((dbg) + (role) * 8 + q, (unsigned long long)t_acc[q]); atomicAdd((dbg) + (role) * 8 + 7, 1ull); } } while (0)
+#else
+#define BLE_SPLIT_T_DECL do {} while (0)
+#define BLE_SPLIT_T(sec) do {} while (0)
+#define BLE_SPLIT_T_FLUSH(dbg, role) do {} while (0)
+#endif
+
 namespace ble {
 
 constexpr int kSplitWaves = 4;
 constexpr int kSplitLanes = 64;
 
-// LDS of one workgroup
+// LDS of one workgroup (12.6 KB)
 struct SplitShared {
   double acs_poly[kAcsPolyDoubles];
-  // stride exchange, [parity][lane]
-  double p[2][kSplitLanes], t_amb[2][kSplitLanes];                         // wave 0
-  double t_int[2][kSplitLanes];                                             // wave 1
-  double vol[2][kSplitLanes], n_air[2][kSplitLanes], sp[2][kSplitLanes];    // wave 3
-  float sin_el[2][kSplitLanes], batt[2][kSplitLanes];                       // wave 2: sun of the NEXT stride, battery
-  uint32_t code2[2][kSplitLanes];                                           // wave 2: bit 0 battery empty, bit 1 next stride is day
-  uint32_t code3[2][kSplitLanes];                                           // wave 3: 0 ok, kBurst, kZeroPressure
-  // step exchange (written in the per-step part, read after its barrier; rewritten a step later, many barriers on)
-  uint32_t map_alt[kSplitLanes], map_pow_env[kSplitLanes];                  // action maps of the safety layers (2 bits per input action)
-  float sin_el0[kSplitLanes]; uint32_t day0[kSplitLanes];                   // wave 2 -> wave 1: the sun of stride 0
+  // ---- stride exchange, [parity][lane]; a lane's slots are written only while its episode runs
+  double p[2][kSplitLanes], t_amb[2][kSplitLanes];                          // wave 0
+  float x[2][kSplitLanes], y[2][kSplitLanes];
+  double t_int[2][kSplitLanes];                                              // wave 1
+  float sin_el[2][kSplitLanes], panel[2][kSplitLanes]; uint32_t day[2][kSplitLanes];      // wave 2: the sun of the NEXT stride
+  double vol[2][kSplitLanes], sp[2][kSplitLanes];                            // wave 2
+  uint32_t code_sp[2][kSplitLanes];                                          // wave 2: 0, kBurst or kZeroPressure after the stride
+  double n_air[2][kSplitLanes];                                              // wave 3
+  float batt[2][kSplitLanes], acs_w[2][kSplitLanes], mdot[2][kSplitLanes], charge[2][kSplitLanes], load[2][kSplitLanes];
+  uint32_t code_batt[2][kSplitLanes];                                        // wave 3: kOutOfPower after the stride, or 0
+  // ---- step exchange (written in the per-step part, read after its barriers; rewritten a step later, many barriers on)
+  double nodes[10][kSplitLanes];                                             // wave 1 -> wave 2: SolarNodes
+  float u[kSplitLanes], v[kSplitLanes];                                      // wave 2 -> wave 0: the wind of the step
+  float sin_el0[kSplitLanes], panel0[kSplitLanes]; uint32_t day0[kSplitLanes];   // wave 2 -> waves 1, 3: the sun of stride 0
+  uint32_t map_alt[kSplitLanes];                                             // wave 0 -> wave 3: the altitude layer's action map
 };
 
 // a safety layer as a map action -> action, 2 bits per input action
@@ -70,10 +94,12 @@ struct SplitArgs {
   int substeps, n_steps;
 };
 
-// One workgroup: 256 threads = 4 waves x 64 lanes; returns this thread's error flags.
+// One wave of a workgroup of 256 threads = 4 waves x 64 lanes; returns this thread's error flags.  `wave` is a
+// compile-time constant: every role is its own instantiation -- its own registers, its own loops -- and the four agree on
+// the number of barriers per step (two in the per-step part, one per stride) by construction.
+template <int wave>
 BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
   const int lane = (int)threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int64_t i = (int64_t)blockIdx.x * kSplitLanes + lane;
   const int64_t n = a.n;
   const bool in_range = i < n;
@@ -84,6 +110,10 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
   EpisodeCacheRow cached = {};
   bool live = false;
   const ble_state_f32& st = a.st;
+  // a lane beyond the batch flies a harmless shadow (never stored): finite, inside the first layer of the atmosphere
+  s.p = 9000.0f; s.t_amb = 215.0f; s.t_int = 220.0f; s.vol = 1810.0f; s.sp = 300.0f; s.n_air = 1500.0f; s.batt = 2000.0f;
+  s.status = kBurst; s.sunrise_h = 43200; s.sunset = 21600;
+  c.ir = 300.0f; c.alpha = 0.5f; c.start_unix = 1356998400;
   if (in_range) {
     // every wave loads the whole state (one round trip): each needs most of it for its part of the per-step work
     s.status = st.status[i];
@@ -101,227 +131,193 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
   __syncthreads();
   const bool was_live = live;
   int last_act = 0;
-  EnvHoisted hc = {};
-  if (live) {
-    if (st.episode_cache != nullptr && episode_cache_hit(cached, c)) {
-      hc = hoisted_from_cache(cached, c);
-    } else {
-      hc = hoist_constants(c);
-      if (wave == 0 && st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
-    }
+  EnvHoisted hc;
+  if (in_range && st.episode_cache != nullptr && episode_cache_hit(cached, c)) {
+    hc = hoisted_from_cache(cached, c);
+  } else {
+    hc = hoist_constants(c);
+    if (wave == 0 && live && st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
   }
-  int xk = 0;                        // exchange counter: stride parity across steps
-  float acs_w = 0.0f, mdot = 0.0f, charge = 0.0f, load = 0.0f;
+  int xk = 0;                        // exchange counter: stride parity, running across the steps
+  BLE_SPLIT_T_DECL;
 
 #pragma unroll 1
   for (int step = 0; step < a.n_steps; ++step) {
     const int64_t o = (int64_t)step * n + i;
-    int act = 0;
-    if (live) { act = a.action[o]; last_act = act; }
+    int act = kStay;
+    if (in_range) act = a.action[o];
+    if (live) last_act = act;
 
-    // ================================================================ per-step part, one role per wave
-    // carried across the strides (each wave uses its own subset)
+    // ================================================================ per-step part (all lanes, live or shadow)
+    // the carried state of the strides; every wave advances its own part and refreshes the rest from LDS
     double p = (double)s.p, t_amb = (double)s.t_amb, t_int = (double)s.t_int, n_air = (double)s.n_air, vol = (double)s.vol,
            sp = (double)s.sp;
     float x = s.x, y = s.y, batt = s.batt;
-    const float p0_in = s.p;
-    const float x_start = s.x, y_start = s.y;
+    float acs_w = 0.0f, mdot = 0.0f, charge = 0.0f, load = 0.0f;
+    float u = 0.0f, v = 0.0f;
+    const float p0_in = s.p, x_start = s.x, y_start = s.y;
     const int32_t t_start = s.t_elapsed;
-    AtmWindow win = {};
-    LayerCursor lc = {};
-    double t_at_p = 0.0;
-    float u = 0.0f, v = 0.0f, fl0 = 0.0f, dfl = 0.0f, oms_c0 = 0.0f, oms_c1 = 0.0f, oms_c2 = 0.0f;
-    SunState sun_next = {};           // wave 2: the sun of the stride about to run
-    float sun_sin = 0.0f; bool sun_day = false;      // wave 1: (sin el, day) of the stride about to run
-    const double q_earth = hc.q_earth;
-    uint32_t my_map = action_map(0, 1, 2);
+    const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
+    const float step_s = (float)(10 * substeps);
+    uint32_t step_flags = 0;
+    // role state
+    AtmWindow win = {}; LayerCursor lc = {}; double t_at_p = 0.0;       // wave 0
+    float fl0 = 0.0f, dfl = 0.0f;                                        // wave 1
+    float oms_c0 = 0.0f, oms_c1 = 0.0f, oms_c2 = 0.0f;                   // wave 2
+    float sun_sin = 0.0f, sun_panel = 0.0f; bool sun_day = false;        // waves 1, 3: the sun of the stride about to run
+    uint32_t map_pow_env = 0; int eff = kStay;                           // wave 3
 
-    if (live) {
-      if (wave == 0 || wave == 2) {
-        // wind at the PRE-step position/time (balloon_arena.py:194,270-275); waves 0 and 2 both need it (position; solar nodes)
-        const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
-        WindCorners corners;
-        wind_gather(a.wind_grid + i * a.grid_env_stride, wq, &corners);
-        float nu = 0.0f, nv = 0.0f;
-        if (a.noise_uv) { nu = a.noise_uv[2 * i]; nv = a.noise_uv[2 * i + 1]; }
-        if (wave == 0) {
-          win = atm_window_from(hc.atm, (double)c.alpha, p, &flags);
-          double altitude;
-          atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
-          lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
-          uint8_t f0 = s.alt_fsm, f1 = s.alt_fsm, f2 = s.alt_fsm;
-          const int r0 = altitude_safety(kDown, altitude, &f0), r1 = altitude_safety(kStay, altitude, &f1),
-                    r2 = altitude_safety(kUp, altitude, &f2);
-          s.alt_fsm = f0;                                   // (the state machine moves independently of the action)
-          my_map = action_map(r0, r1, r2);
-        } else {
-          const int64_t t0 = c.start_unix + (int64_t)s.t_elapsed;
-          const Ephemeris e0 = ephemeris(t0);
-          const float step_s = (float)(10 * substeps);
-          {
-            double sod;
-            if (__builtin_expect(t0 >= 0 && t0 < 4294967296LL, 1)) sod = (double)((uint32_t)t0 % 86400u);
-            else { int64_t m = t0 % 86400; sod = (double)(m < 0 ? m + 86400 : m); }
-            // (the wind must be blended before the nodes: they sit at x0 + k u)
-            wind_blend_corners(corners, wq, &u, &v);
-            u += nu; v += nv;
-            const double b0 = sod * (1.0 / 240.0) + 0.25 * e0.eot_min + (double)c.lng0_deg;
-            const double half_db = 0.5 * ((double)step_s * (1.0 / 240.0) + 0.25 * (double)(e0.eot_min_rate * step_s));  // deg
-            double sb0, cb0;
-            sincos_f64(b0 * (kPiD / 180.0), &sb0, &cb0);
-            const double hr = half_db * (kPiD / 180.0), h2 = hr * hr;
-            const double shh = hr * d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
-            const double ch = d_fma(h2, d_fma(h2, d_fma(h2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
-            const double sb1 = sb0 * ch + cb0 * shh, cb1 = cb0 * ch - sb0 * shh;
-            const double sb2 = sb1 * ch + cb1 * shh, cb2 = cb1 * ch - sb1 * shh;
-            const double sl0 = hc.sin_lat0, cl0 = hc.cos_lat0;
-            const double x0 = (double)s.x, y0 = (double)s.y;
-            const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-            const double sd0 = (double)e0.sin_decl, cd0 = d_sqrt_fast(d_fma(-sd0, sd0, 1.0));
-            const double hsd = 0.5 * (double)(e0.sin_decl_rate * step_s), hcd = -(sd0 * d_rcp(cd0)) * hsd;
-            const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, sb0, cb0, sd0, cd0);
-            const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, sb1, cb1, sd0 + hsd, cd0 + hcd);
-            const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, sb2, cb2, sd0 + 2.0 * hsd, cd0 + 2.0 * hcd);
-            const double m = 0.5 * (double)substeps;
-            oms_c0 = (float)f0;
-            oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
-            oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
-          }
-        }
-        if (wave == 0) {
-          wind_blend_corners(corners, wq, &u, &v);
-          u += nu; v += nv;
-        }
-      } else if (wave == 1) {
-        const Ephemeris e0 = ephemeris(c.start_unix + (int64_t)s.t_elapsed);
-        fl0 = e0.flux; dfl = e0.flux_rate * 10.0f;
-        flags |= hc.flags;
-        // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature, first value of the step
-        flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
-      } else {
-        // the power and envelope layers on the pre-step state (balloon.py:304-313); both state machines move independently
-        // of the action
-        int32_t sr0 = s.sunrise_h, ss0 = s.sunset, sr1 = s.sunrise_h, ss1 = s.sunset, sr2 = s.sunrise_h, ss2 = s.sunset;
-        uint8_t pa0 = s.paused, pa1 = s.paused, pa2 = s.paused, e0 = s.env_fsm, e1 = s.env_fsm, e2 = s.env_fsm;
-        const int q0 = envelope_safety(power_safety(kDown, s.t_elapsed, s.batt, &sr0, &ss0, &pa0), s.sp, &e0);
-        const int q1 = envelope_safety(power_safety(kStay, s.t_elapsed, s.batt, &sr1, &ss1, &pa1), s.sp, &e1);
-        const int q2 = envelope_safety(power_safety(kUp, s.t_elapsed, s.batt, &sr2, &ss2, &pa2), s.sp, &e2);
-        s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = e0;
-        my_map = action_map(q0, q1, q2);
-      }
+    if (wave == 0) {
+      win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
+      lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
+    } else if (wave == 1) {
+      const Ephemeris e0 = ephemeris(t0);
+      fl0 = e0.flux; dfl = e0.flux_rate * 10.0f;
+      const SolarNodes nd = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
+      sh.nodes[0][lane] = nd.sb0; sh.nodes[1][lane] = nd.cb0; sh.nodes[2][lane] = nd.sb1; sh.nodes[3][lane] = nd.cb1;
+      sh.nodes[4][lane] = nd.sb2; sh.nodes[5][lane] = nd.cb2; sh.nodes[6][lane] = nd.sd0; sh.nodes[7][lane] = nd.cd0;
+      sh.nodes[8][lane] = nd.hsd; sh.nodes[9][lane] = nd.hcd;
+      step_flags |= hc.flags;
+      // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature, first value of the step
+      step_flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
+    } else if (wave == 3) {
+      // the power and envelope layers on the pre-step state (balloon.py:304-313); both state machines move independently of
+      // the action, so the three evaluations share everything but the final selects
+      int32_t sr0 = s.sunrise_h, ss0 = s.sunset, sr1 = s.sunrise_h, ss1 = s.sunset, sr2 = s.sunrise_h, ss2 = s.sunset;
+      uint8_t pa0 = s.paused, pa1 = s.paused, pa2 = s.paused, e0 = s.env_fsm, e1 = s.env_fsm, e2 = s.env_fsm;
+      const int q0 = envelope_safety(power_safety(kDown, s.t_elapsed, s.batt, &sr0, &ss0, &pa0), s.sp, &e0);
+      const int q1 = envelope_safety(power_safety(kStay, s.t_elapsed, s.batt, &sr1, &ss1, &pa1), s.sp, &e1);
+      const int q2 = envelope_safety(power_safety(kUp, s.t_elapsed, s.batt, &sr2, &ss2, &pa2), s.sp, &e2);
+      if (live) { s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = e0; }
+      map_pow_env = action_map(q0, q1, q2);
     }
-    // wave 2: the sun of stride 0 (and of every later stride one stride ahead)
-    auto sun_at = [&](int kk) -> SunState {
-      const float fkk = (float)kk;
-      bool near;
-      SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
-      if (__builtin_expect(near, 0)) {
-        const double dk = 10.0 * (double)kk;
-        r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
-                      c.start_unix + (int64_t)(t_start + 10 * kk));
-      }
-      return r;
-    };
-    if (wave == 2 && live) {
-      sun_next = sun_at(0);
-      sh.sin_el0[lane] = sun_next.sin_el;
-      sh.day0[lane] = sun_next.day ? 1u : 0u;
+    // wave 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275); the gather is in flight across barrier 1
+    WindQuery wq = {};
+    WindCorners corners = {};
+    float nu = 0.0f, nv = 0.0f;
+    if (wave == 2) {
+      wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+      wind_gather(a.wind_grid + (in_range ? i : 0) * a.grid_env_stride, wq, &corners);
+      if (a.noise_uv && in_range) { nu = a.noise_uv[2 * i]; nv = a.noise_uv[2 * i + 1]; }
     }
-    if (wave == 0) sh.map_alt[lane] = my_map;
-    if (wave == 3) sh.map_pow_env[lane] = my_map;
-    __syncthreads();
-    const int eff = action_apply_any(sh.map_alt[lane], sh.map_pow_env[lane], act);
-    if (wave == 1) { sun_sin = sh.sin_el0[lane]; sun_day = sh.day0[lane] != 0u; }
+    BLE_SPLIT_T(0);
+    __syncthreads();                                   // ---- barrier 1: the time-only solar nodes are there
+    BLE_SPLIT_T(1);
+    if (wave == 0) {
+      double altitude;
+      atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
+      uint8_t f0 = s.alt_fsm, f1 = s.alt_fsm, f2 = s.alt_fsm;
+      const int r0 = altitude_safety(kDown, altitude, &f0), r1 = altitude_safety(kStay, altitude, &f1),
+                r2 = altitude_safety(kUp, altitude, &f2);
+      if (live) s.alt_fsm = f0;                         // (the state machine moves independently of the action)
+      sh.map_alt[lane] = action_map(r0, r1, r2);
+    } else if (wave == 2) {
+      wind_blend_corners(corners, wq, &u, &v);
+      u += nu; v += nv;                                 // WindField.get_ground_truth = forecast + noise
+      SolarNodes nd;
+      nd.sb0 = sh.nodes[0][lane]; nd.cb0 = sh.nodes[1][lane]; nd.sb1 = sh.nodes[2][lane]; nd.cb1 = sh.nodes[3][lane];
+      nd.sb2 = sh.nodes[4][lane]; nd.cb2 = sh.nodes[5][lane]; nd.sd0 = sh.nodes[6][lane]; nd.cd0 = sh.nodes[7][lane];
+      nd.hsd = sh.nodes[8][lane]; nd.hcd = sh.nodes[9][lane];
+      solar_nodes_site(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps, &oms_c0, &oms_c1, &oms_c2);
+      const SunState sun0 = sun_at_stride(0, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
+      sh.u[lane] = u; sh.v[lane] = v;
+      sh.sin_el0[lane] = sun0.sin_el; sh.panel0[lane] = solar_panel_factor(sun0); sh.day0[lane] = sun0.day ? 1u : 0u;
+    }
+    BLE_SPLIT_T(0);
+    __syncthreads();                                   // ---- barrier 2: wind, the sun of stride 0, the altitude layer's map
+    BLE_SPLIT_T(1);
+    if (wave == 0) { u = sh.u[lane]; v = sh.v[lane]; }
+    if (wave == 1 || wave == 3) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
+    if (wave == 3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
+    if (live) flags |= step_flags;
 
     // ================================================================ the strides
     bool active = live;
-    int k_done = 0, last_rd = 0;       // strides this lane ran; the exchange parity of its last one
-    int status3 = kOk; bool batt_empty = false;
+    int k_done = 0, last_rd = 0, status = kOk;        // strides this lane ran; the exchange parity and the status of its last one
 #pragma unroll 1
     for (int k = 0; k < substeps; ++k) {
-      if (__ballot(active) == 0ull) break;      // (the same decision in all four waves: `active` derives from shared words)
+      if (__ballot(active) == 0ull) break;            // (the same decision in all four waves: `active` derives from shared words)
       const int wr = (xk + 1) & 1;
-      if (active) {
+      // who publishes: a running episode, and the shadow of one that was over on entry (nobody reads ITS finals, and its own
+      // reads must find finite numbers); a lane that ended in this step keeps its slots -- they hold its final state
+      const bool publish = active || !live;
+      if (wave == 0) {
         const double rp = d_rcp(p);
-        if (wave == 0) {
-          const double yc = inv_cbrt_volume(vol);
-          const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
-          x = f_fma(u, kStride, x); y = f_fma(v, kStride, y);
-          t_amb = t_at_p;
-          t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new);
-          p = p_new;
-          sh.p[wr][lane] = p; sh.t_amb[wr][lane] = t_amb;
-        } else if (wave == 1) {
-          const float pf = (float)p;
-          const float flux = f_fma((float)k, dfl, fl0);
-          const double yc = inv_cbrt_volume(vol);
-          const float att = solar_attenuation(sun_sin, pf, sun_day);
-          t_int = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth);
-          sh.t_int[wr][lane] = t_int;
-        } else if (wave == 2) {
-          const float pf = (float)p;
-          const SunState sun = sun_next;
-          const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-          // the ACS power of this stride, as wave 3 evaluates it (acs_down_poly on the same inputs)
-          double w_down, mdot_down;
-          acs_down_poly(sh.acs_poly, d_max(sp, 0.0) * rp, &w_down, &mdot_down);
-          acs_w = eff == kDown ? (float)w_down : 0.0f;
-          stride_power(sun, att, acs_w, &charge, &load, &batt);
-          x = f_fma(u, kStride, x); y = f_fma(v, kStride, y);
-          sun_next = sun_at(k + 1);
-          sh.sin_el[wr][lane] = sun_next.sin_el; sh.batt[wr][lane] = batt;
-          sh.code2[wr][lane] = (batt <= 0.0f ? 1u : 0u) | (sun_next.day ? 2u : 0u);
-        } else {
-          double vol_new, sp_new, mdot_d;
-          superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new);
-          stride_acs(sh.acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
-          mdot = (float)mdot_d;
-          n_air = stride_mols_air(n_air, mdot_d);
-          vol = vol_new; sp = sp_new;
-          // balloon.py:479-482: burst above 2 380 Pa, zero pressure at <= 0 (later checks override earlier ones)
-          sh.code3[wr][lane] = sp_new <= 0.0 ? (uint32_t)kZeroPressure : (!(sp_new <= 2380.0) ? (uint32_t)kBurst : 0u);
-          sh.vol[wr][lane] = vol; sh.n_air[wr][lane] = n_air; sh.sp[wr][lane] = sp;
+        const double yc = inv_cbrt_volume(vol);
+        const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
+        x = f_fma(u, kStride, x); y = f_fma(v, kStride, y);            // step 1 (balloon.py:394-395)
+        t_amb = t_at_p;                                                 // ambient_temperature' = T(p_old)  (balloon.py:457)
+        t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new);
+        p = p_new;
+        if (publish) { sh.p[wr][lane] = p; sh.t_amb[wr][lane] = t_amb; sh.x[wr][lane] = x; sh.y[wr][lane] = y; }
+      } else if (wave == 1) {
+        const float flux = f_fma((float)k, dfl, fl0);
+        const double yc = inv_cbrt_volume(vol);
+        const float att = solar_attenuation(sun_sin, (float)p, sun_day);
+        t_int = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth);
+        if (publish) sh.t_int[wr][lane] = t_int;
+      } else if (wave == 2) {
+        const SunState sn = sun_at_stride(k + 1, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
+        const float pf = solar_panel_factor(sn);
+        // step 4: superpressure and volume (balloon.py:470-482): burst above 2 380 Pa, zero pressure at <= 0 (the later check overrides)
+        superpressure_volume_f64(n_air, t_int, p, d_rcp(p), &vol, &sp);
+        const uint32_t code = sp <= 0.0 ? (uint32_t)kZeroPressure : (!(sp <= 2380.0) ? (uint32_t)kBurst : 0u);
+        if (publish) {
+          sh.sin_el[wr][lane] = sn.sin_el; sh.panel[wr][lane] = pf; sh.day[wr][lane] = sn.day ? 1u : 0u;
+          sh.vol[wr][lane] = vol; sh.sp[wr][lane] = sp; sh.code_sp[wr][lane] = code;
+        }
+      } else {
+        const double rp = d_rcp(p);
+        const float att = solar_attenuation(sun_sin, (float)p, sun_day);
+        double mdot_d;
+        stride_acs(sh.acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
+        mdot = (float)mdot_d;
+        n_air = stride_mols_air(n_air, mdot_d);
+        stride_power_from_factor(sun_day, sun_panel, att, acs_w, &charge, &load, &batt);
+        if (publish) {
+          sh.n_air[wr][lane] = n_air; sh.batt[wr][lane] = batt; sh.acs_w[wr][lane] = acs_w; sh.mdot[wr][lane] = mdot;
+          sh.charge[wr][lane] = charge; sh.load[wr][lane] = load;
+          sh.code_batt[wr][lane] = batt <= 0.0f ? (uint32_t)kOutOfPower : 0u;         // balloon.py:541-542
         }
       }
+      BLE_SPLIT_T(2);
       __syncthreads();
+      BLE_SPLIT_T(3);
       ++xk;
-      if (active) {
-        const int rd = xk & 1;
-        k_done = k + 1; last_rd = rd;
-        const uint32_t c2 = sh.code2[rd][lane], c3 = sh.code3[rd][lane];
-        if (wave == 0) { vol = sh.vol[rd][lane]; n_air = sh.n_air[rd][lane]; }
-        else if (wave == 1) { p = sh.p[rd][lane]; t_amb = sh.t_amb[rd][lane]; vol = sh.vol[rd][lane]; sun_sin = sh.sin_el[rd][lane]; sun_day = (c2 & 2u) != 0u; }
-        else if (wave == 2) { p = sh.p[rd][lane]; sp = sh.sp[rd][lane]; }
-        else { p = sh.p[rd][lane]; t_int = sh.t_int[rd][lane]; }
-        status3 = (int)c3; batt_empty = (c2 & 1u) != 0u;
-        if (status3 != kOk || batt_empty) active = false;          // balloon.py:327-328
-      }
+      const int rd = xk & 1;
+      if (wave == 0) { vol = sh.vol[rd][lane]; n_air = sh.n_air[rd][lane]; }
+      else if (wave == 1) { p = sh.p[rd][lane]; t_amb = sh.t_amb[rd][lane]; vol = sh.vol[rd][lane]; sun_sin = sh.sin_el[rd][lane]; sun_day = sh.day[rd][lane] != 0u; }
+      else if (wave == 2) { p = sh.p[rd][lane]; t_int = sh.t_int[rd][lane]; n_air = sh.n_air[rd][lane]; }
+      else { p = sh.p[rd][lane]; t_int = sh.t_int[rd][lane]; sp = sh.sp[rd][lane]; sun_sin = sh.sin_el[rd][lane]; sun_panel = sh.panel[rd][lane]; sun_day = sh.day[rd][lane] != 0u; }
+      // later checks override earlier ones (balloon.py:479-482, 541-542): burst, zero pressure, out of power
+      const uint32_t cb = sh.code_batt[rd][lane], cs = sh.code_sp[rd][lane];
+      const int code = (int)(cb != 0u ? cb : cs);
+      k_done = active ? k + 1 : k_done; last_rd = active ? rd : last_rd; status = active ? code : status;
+      active = active && code == kOk;                 // balloon.py:327-328
+      BLE_SPLIT_T(4);
     }
 
     // ================================================================ end of the step: float32 state, status, reward
     if (live) {
-      const int rd = last_rd;         // this lane's last stride (it may have ended before the others): every wave fetches what it does not own
-      int status = status3;
-      if (batt_empty) status = kOutOfPower;
-      if (wave != 0) { p = sh.p[rd][lane]; t_amb = sh.t_amb[rd][lane]; }
-      if (wave != 1) t_int = sh.t_int[rd][lane];
-      if (wave != 3) { vol = sh.vol[rd][lane]; n_air = sh.n_air[rd][lane]; sp = sh.sp[rd][lane]; }
-      if (wave != 2) batt = sh.batt[rd][lane];
-      s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
-      s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;
+      const int rd = last_rd;         // this lane's last stride (it may have ended before the others)
+      s.p = (float)sh.p[rd][lane]; s.t_amb = (float)sh.t_amb[rd][lane]; s.t_int = (float)sh.t_int[rd][lane];
+      s.vol = (float)sh.vol[rd][lane]; s.sp = (float)sh.sp[rd][lane]; s.n_air = (float)sh.n_air[rd][lane];
+      s.batt = sh.batt[rd][lane]; s.x = sh.x[rd][lane]; s.y = sh.y[rd][lane];
       s.t_elapsed += 10 * k_done;
       s.status = (uint8_t)status;
-      if (wave == 0 || wave == 2) { s.x = x; s.y = y; }       // (waves 1 and 3 never read the position)
       if (wave == 1) flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
       if (wave == 2) {
-        s.acs_power = acs_w; s.charge = charge; s.load = load;
+        s.acs_power = sh.acs_w[rd][lane];
         // solar_atmospheric_attenuation's range check (solar.py:194-197); p moves < 3 kPa per step
         flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
-        // ---- reward (env/balloon_env.py:44-102), on the post-step state
+        // the sun at the end of the step = what this wave published at the lane's last stride: sun_at_stride(k_done); the reward
+        // needs sin el and day (attenuation) and the panel factor (solar_power == solar_power_from_factor o solar_panel_factor)
+        SunState sun_end = {};
+        sun_end.sin_el = sh.sin_el[rd][lane]; sun_end.day = sh.day[rd][lane] != 0u;
+        const float panel_end = sh.panel[rd][lane];
         float r = reward_distance(s.x, s.y);
-        if (act == kDown) {   // last_command is the RAW action (balloon.py:286)
-          const SunState sun = sun_next;             // == sun_at(k_done)
-          const float pw = solar_power(sun, solar_attenuation(sun.sin_el, s.p, sun.day));
+        if (act == kDown) {   // last_command is the RAW action (balloon.py:286); step_reward() with the panel factor at hand
+          const float pw = solar_power_from_factor(panel_end, solar_attenuation(sun_end.sin_el, s.p, sun_end.day));
           const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
           if (!excess) {
             const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
@@ -333,21 +329,22 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         a.terminal[o] = s.status != kOk;
       }
       if (wave == 3) {
-        s.acs_power = acs_w; s.mdot = mdot;
+        s.acs_power = sh.acs_w[rd][lane]; s.mdot = sh.mdot[rd][lane]; s.charge = sh.charge[rd][lane]; s.load = sh.load[rd][lane];
         if (a.effective_action) a.effective_action[o] = (uint8_t)eff;
       }
     } else if (in_range) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
       if (wave == 2) { a.reward[o] = 0.0f; a.terminal[o] = 1; }
       if (wave == 3 && a.effective_action) a.effective_action[o] = a.action[o];
     }
+#ifndef BLE_SPLIT_TIMING
     if (wave == 0 && a.active_count) {
       const unsigned long long m = __ballot(live);
       if (lane == 0 && m)
         atomicAdd(a.active_count + (int64_t)step * BLE_COUNT_SLOTS + (blockIdx.x & (BLE_COUNT_SLOTS - 1)), (unsigned long long)__popcll(m));
     }
+#endif
     live = live && s.status == kOk;
-    // the safety layers' state and the position live in their own waves; the next step's per-step part needs: wave 0 x, y
-    // (own), wave 2 x, y (own), wave 3 sunrise / sunset / paused / env_fsm (own), wave 0 alt_fsm (own): nothing to exchange
+    BLE_SPLIT_T(5);
   }
 
   if (was_live) {
@@ -357,13 +354,13 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     } else if (wave == 1) {
       st.internal_temperature[i] = s.t_int; st.status[i] = s.status; st.last_command[i] = (uint8_t)last_act;
     } else if (wave == 2) {
-      st.battery_charge[i] = s.batt; st.solar_charging[i] = s.charge; st.power_load[i] = s.load;
+      st.battery_charge[i] = s.batt; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp; st.mols_air[i] = s.n_air;
     } else {
-      st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp; st.mols_air[i] = s.n_air;
-      st.acs_power[i] = s.acs_power; st.acs_mass_flow[i] = s.mdot;
+      st.acs_power[i] = s.acs_power; st.acs_mass_flow[i] = s.mdot; st.solar_charging[i] = s.charge; st.power_load[i] = s.load;
       st.sunrise_h_rel[i] = s.sunrise_h; st.sunset_rel[i] = s.sunset; st.env_fsm[i] = s.env_fsm; st.power_paused[i] = s.paused;
     }
   }
+  BLE_SPLIT_T_FLUSH(a.active_count, wave);
   return flags;
 }
 
