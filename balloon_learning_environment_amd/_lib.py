@@ -49,7 +49,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
       hipcc = 'hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', os.path.join(_PKG_DIR, 'csrc'),
+    # -ffp-contract=on: a * b + c fuses where the SOURCE writes it in one expression and nowhere else.  hipcc's default
+    # ("fast") also fuses across statements wherever the optimiser happens to see a product next to a sum, which depends on the
+    # code around it (inlining, vectorisation): the same lane function then rounds differently in two kernels.  The transition
+    # exists in three kernels that must agree bit for bit (one lane per environment, four waves per environment, noise
+    # generated in-kernel); measured neutral on both hot kernels (profiles/r04_notes.md).
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '-fPIC', '-shared', '-I', os.path.join(_PKG_DIR, 'csrc'),
            '-o', LIB_PATH, _SOURCES[0]]
     if verbose:
       cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')

@@ -129,6 +129,9 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
           wind_noise_cached(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, gen.harmonic_cache, n, &nu, &nv);
         else
           wind_noise(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, &nu, &nv);
+        // the noise is a VALUE here as it is between ble_wind_noise_f32 and ble_step_f32: without this the compiler is free to
+        // fuse the generator's last multiplication into agent_step's `u += noise_u` (one rounding instead of two)
+        asm volatile("" : "+v"(nu), "+v"(nv));
       } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
       const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, &r, &flags);

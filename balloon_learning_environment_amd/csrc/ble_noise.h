@@ -10,6 +10,10 @@
 // primitive here is Gustavson's 4-D simplex noise with hashed gradients (no permutation tables:
 // 10 generators x 256 B per environment would not fit LDS at one lane per environment), its
 // empirical variance measured on the device (tests/test_gpu_noise.py).
+//
+// Every function below evaluates with `fp contract(off)`: the generator runs in two kernels -- ble_wind_noise_kernel and,
+// inlined, ble_step_kernel<noise> (ABI 3) -- and the two must produce the same bits whatever the surrounding code lets the
+// compiler fuse (tests/test_gpu_parity.py: fused rollout in the ground-truth wind == noise kernel + single steps).
 #pragma once
 #include <math.h>
 
@@ -49,6 +53,7 @@ BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
 // One corner: (0.6 - |d|^2)^4 * (gradient . d), gradient = one of the 32 midpoints of the edges of
 // the 4-cube (one zero component, the other three +-1).
 BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h) {
+  BLE_NO_CONTRACT
   float t = 0.6f - x * x - y * y - z * z - w * w;
   if (t < 0.0f) return 0.0f;
   const uint32_t g = h >> 27;                      // 5 bits
@@ -59,6 +64,7 @@ BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h) {
   return t * t * (a + b + c);
 }
 BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed) {
+  BLE_NO_CONTRACT
   const float F4 = 0.30901699437494745f, G4 = 0.1381966011250105f;
   const float s = (x + y + z + w) * F4;
   const int i = (int)floorf(x + s), j = (int)floorf(y + s), k = (int)floorf(z + s), l = (int)floorf(w + s);
@@ -99,17 +105,22 @@ BLE_FN HarmonicDraw harmonic_draw(Philox& g) {
 struct NoiseAccumulator { float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f; };
 BLE_FN void noise_add_harmonic(NoiseAccumulator& a, int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure,
                                float t_h) {
+  BLE_NO_CONTRACT
   const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
   const Harmonic hp = harmonic_params(comp, h);
   const float nz = magnitude * simplex4(x_km / hp.x_spacing + d.ox, y_km / hp.y_spacing + d.oy, pressure / hp.p_spacing + d.op,
                                         t_h / hp.t_spacing + d.ot, d.hseed);
   a.acc = f_fma(nz, hp.weight, a.acc); a.wsum += hp.weight; a.w2sum = f_fma(hp.weight, hp.weight, a.w2sum);
 }
-BLE_FN float noise_finish(const NoiseAccumulator& a) { return a.acc / a.wsum * sqrtf(a.wsum / a.w2sum); }
+BLE_FN float noise_finish(const NoiseAccumulator& a) {
+  BLE_NO_CONTRACT
+  return a.acc / a.wsum * sqrtf(a.wsum / a.w2sum);
+}
 
 // Both components at one point, the harmonics' seeds and offsets drawn on the spot (50 Philox draws).
 BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env,
                                   uint32_t episode, float* u, float* v) {
+  BLE_NO_CONTRACT
   Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
   const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
   float out[2];
@@ -133,6 +144,7 @@ BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, 
 constexpr int kNoiseCacheRows = 53;
 BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint32_t episode,
                               uint32_t* cache, int64_t n, float* u, float* v) {
+  BLE_NO_CONTRACT
   uint32_t* mine = cache + env;
   const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
   if (!(mine[50 * n] == k0 && mine[51 * n] == k1 && mine[52 * n] == k2)) {

@@ -205,17 +205,28 @@ BLE_FN SolarNodes solar_nodes_time(const Ephemeris& e0, int64_t t0, float lng0_d
   n.sd0 = sd0; n.cd0 = cd0; n.hsd = hsd; n.hcd = hcd;
   return n;
 }
-BLE_FN void solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps,
-                             float* oms_c0, float* oms_c1, float* oms_c2) {
+// 1 - sin(el_uncorrected) at node j (0: start of the step, 1: middle, 2: end); the balloon moves with the step's constant wind
+template <int j>
+BLE_FN double solar_node(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps) {
   const double x0 = (double)x_m, y0 = (double)y_m;
   const double dx = (double)u * (5.0 * (double)substeps), dy = (double)v * (5.0 * (double)substeps);  // half step
-  const double f0 = sun_one_minus_sin_f64(sl0, cl0, x0, y0, n.sb0, n.cb0, n.sd0, n.cd0);
-  const double f1 = sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, n.sb1, n.cb1, n.sd0 + n.hsd, n.cd0 + n.hcd);
-  const double f2 = sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, n.sb2, n.cb2, n.sd0 + 2.0 * n.hsd, n.cd0 + 2.0 * n.hcd);
+  if (j == 0) return sun_one_minus_sin_f64(sl0, cl0, x0, y0, n.sb0, n.cb0, n.sd0, n.cd0);
+  if (j == 1) return sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, n.sb1, n.cb1, n.sd0 + n.hsd, n.cd0 + n.hcd);
+  return sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, n.sb2, n.cb2, n.sd0 + 2.0 * n.hsd, n.cd0 + 2.0 * n.hcd);
+}
+// the quadratic through the three nodes, in the stride index
+BLE_FN void solar_node_coefs(double f0, double f1, double f2, int substeps, float* oms_c0, float* oms_c1, float* oms_c2) {
   const double m = 0.5 * (double)substeps;
   *oms_c0 = (float)f0;
   *oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
   *oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+}
+BLE_FN void solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps,
+                             float* oms_c0, float* oms_c1, float* oms_c2) {
+  const double f0 = solar_node<0>(n, sl0, cl0, x_m, y_m, u, v, substeps);
+  const double f1 = solar_node<1>(n, sl0, cl0, x_m, y_m, u, v, substeps);
+  const double f2 = solar_node<2>(n, sl0, cl0, x_m, y_m, u, v, substeps);
+  solar_node_coefs(f0, f1, f2, substeps, oms_c0, oms_c1, oms_c2);
 }
 // Sun at stride kk of a step: the quadratic through the three fp64 nodes, fp32; the reference's own fp64 chain on the (rare)
 // strides where a solar threshold is within the fp32 floor.  (x_start, y_start, t_start: position and time at the START of the step.)
@@ -232,6 +243,11 @@ BLE_FN SunState sun_at_stride(int kk, float oms_c0, float oms_c1, float oms_c2, 
   }
   return r;
 }
+// BalloonState.excess_energy's battery test (balloon.py:231-238): battery_charge / battery_capacity > 0.99 in the reference's
+// float64, on the float32 charge the ABI carries.  A correctly rounded division is monotone in its numerator, so the predicate
+// is a threshold on the float32 itself: 3027.9746 (0x1.7a7f3p+11) is the smallest float32 b with (double)b / 3058.56 > 0.99
+// (its predecessor gives 0.98999999; tests/test_kernel_numerics_host.py) -- the same decision without the fp64 division.
+BLE_FN bool battery_above_99_percent(float batt) { return batt >= 3027.9746f; }
 // perciatelli_reward_function (env/balloon_env.py:44-102) on the post-step state; `sun` = the sun at the end of the step
 // (only read when the raw action was DOWN: last_command is the RAW action, balloon.py:286)
 template <typename SunFn>
@@ -240,7 +256,7 @@ BLE_FN float step_reward(int action, float x, float y, float p, float batt, floa
   if (action == kDown) {
     const SunState sun = sun_end();
     const float pw = solar_power(sun, solar_attenuation(sun.sin_el, p, sun.day));
-    const bool excess = (pw > kDayLoad) && ((double)batt / 3058.56 > 0.99);   // balloon.py:231-238
+    const bool excess = (pw > kDayLoad) && battery_above_99_percent(batt);   // balloon.py:231-238
     if (!excess) {
       const float scale = f_clamp((acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
       r *= f_fma(-0.3f, scale, 0.95f);

@@ -15,9 +15,10 @@
 //   wave 3  ACS + power: mols of air, battery                                   (stride_acs, stride_power_from_factor)
 //
 // After every stride the waves publish what they own in LDS (double-buffered by stride parity), meet at ONE workgroup
-// barrier and read what they need.  The per-step part is spread the same way (atmosphere window + altitude layer | ephemeris
-// + hour-angle nodes | wind lookup + solar nodes + the sun of stride 0 | power + envelope layers) around two barriers; the
-// safety layers publish their action MAPS (a layer is a function of the action alone once its state machine has moved).
+// barrier and read what they need.  The per-step part is spread the same way around two barriers (atmosphere window |
+// ephemeris | wind lookup | power + envelope layers; then the altitude layer and one solar node each on waves 1, 2, 3, wave 2
+// the sun of stride 0 with it); the safety layers publish their action MAPS (a layer is a function of the action alone once
+// its state machine has moved).
 // Between agent steps every value goes through float32, exactly where ble_step_kernel keeps its state as float32.
 //
 // The stride loops are straight-line: a lane whose episode ended (or was over on entry) keeps computing on a shadow of its
@@ -63,8 +64,9 @@ struct SplitShared {
   float batt[2][kSplitLanes], acs_w[2][kSplitLanes], mdot[2][kSplitLanes], charge[2][kSplitLanes], load[2][kSplitLanes];
   uint32_t code_batt[2][kSplitLanes];                                        // wave 3: kOutOfPower after the stride, or 0
   // ---- step exchange (written in the per-step part, read after its barriers; rewritten a step later, many barriers on)
-  double nodes[10][kSplitLanes];                                             // wave 1 -> wave 2: SolarNodes
-  float u[kSplitLanes], v[kSplitLanes];                                      // wave 2 -> wave 0: the wind of the step
+  double eot_min[kSplitLanes]; float eph[3][kSplitLanes];                    // wave 1 -> waves 2, 3: the ephemeris fields the hour-angle nodes need
+  double node_f[2][kSplitLanes];                                             // waves 1, 3 -> wave 2: the middle and end nodes of the step
+  float u[kSplitLanes], v[kSplitLanes];                                      // wave 2 -> all: the wind of the step
   float sin_el0[kSplitLanes], panel0[kSplitLanes]; uint32_t day0[kSplitLanes];   // wave 2 -> waves 1, 3: the sun of stride 0
   uint32_t map_alt[kSplitLanes];                                             // wave 0 -> wave 3: the altitude layer's action map
 };
@@ -162,8 +164,8 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     uint32_t step_flags = 0;
     // role state
     AtmWindow win = {}; LayerCursor lc = {}; double t_at_p = 0.0;       // wave 0
-    float fl0 = 0.0f, dfl = 0.0f;                                        // wave 1
-    float oms_c0 = 0.0f, oms_c1 = 0.0f, oms_c2 = 0.0f;                   // wave 2
+    float fl0 = 0.0f, dfl = 0.0f; Ephemeris e0 = {};                     // wave 1 (e0: the part solar_nodes_time reads, on waves 1, 2, 3)
+    float oms_c0 = 0.0f, oms_c1 = 0.0f, oms_c2 = 0.0f; double node_f0 = 0.0;   // wave 2
     float sun_sin = 0.0f, sun_panel = 0.0f; bool sun_day = false;        // waves 1, 3: the sun of the stride about to run
     uint32_t map_pow_env = 0; int eff = kStay;                           // wave 3
 
@@ -171,12 +173,10 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
       lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
     } else if (wave == 1) {
-      const Ephemeris e0 = ephemeris(t0);
+      e0 = ephemeris(t0);
       fl0 = e0.flux; dfl = e0.flux_rate * 10.0f;
-      const SolarNodes nd = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
-      sh.nodes[0][lane] = nd.sb0; sh.nodes[1][lane] = nd.cb0; sh.nodes[2][lane] = nd.sb1; sh.nodes[3][lane] = nd.cb1;
-      sh.nodes[4][lane] = nd.sb2; sh.nodes[5][lane] = nd.cb2; sh.nodes[6][lane] = nd.sd0; sh.nodes[7][lane] = nd.cd0;
-      sh.nodes[8][lane] = nd.hsd; sh.nodes[9][lane] = nd.hcd;
+      // what the hour-angle nodes of the step need of it (solar_nodes_time)
+      sh.eot_min[lane] = e0.eot_min; sh.eph[0][lane] = e0.eot_min_rate; sh.eph[1][lane] = e0.sin_decl; sh.eph[2][lane] = e0.sin_decl_rate;
       step_flags |= hc.flags;
       // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature, first value of the step
       step_flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
@@ -191,17 +191,19 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       if (live) { s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = e0; }
       map_pow_env = action_map(q0, q1, q2);
     }
-    // wave 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275); the gather is in flight across barrier 1
-    WindQuery wq = {};
-    WindCorners corners = {};
-    float nu = 0.0f, nv = 0.0f;
+    // wave 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275): WindField.get_ground_truth = forecast + noise
     if (wave == 2) {
-      wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+      const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
+      WindCorners corners;
       wind_gather(a.wind_grid + (in_range ? i : 0) * a.grid_env_stride, wq, &corners);
+      float nu = 0.0f, nv = 0.0f;
       if (a.noise_uv && in_range) { nu = a.noise_uv[2 * i]; nv = a.noise_uv[2 * i + 1]; }
+      wind_blend_corners(corners, wq, &u, &v);
+      u += nu; v += nv;
+      sh.u[lane] = u; sh.v[lane] = v;
     }
     BLE_SPLIT_T(0);
-    __syncthreads();                                   // ---- barrier 1: the time-only solar nodes are there
+    __syncthreads();                                   // ---- barrier 1: the ephemeris and the wind are there
     BLE_SPLIT_T(1);
     if (wave == 0) {
       double altitude;
@@ -211,22 +213,27 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
                 r2 = altitude_safety(kUp, altitude, &f2);
       if (live) s.alt_fsm = f0;                         // (the state machine moves independently of the action)
       sh.map_alt[lane] = action_map(r0, r1, r2);
-    } else if (wave == 2) {
-      wind_blend_corners(corners, wq, &u, &v);
-      u += nu; v += nv;                                 // WindField.get_ground_truth = forecast + noise
-      SolarNodes nd;
-      nd.sb0 = sh.nodes[0][lane]; nd.cb0 = sh.nodes[1][lane]; nd.sb1 = sh.nodes[2][lane]; nd.cb1 = sh.nodes[3][lane];
-      nd.sb2 = sh.nodes[4][lane]; nd.cb2 = sh.nodes[5][lane]; nd.sd0 = sh.nodes[6][lane]; nd.cd0 = sh.nodes[7][lane];
-      nd.hsd = sh.nodes[8][lane]; nd.hcd = sh.nodes[9][lane];
-      solar_nodes_site(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps, &oms_c0, &oms_c1, &oms_c2);
-      const SunState sun0 = sun_at_stride(0, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
-      sh.u[lane] = u; sh.v[lane] = v;
-      sh.sin_el0[lane] = sun0.sin_el; sh.panel0[lane] = solar_panel_factor(sun0); sh.day0[lane] = sun0.day ? 1u : 0u;
+      u = sh.u[lane]; v = sh.v[lane];
+    } else {
+      // the three solar nodes of the step, one per wave (wave 2 has the wind in registers, wave 1 the ephemeris); each wave
+      // forms the time-only half itself -- the same function of the same four numbers -- and uses its own node of it
+      if (wave != 2) { u = sh.u[lane]; v = sh.v[lane]; }
+      if (wave != 1) { e0.eot_min = sh.eot_min[lane]; e0.eot_min_rate = sh.eph[0][lane]; e0.sin_decl = sh.eph[1][lane]; e0.sin_decl_rate = sh.eph[2][lane]; }
+      const SolarNodes nd = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
+      if (wave == 1) sh.node_f[0][lane] = solar_node<1>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
+      if (wave == 3) sh.node_f[1][lane] = solar_node<2>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
+      if (wave == 2) {
+        node_f0 = solar_node<0>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
+        // the sun of stride 0 needs the first node alone: the quadratic at index 0 is its constant term (the other two
+        // coefficients are finite), so it is ready at the same barrier as the nodes
+        const SunState sun0 = sun_at_stride(0, (float)node_f0, 0.0f, 0.0f, c, u, v, x_start, y_start, t_start);
+        sh.sin_el0[lane] = sun0.sin_el; sh.panel0[lane] = solar_panel_factor(sun0); sh.day0[lane] = sun0.day ? 1u : 0u;
+      }
     }
     BLE_SPLIT_T(0);
-    __syncthreads();                                   // ---- barrier 2: wind, the sun of stride 0, the altitude layer's map
+    __syncthreads();                                   // ---- barrier 2: the nodes, the sun of stride 0, the altitude layer's map
     BLE_SPLIT_T(1);
-    if (wave == 0) { u = sh.u[lane]; v = sh.v[lane]; }
+    if (wave == 2) solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps, &oms_c0, &oms_c1, &oms_c2);
     if (wave == 1 || wave == 3) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
     if (wave == 3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
     if (live) flags |= step_flags;
@@ -318,7 +325,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         float r = reward_distance(s.x, s.y);
         if (act == kDown) {   // last_command is the RAW action (balloon.py:286); step_reward() with the panel factor at hand
           const float pw = solar_power_from_factor(panel_end, solar_attenuation(sun_end.sin_el, s.p, sun_end.day));
-          const bool excess = (pw > kDayLoad) && ((double)s.batt / 3058.56 > 0.99);   // balloon.py:231-238
+          const bool excess = (pw > kDayLoad) && battery_above_99_percent(s.batt);   // balloon.py:231-238
           if (!excess) {
             const float scale = f_clamp((s.acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
             r *= f_fma(-0.3f, scale, 0.95f);

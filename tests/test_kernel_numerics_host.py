@@ -267,3 +267,22 @@ def test_dates_outside_the_samplers_range_and_the_reference_julian_day_quirk():
     e.lib().emul_solar(ctypes.c_int64(1), *[a.ctypes.data_as(ctypes.c_void_p) for a in args])
     day_shift = abs(el_next_day - el_ref)                       # what one day of declination is worth at this date
     assert (abs(float(el[0]) - el_ref) > 0.3 * day_shift) == off_by_a_day, (when, el[0], el_ref, day_shift)
+
+
+def test_battery_excess_threshold_is_the_reference_division():
+  """BalloonState.excess_energy compares battery_charge / battery_capacity > 0.99 in float64 (balloon.py:231-238); the kernels
+  compare the float32 charge with 3027.9746 instead (csrc/ble_step_core.h::battery_above_99_percent).  A correctly rounded
+  division is monotone in its numerator, so the two agree on EVERY float32 iff they agree at the threshold and its neighbours."""
+  thr = np.float32(3027.9746)
+  assert float(thr).hex() == '0x1.7a7f300000000p+11'
+  nb = [thr]
+  for _ in range(4):
+    nb.append(np.nextafter(nb[-1], np.float32(np.inf)))
+  lo = thr
+  for _ in range(4):
+    lo = np.nextafter(lo, np.float32(-np.inf)); nb.append(lo)
+  for b in nb + [np.float32(0.0), np.float32(3058.56), np.float32(2905.6), np.float32(3027.0), np.float32(3028.5)]:
+    assert (np.float64(b) / 3058.56 > 0.99) == bool(b >= thr), b
+  rng = np.random.default_rng(0)
+  b = rng.uniform(3020.0, 3035.0, 200000).astype(np.float32)
+  assert np.array_equal(b.astype(np.float64) / 3058.56 > 0.99, b >= thr)
