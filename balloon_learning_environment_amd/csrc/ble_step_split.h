@@ -27,7 +27,8 @@
 //
 // Same lane functions as agent_step (ble_step_core.h), same expressions around them: the results are bit for bit those of
 // ble_step_kernel (tests/test_gpu_parity.py::test_split_kernel_equals_one_lane_kernel).  Selected by the host entry
-// points for n <= BLE_SPLIT_MAX_ENVS (4 waves x n / 64 workgroups still fit one wave per SIMD).
+// points for n <= BLE_SPLIT_MAX_ENVS = 32 768 (two waves per SIMD: measured 1.4x the one-lane kernel there, 1.9x at <= 16 384
+// environments where every wave has a SIMD to itself; at 65 536 -- four waves per SIMD -- the one-lane kernel wins).
 #pragma once
 #include "ble_step_core.h"
 
@@ -299,6 +300,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       // later checks override earlier ones (balloon.py:479-482, 541-542): burst, zero pressure, out of power
       const uint32_t cb = sh.code_batt[rd][lane], cs = sh.code_sp[rd][lane];
       const int code = (int)(cb != 0u ? cb : cs);
+      // (selects, not a branch: a rarely taken block in this loop measured +3 %)
       k_done = active ? k + 1 : k_done; last_rd = active ? rd : last_rd; status = active ? code : status;
       active = active && code == kOk;                 // balloon.py:327-328
       BLE_SPLIT_T(4);

@@ -120,9 +120,10 @@ typedef struct ble_state_f32 {
 #define BLE_EPISODE_CACHE_ROWS 7
 #define BLE_MAX_SUBSTEPS 60
 /* Up to this many environments ble_step_f32 / ble_step_n_f32 (without a noise generator) run the four-wavefronts-per-
- * environment form of the transition (csrc/ble_step_split.h: 4 x n / 64 waves, still at most one per SIMD), above it the
- * one-lane-per-environment kernel.  The two are bit-identical; BLE_STEP_SPLIT=0 / 1 in the process environment forces one. */
-#define BLE_SPLIT_MAX_ENVS 16384
+ * environment form of the transition (csrc/ble_step_split.h: 4 x n / 64 waves -- one per SIMD up to 16 384 environments,
+ * two up to 32 768), above it the one-lane-per-environment kernel (one wave per SIMD at 65 536).  The two are
+ * bit-identical; BLE_STEP_SPLIT=0 / 1 in the process environment forces one. */
+#define BLE_SPLIT_MAX_ENVS 32768
 
 int ble_abi_version(void);
 
