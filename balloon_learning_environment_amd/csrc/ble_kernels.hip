@@ -71,6 +71,8 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   __shared__ double acs_poly[kAcsPolyDoubles];
+  // kNoise: the harmonics' seeds and offsets of this wave's environments, fetched once per launch ([50][64] words)
+  __shared__ uint32_t noise_draws[kNoise ? 50 * kBlock : 1];
   const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
   const bool in_range = i < n && (int)threadIdx.x < lanes;
   uint32_t flags = 0;
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       if (st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
     }
   }
+  if (kNoise && in_range)
+    noise_draws_fetch(gen.seed, (uint64_t)i, gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n, noise_draws + threadIdx.x, kBlock);
   BLE_STEP_MARK(3);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
@@ -124,11 +128,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
       float nu = 0.0f, nv = 0.0f;
       if (kNoise) {
-        const uint32_t ep = gen.episode ? gen.episode[i] : 0u;
-        if (gen.harmonic_cache != nullptr)
-          wind_noise_cached(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, gen.harmonic_cache, n, &nu, &nv);
-        else
-          wind_noise(s.x, s.y, s.p, s.t_elapsed, gen.seed, (uint64_t)i, ep, &nu, &nv);
+        wind_noise_from_rows(s.x, s.y, s.p, s.t_elapsed, noise_draws + threadIdx.x, kBlock, &nu, &nv);
         // the noise is a VALUE here as it is between ble_wind_noise_f32 and ble_step_f32: without this the compiler is free to
         // fuse the generator's last multiplication into agent_step's `u += noise_u` (one rounding instead of two)
         asm volatile("" : "+v"(nu), "+v"(nv));

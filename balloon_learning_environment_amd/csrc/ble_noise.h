@@ -137,11 +137,61 @@ BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, 
   *u = out[0]; *v = out[1];
 }
 
+// Both components from draws that lie in memory as 50 words `stride` apart (rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic
+// k = 5 comp + h): the HBM cache below, or the copy ble_step_kernel<noise> keeps in LDS for the steps of a launch.
+BLE_FN void wind_noise_from_rows(float x_m, float y_m, float pressure, int32_t elapsed_s, const uint32_t* rows, int64_t stride,
+                                 float* u, float* v) {
+  BLE_NO_CONTRACT
+  const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
+  float out[2];
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    NoiseAccumulator a;
+#pragma unroll 1
+    for (int h = 0; h < 5; ++h) {
+      const uint32_t* row = rows + (int64_t)(5 * (5 * comp + h)) * stride;
+      HarmonicDraw d;
+      d.hseed = row[0]; d.ox = u32_bits_float(row[stride]); d.oy = u32_bits_float(row[2 * stride]); d.op = u32_bits_float(row[3 * stride]);
+      d.ot = u32_bits_float(row[4 * stride]);
+      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
+    }
+    out[comp] = noise_finish(a);
+  }
+  *u = out[0]; *v = out[1];
+}
+// The draws of one environment into `dst` (50 words, `dst_stride` apart): from the HBM cache when it holds this (seed, episode)'s
+// -- redrawn and stored there otherwise -- or straight from the Philox stream when there is no cache.
+constexpr int kNoiseCacheRows = 53;
+BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint32_t episode, uint32_t* cache, int64_t n, uint32_t* dst, int64_t dst_stride) {
+  if (cache != nullptr) {
+    uint32_t* mine = cache + env;
+    const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
+    if (mine[50 * n] == k0 && mine[51 * n] == k1 && mine[52 * n] == k2) {
+#pragma unroll 1
+      for (int r = 0; r < 50; ++r) dst[r * dst_stride] = mine[(int64_t)r * n];
+      return;
+    }
+  }
+  Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
+#pragma unroll 1
+  for (int k = 0; k < 10; ++k) {
+    const HarmonicDraw d = harmonic_draw(g);
+    const uint32_t w[5] = {d.hseed, float_bits_u32(d.ox), float_bits_u32(d.oy), float_bits_u32(d.op), float_bits_u32(d.ot)};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      dst[(5 * k + q) * dst_stride] = w[q];
+      if (cache != nullptr) cache[env + (int64_t)(5 * k + q) * n] = w[q];
+    }
+  }
+  if (cache != nullptr) {
+    cache[env + 50 * n] = episode + 1u; cache[env + 51 * n] = (uint32_t)seed; cache[env + 52 * n] = (uint32_t)(seed >> 32);
+  }
+}
+
 // The same with the draws kept in HBM between calls, as the reference keeps them in its NoisyWindHarmonic objects between
 // resets: `cache` is [kNoiseCacheRows][n] 32-bit words (coalesced), rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic k
 // = 5 comp + h, rows 50 .. 52 the key (episode + 1, seed lo, seed hi) the entry was drawn for; an entry drawn for another
 // (seed, episode) -- or an all-zero, fresh one -- is redrawn and stored.  Same values as wind_noise(), bit for bit.
-constexpr int kNoiseCacheRows = 53;
 BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint32_t episode,
                               uint32_t* cache, int64_t n, float* u, float* v) {
   BLE_NO_CONTRACT
@@ -158,22 +208,7 @@ BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elap
     }
     mine[50 * n] = k0; mine[51 * n] = k1; mine[52 * n] = k2;
   }
-  const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
-  float out[2];
-#pragma unroll
-  for (int comp = 0; comp < 2; ++comp) {
-    NoiseAccumulator a;
-#pragma unroll 1
-    for (int h = 0; h < 5; ++h) {
-      const uint32_t* row = mine + (int64_t)(5 * (5 * comp + h)) * n;
-      HarmonicDraw d;
-      d.hseed = row[0]; d.ox = u32_bits_float(row[n]); d.oy = u32_bits_float(row[2 * n]); d.op = u32_bits_float(row[3 * n]);
-      d.ot = u32_bits_float(row[4 * n]);
-      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
-    }
-    out[comp] = noise_finish(a);
-  }
-  *u = out[0]; *v = out[1];
+  wind_noise_from_rows(x_m, y_m, pressure, elapsed_s, mine, n, u, v);
 }
 
 }  // namespace ble
