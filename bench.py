@@ -650,11 +650,16 @@ def main():
       size = None
       if cfg == 3 and world == 1:
         size = 8192                                      # one GPU's share of configs[3] on an 8-GPU node
-      r = make(cfg, n=size, steps=min(args.steps, 64))
+      # side legs time 64-step regions whatever --steps says (two 32-step launches on one rank): a 20-step region of a
+      # 10 us-per-step shard is 0.2 ms, of which the host's launch + synchronise is 12 %
+      r = make(cfg, n=size, steps=64)
       s = r.summary(extra_reps)
       key = f'configs[{cfg}]' + (' per-GPU shard (8 192 of 65 536), 1 GPU' if (cfg == 3 and world == 1) else '')
-      configs[key] = {k: s[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step', 'decode_ms')}
+      configs[key] = {k: s[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step', 'decode_ms',
+                                        'steps_per_repetition', 'kernel_ms_mean')}
       configs[key]['workload'] = PRESETS[cfg]
+      configs[key]['kernel'] = ('ble_step_split_kernel (one environment on four wavefronts: n <= 32 768)' if s['envs_per_gpu'] <= 32768
+                                else 'ble_step_kernel (one lane per environment)')
       del r
       torch.cuda.empty_cache()
     if rank == 0:

@@ -5,7 +5,7 @@
 # combine with sys/hip/hsa/memory-copy tracing.  Raw output goes to gpurun_out/ (scratch);
 # profiles/summarize.py turns it into the committed profiles/<tag>_*.json / .md files.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -36,4 +36,11 @@ run_obs pmc_obs2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST
 run_obs pmc_obs3 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run_obs pmc_obs_fetch FETCH_SIZE
 run_obs pmc_obs_write WRITE_SIZE
+# ---- the small-batch form of the transition (one environment on four wavefronts) against the one-lane kernel at one GPU's
+# share of configs[3]: 16 fused 32-step launches of each at 8 192 environments
+SPLIT="python $ROOT/profiles/split_launches.py 8192 16"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_split -o trace_split -- $SPLIT > $OUT/trace_split.log 2>&1
+run_split () { local name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $SPLIT > $OUT/$name.log 2>&1; }
+run_split pmc_split1 SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_INSTS_LDS
+run_split pmc_split2 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_ANY
 find $OUT -name "*.csv" | wc -l

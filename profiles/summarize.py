@@ -126,6 +126,43 @@ def main(tag):
         traffic = {}
       traffic['observe_hbm_bytes_per_launch'] = 2 * of + ow
       traffic['observe_note'] = 'FETCH_SIZE x2 (16 B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE, steady-state launch, 65 536 envs' 
+  # ---- the small-batch kernel (ble_step_split_kernel) against the one-lane kernel at 8 192 environments, 32-step launches
+  split_md = []
+  sp_trace = os.path.join(base, 'trace_split', 'trace_split_kernel_trace.csv')
+  if os.path.exists(sp_trace):
+    durs = collections.defaultdict(list)
+    with open(sp_trace) as f:
+      for r in csv.DictReader(f):
+        for key in ('ble_step_split_kernel', 'ble_step_kernel'):
+          if key in r['Kernel_Name']:
+            durs[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    sc = {k: collections.defaultdict(list) for k in ('ble_step_split_kernel', 'ble_step_kernel')}
+    for name in ('pmc_split1', 'pmc_split2'):
+      p = os.path.join(base, name, f'{name}_counter_collection.csv')
+      if os.path.exists(p):
+        with open(p) as f:
+          for r in csv.DictReader(f):
+            for key in sc:
+              if key in r['Kernel_Name']:
+                sc[key][r['Counter_Name']].append(float(r['Counter_Value']))
+    out['split'] = {}
+    split_md = ['| kernel (8 192 environments, 32 agent steps per launch) | launches | avg us per launch | us per agent step | waves | VALU / wave / step | of which fp64 | SALU / wave / step | LDS / wave / step | issue utilisation | waiting |',
+                '|---|---|---|---|---|---|---|---|---|---|---|']
+    for key in ('ble_step_split_kernel', 'ble_step_kernel'):
+      if not durs[key]:
+        continue
+      d = sorted(durs[key])[:-1] or durs[key]            # (drop the slowest: the first, cold launch)
+      a = {k: sum(v) / len(v) for k, v in sc[key].items()}
+      w = a.get('SQ_WAVES', 0) or 1
+      f64 = sum(a.get(k, 0) for k in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_TRANS_F64'))
+      e = {'launches': len(d), 'avg_us': sum(d) / len(d), 'us_per_step': sum(d) / len(d) / 32.0, 'waves': w,
+           'valu_per_wave_step': a.get('SQ_INSTS_VALU', 0) / w / 32.0, 'fp64_per_wave_step': f64 / w / 32.0,
+           'salu_per_wave_step': a.get('SQ_INSTS_SALU', 0) / w / 32.0, 'lds_per_wave_step': a.get('SQ_INSTS_LDS', 0) / w / 32.0,
+           'issue_utilisation': a.get('SQ_ACTIVE_INST_ANY', 0) / (a.get('SQ_WAVE_CYCLES', 0) or 1),
+           'wait_frac': a.get('SQ_WAIT_ANY', 0) / (a.get('SQ_WAVE_CYCLES', 0) or 1), 'pmc_per_launch': a}
+      out['split'][key] = e
+      split_md.append(f"| `{key}` | {e['launches']} | {e['avg_us']:.1f} | {e['us_per_step']:.2f} | {w:.0f} | {e['valu_per_wave_step']:.0f} | {e['fp64_per_wave_step']:.0f} | "
+                      f"{e['salu_per_wave_step']:.0f} | {e['lds_per_wave_step']:.1f} | {e['issue_utilisation']:.3f} | {e['wait_frac']:.3f} |")
   try:
     json.dump(traffic, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'))
   except NameError:
@@ -142,6 +179,9 @@ def main(tag):
       f.write('\n'.join(obs_md) + '\n\n## ble_observe_kernel PMC (steady state: last 8 launches)\n\n```json\n')
       f.write(json.dumps({k: out[k] for k in ('observe_dispatch', 'observe_pmc_per_launch_steady', 'observe_hbm') if k in out}, indent=1))
       f.write('\n```\n')
+    if split_md:
+      f.write('\n# `python profiles/split_launches.py 8192 16`: the small-batch form of the transition (one environment on four wavefronts) against the one-lane kernel\n\n')
+      f.write('\n'.join(split_md) + '\n')
   print(json.dumps(out, indent=1))
 
 
