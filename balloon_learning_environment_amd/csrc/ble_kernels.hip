@@ -176,11 +176,19 @@ __global__ __launch_bounds__(kSplitWaves * kSplitLanes) void ble_step_split_kern
   __shared__ SplitShared sh;
   uint32_t flags;
   switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {       // (scalar: one role per wave)
-    case 0: flags = split_agent_steps<0>(a, sh); break;
-    case 1: flags = split_agent_steps<1>(a, sh); break;
-    case 2: flags = split_agent_steps<2>(a, sh); break;
-    default: flags = split_agent_steps<3>(a, sh); break;
+    case 0: flags = split_agent_steps<4, 0>(a, sh); break;
+    case 1: flags = split_agent_steps<4, 1>(a, sh); break;
+    case 2: flags = split_agent_steps<4, 2>(a, sh); break;
+    default: flags = split_agent_steps<4, 3>(a, sh); break;
   }
+  report_flags(flags, a.err_flags);
+}
+// ... and on two: {vertical, thermal} | {sun + envelope, ACS + power}, 128-thread workgroups (two waves per SIMD at 65 536 environments)
+__global__ __launch_bounds__(2 * kSplitLanes) void ble_step_pair_kernel(SplitArgs a) {
+  __shared__ SplitShared sh;
+  uint32_t flags;
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) flags = split_agent_steps<2, 0>(a, sh);
+  else flags = split_agent_steps<2, 1>(a, sh);
   report_flags(flags, a.err_flags);
 }
 
@@ -546,11 +554,17 @@ inline int env_lanes() { return kBlock; }   // one environment per lane, all 64 
 // Below BLE_SPLIT_MAX_ENVS environments the one-lane kernel leaves most SIMDs idle (n / 64 waves on 1 024 SIMDs) and the
 // four-wave kernel still fits one wave per SIMD: it is the faster one (bit-identical results).  BLE_STEP_SPLIT=0 / 1 in the
 // environment forces one or the other (A/B runs and the parity test).
-inline bool use_split(int64_t n) {
+// returns the number of waves per environment: 1 (ble_step_kernel), 2 (ble_step_pair_kernel) or 4 (ble_step_split_kernel)
+inline int split_waves(int64_t n) {
   const char* e = getenv("BLE_STEP_SPLIT");
-  if (e != nullptr && (e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
-  return n <= BLE_SPLIT_MAX_ENVS;
+  if (e != nullptr && e[1] == 0) {
+    if (e[0] == '0') return 1;
+    if (e[0] == '1' || e[0] == '4') return 4;
+    if (e[0] == '2') return 2;
+  }
+  return n <= BLE_SPLIT_MAX_ENVS ? 4 : 1;
 }
+inline bool use_split(int64_t n) { return split_waves(n) != 1; }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                         const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
                         unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream);
@@ -577,7 +591,10 @@ inline int launch_split(const ble_state_f32* st, const uint8_t* action, const fl
   a.st = *st; a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
   a.reward = reward; a.terminal = terminal; a.effective_action = effective_action; a.err_flags = err_flags;
   a.active_count = active_count; a.n = n; a.substeps = substeps; a.n_steps = n_steps;
-  BLE_LAUNCH(ble_step_split_kernel, dim3(blocks(n, kSplitLanes)), dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  if (split_waves(n) == 2)
+    BLE_LAUNCH(ble_step_pair_kernel, dim3(blocks(n, kSplitLanes)), dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
+  else
+    BLE_LAUNCH(ble_step_split_kernel, dim3(blocks(n, kSplitLanes)), dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 inline bool state_ok(const ble_state_f32* st) {

@@ -100,8 +100,12 @@ struct SplitArgs {
 // One wave of a workgroup of 256 threads = 4 waves x 64 lanes; returns this thread's error flags.  `wave` is a
 // compile-time constant: every role is its own instantiation -- its own registers, its own loops -- and the four agree on
 // the number of barriers per step (two in the per-step part, one per stride) by construction.
-template <int wave>
+template <int kWaves, int wave>
 BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
+  static_assert((kWaves == 4 || kWaves == 2) && wave >= 0 && wave < kWaves, "four waves = one role each, two waves = two roles each");
+  // the roles this wave plays: 0 vertical, 1 thermal, 2 sun + envelope, 3 ACS + power (kWaves == 2: {0, 1} and {2, 3})
+  constexpr bool r0 = kWaves == 4 ? wave == 0 : wave == 0, r1 = kWaves == 4 ? wave == 1 : wave == 0;
+  constexpr bool r2 = kWaves == 4 ? wave == 2 : wave == 1, r3 = kWaves == 4 ? wave == 3 : wave == 1;
   const int lane = (int)threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * kSplitLanes + lane;
   const int64_t n = a.n;
@@ -130,7 +134,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     if (st.episode_cache != nullptr) cached = episode_cache_load(st.episode_cache, n, i);
     live = s.status == kOk;
   }
-  for (int t = (int)threadIdx.x; t < kAcsPolyDoubles; t += kSplitWaves * kSplitLanes) sh.acs_poly[t] = kAcsPoly.c[t];
+  for (int t = (int)threadIdx.x; t < kAcsPolyDoubles; t += kWaves * kSplitLanes) sh.acs_poly[t] = kAcsPoly.c[t];
   __syncthreads();
   const bool was_live = live;
   int last_act = 0;
@@ -139,7 +143,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     hc = hoisted_from_cache(cached, c);
   } else {
     hc = hoist_constants(c);
-    if (wave == 0 && live && st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
+    if (r0 && live && st.episode_cache != nullptr) episode_cache_store(st.episode_cache, n, i, c, hc);
   }
   int xk = 0;                        // exchange counter: stride parity, running across the steps
   BLE_SPLIT_T_DECL;
@@ -170,10 +174,11 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     float sun_sin = 0.0f, sun_panel = 0.0f; bool sun_day = false;        // waves 1, 3: the sun of the stride about to run
     uint32_t map_pow_env = 0; int eff = kStay;                           // wave 3
 
-    if (wave == 0) {
+    if (r0) {
       win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
       lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
-    } else if (wave == 1) {
+    }
+    if (r1) {
       e0 = ephemeris(t0);
       fl0 = e0.flux; dfl = e0.flux_rate * 10.0f;
       // what the hour-angle nodes of the step need of it (solar_nodes_time)
@@ -181,19 +186,20 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       step_flags |= hc.flags;
       // total_absorptivity's range check (thermal.py:142-145) on the balloon's own temperature, first value of the step
       step_flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
-    } else if (wave == 3) {
+    }
+    if (r3) {
       // the power and envelope layers on the pre-step state (balloon.py:304-313); both state machines move independently of
       // the action, so the three evaluations share everything but the final selects
       int32_t sr0 = s.sunrise_h, ss0 = s.sunset, sr1 = s.sunrise_h, ss1 = s.sunset, sr2 = s.sunrise_h, ss2 = s.sunset;
-      uint8_t pa0 = s.paused, pa1 = s.paused, pa2 = s.paused, e0 = s.env_fsm, e1 = s.env_fsm, e2 = s.env_fsm;
-      const int q0 = envelope_safety(power_safety(kDown, s.t_elapsed, s.batt, &sr0, &ss0, &pa0), s.sp, &e0);
-      const int q1 = envelope_safety(power_safety(kStay, s.t_elapsed, s.batt, &sr1, &ss1, &pa1), s.sp, &e1);
-      const int q2 = envelope_safety(power_safety(kUp, s.t_elapsed, s.batt, &sr2, &ss2, &pa2), s.sp, &e2);
-      if (live) { s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = e0; }
+      uint8_t pa0 = s.paused, pa1 = s.paused, pa2 = s.paused, f0 = s.env_fsm, f1 = s.env_fsm, f2 = s.env_fsm;
+      const int q0 = envelope_safety(power_safety(kDown, s.t_elapsed, s.batt, &sr0, &ss0, &pa0), s.sp, &f0);
+      const int q1 = envelope_safety(power_safety(kStay, s.t_elapsed, s.batt, &sr1, &ss1, &pa1), s.sp, &f1);
+      const int q2 = envelope_safety(power_safety(kUp, s.t_elapsed, s.batt, &sr2, &ss2, &pa2), s.sp, &f2);
+      if (live) { s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = f0; }
       map_pow_env = action_map(q0, q1, q2);
     }
-    // wave 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275): WindField.get_ground_truth = forecast + noise
-    if (wave == 2) {
+    // role 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275): WindField.get_ground_truth = forecast + noise
+    if (r2) {
       const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
       WindCorners corners;
       wind_gather(a.wind_grid + (in_range ? i : 0) * a.grid_env_stride, wq, &corners);
@@ -206,37 +212,38 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     BLE_SPLIT_T(0);
     __syncthreads();                                   // ---- barrier 1: the ephemeris and the wind are there
     BLE_SPLIT_T(1);
-    if (wave == 0) {
+    if (!r2) { u = sh.u[lane]; v = sh.v[lane]; }
+    if (!r1) { e0.eot_min = sh.eot_min[lane]; e0.eot_min_rate = sh.eph[0][lane]; e0.sin_decl = sh.eph[1][lane]; e0.sin_decl_rate = sh.eph[2][lane]; }
+    if (r0) {
       double altitude;
       atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
       uint8_t f0 = s.alt_fsm, f1 = s.alt_fsm, f2 = s.alt_fsm;
-      const int r0 = altitude_safety(kDown, altitude, &f0), r1 = altitude_safety(kStay, altitude, &f1),
-                r2 = altitude_safety(kUp, altitude, &f2);
+      const int q0 = altitude_safety(kDown, altitude, &f0), q1 = altitude_safety(kStay, altitude, &f1),
+                q2 = altitude_safety(kUp, altitude, &f2);
       if (live) s.alt_fsm = f0;                         // (the state machine moves independently of the action)
-      sh.map_alt[lane] = action_map(r0, r1, r2);
-      u = sh.u[lane]; v = sh.v[lane];
-    } else {
-      // the three solar nodes of the step, one per wave (wave 2 has the wind in registers, wave 1 the ephemeris); each wave
-      // forms the time-only half itself -- the same function of the same four numbers -- and uses its own node of it
-      if (wave != 2) { u = sh.u[lane]; v = sh.v[lane]; }
-      if (wave != 1) { e0.eot_min = sh.eot_min[lane]; e0.eot_min_rate = sh.eph[0][lane]; e0.sin_decl = sh.eph[1][lane]; e0.sin_decl_rate = sh.eph[2][lane]; }
+      sh.map_alt[lane] = action_map(q0, q1, q2);
+    }
+    if (r1 || r2 || r3) {
+      // the three solar nodes of the step, one per role (role 2 has the wind in registers, role 1 the ephemeris); each wave
+      // forms the time-only half itself -- the same function of the same four numbers -- and uses its own nodes of it
       const SolarNodes nd = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
-      if (wave == 1) sh.node_f[0][lane] = solar_node<1>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
-      if (wave == 3) sh.node_f[1][lane] = solar_node<2>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
-      if (wave == 2) {
+      if (r1) sh.node_f[0][lane] = solar_node<1>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
+      if (r3) sh.node_f[1][lane] = solar_node<2>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
+      if (r2) {
         node_f0 = solar_node<0>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
         // the sun of stride 0 needs the first node alone: the quadratic at index 0 is its constant term (the other two
         // coefficients are finite), so it is ready at the same barrier as the nodes
         const SunState sun0 = sun_at_stride(0, (float)node_f0, 0.0f, 0.0f, c, u, v, x_start, y_start, t_start);
-        sh.sin_el0[lane] = sun0.sin_el; sh.panel0[lane] = solar_panel_factor(sun0); sh.day0[lane] = sun0.day ? 1u : 0u;
+        sun_sin = sun0.sin_el; sun_panel = solar_panel_factor(sun0); sun_day = sun0.day;
+        sh.sin_el0[lane] = sun_sin; sh.panel0[lane] = sun_panel; sh.day0[lane] = sun_day ? 1u : 0u;
       }
     }
     BLE_SPLIT_T(0);
     __syncthreads();                                   // ---- barrier 2: the nodes, the sun of stride 0, the altitude layer's map
     BLE_SPLIT_T(1);
-    if (wave == 2) solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps, &oms_c0, &oms_c1, &oms_c2);
-    if (wave == 1 || wave == 3) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
-    if (wave == 3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
+    if (r2) solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps, &oms_c0, &oms_c1, &oms_c2);
+    if ((r1 || r3) && !r2) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
+    if (r3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
     if (live) flags |= step_flags;
 
     // ================================================================ the strides
@@ -249,43 +256,47 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       // who publishes: a running episode, and the shadow of one that was over on entry (nobody reads ITS finals, and its own
       // reads must find finite numbers); a lane that ended in this step keeps its slots -- they hold its final state
       const bool publish = active || !live;
-      if (wave == 0) {
-        const double rp = d_rcp(p);
+      // every right-hand side reads the state of stride k (balloon.py:322-325): new values into *_n, committed after the barrier
+      double p_n = p, t_amb_n = t_amb, t_at_p_n = t_at_p, t_int_n = t_int, vol_n = vol, sp_n = sp, n_air_n = n_air;
+      float x_n = x, y_n = y, batt_n = batt, sun_sin_n = sun_sin, sun_panel_n = sun_panel; bool sun_day_n = sun_day;
+      const double rp = d_rcp(p);
+      if (r0) {
         const double yc = inv_cbrt_volume(vol);
-        const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
-        x = f_fma(u, kStride, x); y = f_fma(v, kStride, y);            // step 1 (balloon.py:394-395)
-        t_amb = t_at_p;                                                 // ambient_temperature' = T(p_old)  (balloon.py:457)
-        t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new);
-        p = p_new;
-        if (publish) { sh.p[wr][lane] = p; sh.t_amb[wr][lane] = t_amb; sh.x[wr][lane] = x; sh.y[wr][lane] = y; }
-      } else if (wave == 1) {
+        p_n = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
+        x_n = f_fma(u, kStride, x); y_n = f_fma(v, kStride, y);        // step 1 (balloon.py:394-395)
+        t_amb_n = t_at_p;                                               // ambient_temperature' = T(p_old)  (balloon.py:457)
+        t_at_p_n = stride_ambient_advance(win, lc, p, rp, t_at_p, p_n);
+        if (publish) { sh.p[wr][lane] = p_n; sh.t_amb[wr][lane] = t_amb_n; sh.x[wr][lane] = x_n; sh.y[wr][lane] = y_n; }
+      }
+      if (r1) {
         const float flux = f_fma((float)k, dfl, fl0);
         const double yc = inv_cbrt_volume(vol);
         const float att = solar_attenuation(sun_sin, (float)p, sun_day);
-        t_int = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth);
-        if (publish) sh.t_int[wr][lane] = t_int;
-      } else if (wave == 2) {
+        t_int_n = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth);
+        if (publish) sh.t_int[wr][lane] = t_int_n;
+      }
+      if (r2) {
         const SunState sn = sun_at_stride(k + 1, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
-        const float pf = solar_panel_factor(sn);
+        sun_sin_n = sn.sin_el; sun_panel_n = solar_panel_factor(sn); sun_day_n = sn.day;
         // step 4: superpressure and volume (balloon.py:470-482): burst above 2 380 Pa, zero pressure at <= 0 (the later check overrides)
-        superpressure_volume_f64(n_air, t_int, p, d_rcp(p), &vol, &sp);
-        const uint32_t code = sp <= 0.0 ? (uint32_t)kZeroPressure : (!(sp <= 2380.0) ? (uint32_t)kBurst : 0u);
+        superpressure_volume_f64(n_air, t_int, p, rp, &vol_n, &sp_n);
+        const uint32_t code = sp_n <= 0.0 ? (uint32_t)kZeroPressure : (!(sp_n <= 2380.0) ? (uint32_t)kBurst : 0u);
         if (publish) {
-          sh.sin_el[wr][lane] = sn.sin_el; sh.panel[wr][lane] = pf; sh.day[wr][lane] = sn.day ? 1u : 0u;
-          sh.vol[wr][lane] = vol; sh.sp[wr][lane] = sp; sh.code_sp[wr][lane] = code;
+          sh.sin_el[wr][lane] = sun_sin_n; sh.panel[wr][lane] = sun_panel_n; sh.day[wr][lane] = sun_day_n ? 1u : 0u;
+          sh.vol[wr][lane] = vol_n; sh.sp[wr][lane] = sp_n; sh.code_sp[wr][lane] = code;
         }
-      } else {
-        const double rp = d_rcp(p);
+      }
+      if (r3) {
         const float att = solar_attenuation(sun_sin, (float)p, sun_day);
         double mdot_d;
         stride_acs(sh.acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
         mdot = (float)mdot_d;
-        n_air = stride_mols_air(n_air, mdot_d);
-        stride_power_from_factor(sun_day, sun_panel, att, acs_w, &charge, &load, &batt);
+        n_air_n = stride_mols_air(n_air, mdot_d);
+        stride_power_from_factor(sun_day, sun_panel, att, acs_w, &charge, &load, &batt_n);
         if (publish) {
-          sh.n_air[wr][lane] = n_air; sh.batt[wr][lane] = batt; sh.acs_w[wr][lane] = acs_w; sh.mdot[wr][lane] = mdot;
+          sh.n_air[wr][lane] = n_air_n; sh.batt[wr][lane] = batt_n; sh.acs_w[wr][lane] = acs_w; sh.mdot[wr][lane] = mdot;
           sh.charge[wr][lane] = charge; sh.load[wr][lane] = load;
-          sh.code_batt[wr][lane] = batt <= 0.0f ? (uint32_t)kOutOfPower : 0u;         // balloon.py:541-542
+          sh.code_batt[wr][lane] = batt_n <= 0.0f ? (uint32_t)kOutOfPower : 0u;         // balloon.py:541-542
         }
       }
       BLE_SPLIT_T(2);
@@ -293,10 +304,14 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       BLE_SPLIT_T(3);
       ++xk;
       const int rd = xk & 1;
-      if (wave == 0) { vol = sh.vol[rd][lane]; n_air = sh.n_air[rd][lane]; }
-      else if (wave == 1) { p = sh.p[rd][lane]; t_amb = sh.t_amb[rd][lane]; vol = sh.vol[rd][lane]; sun_sin = sh.sin_el[rd][lane]; sun_day = sh.day[rd][lane] != 0u; }
-      else if (wave == 2) { p = sh.p[rd][lane]; t_int = sh.t_int[rd][lane]; n_air = sh.n_air[rd][lane]; }
-      else { p = sh.p[rd][lane]; t_int = sh.t_int[rd][lane]; sp = sh.sp[rd][lane]; sun_sin = sh.sin_el[rd][lane]; sun_panel = sh.panel[rd][lane]; sun_day = sh.day[rd][lane] != 0u; }
+      // commit: what this wave advanced from its registers, what it needs of the others from LDS
+      if (r0) { p = p_n; t_amb = t_amb_n; t_at_p = t_at_p_n; x = x_n; y = y_n; } else if (r1 || r2 || r3) { p = sh.p[rd][lane]; }
+      if (r1 && !r0) t_amb = sh.t_amb[rd][lane];
+      if (r1) t_int = t_int_n; else if (r2 || r3) t_int = sh.t_int[rd][lane];
+      if (r2) { vol = vol_n; sp = sp_n; } else { if (r0 || r1) vol = sh.vol[rd][lane]; if (r3) sp = sh.sp[rd][lane]; }
+      if (r3) { n_air = n_air_n; batt = batt_n; } else if (r0 || r2) n_air = sh.n_air[rd][lane];
+      if (r2) { sun_sin = sun_sin_n; sun_panel = sun_panel_n; sun_day = sun_day_n; }
+      else if (r1 || r3) { sun_sin = sh.sin_el[rd][lane]; sun_day = sh.day[rd][lane] != 0u; if (r3) sun_panel = sh.panel[rd][lane]; }
       // later checks override earlier ones (balloon.py:479-482, 541-542): burst, zero pressure, out of power
       const uint32_t cb = sh.code_batt[rd][lane], cs = sh.code_sp[rd][lane];
       const int code = (int)(cb != 0u ? cb : cs);
@@ -314,8 +329,8 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       s.batt = sh.batt[rd][lane]; s.x = sh.x[rd][lane]; s.y = sh.y[rd][lane];
       s.t_elapsed += 10 * k_done;
       s.status = (uint8_t)status;
-      if (wave == 1) flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
-      if (wave == 2) {
+      if (r1) flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
+      if (r2) {
         s.acs_power = sh.acs_w[rd][lane];
         // solar_atmospheric_attenuation's range check (solar.py:194-197); p moves < 3 kPa per step
         flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
@@ -337,16 +352,16 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         a.reward[o] = r;
         a.terminal[o] = s.status != kOk;
       }
-      if (wave == 3) {
+      if (r3) {
         s.acs_power = sh.acs_w[rd][lane]; s.mdot = sh.mdot[rd][lane]; s.charge = sh.charge[rd][lane]; s.load = sh.load[rd][lane];
         if (a.effective_action) a.effective_action[o] = (uint8_t)eff;
       }
     } else if (in_range) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
-      if (wave == 2) { a.reward[o] = 0.0f; a.terminal[o] = 1; }
-      if (wave == 3 && a.effective_action) a.effective_action[o] = a.action[o];
+      if (r2) { a.reward[o] = 0.0f; a.terminal[o] = 1; }
+      if (r3 && a.effective_action) a.effective_action[o] = a.action[o];
     }
 #ifndef BLE_SPLIT_TIMING
-    if (wave == 0 && a.active_count) {
+    if (r0 && a.active_count) {
       const unsigned long long m = __ballot(live);
       if (lane == 0 && m)
         atomicAdd(a.active_count + (int64_t)step * BLE_COUNT_SLOTS + (blockIdx.x & (BLE_COUNT_SLOTS - 1)), (unsigned long long)__popcll(m));
@@ -357,14 +372,13 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
   }
 
   if (was_live) {
-    if (wave == 0) {
+    if (r0) {
       st.x[i] = s.x; st.y[i] = s.y; st.pressure[i] = s.p; st.ambient_temperature[i] = s.t_amb;
       st.time_elapsed_s[i] = s.t_elapsed; st.alt_fsm[i] = s.alt_fsm;
-    } else if (wave == 1) {
-      st.internal_temperature[i] = s.t_int; st.status[i] = s.status; st.last_command[i] = (uint8_t)last_act;
-    } else if (wave == 2) {
-      st.battery_charge[i] = s.batt; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp; st.mols_air[i] = s.n_air;
-    } else {
+    }
+    if (r1) { st.internal_temperature[i] = s.t_int; st.status[i] = s.status; st.last_command[i] = (uint8_t)last_act; }
+    if (r2) { st.battery_charge[i] = s.batt; st.envelope_volume[i] = s.vol; st.superpressure[i] = s.sp; st.mols_air[i] = s.n_air; }
+    if (r3) {
       st.acs_power[i] = s.acs_power; st.acs_mass_flow[i] = s.mdot; st.solar_charging[i] = s.charge; st.power_load[i] = s.load;
       st.sunrise_h_rel[i] = s.sunrise_h; st.sunset_rel[i] = s.sunset; st.env_fsm[i] = s.env_fsm; st.power_paused[i] = s.paused;
     }

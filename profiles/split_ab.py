@@ -12,13 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from balloon_learning_environment_amd import reset_host, vec_state  # noqa: E402
 
+modes = os.environ.get('SPLIT_AB_MODES', '0,4').split(',')       # BLE_STEP_SPLIT values: 0 one lane, 2 / 4 wavefronts per environment
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384, 32768]
 field = (np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).astype(np.float32)
 for n in sizes:
   init = reset_host.sample_initial_state(n, seed=1000)
   acts = torch.randint(0, 3, (64, n), dtype=torch.uint8, device='cuda')
   rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
-  for split in ('0', '1'):
+  for split in modes:
     os.environ['BLE_STEP_SPLIT'] = split
     sim = vec_state.VecSimulator(n); sim.set_grid(field)
     res = {}

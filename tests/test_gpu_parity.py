@@ -830,8 +830,9 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
   assert np.median(moved) > 100.0                   # ~1 m/s of noise over 18 minutes
 
 
+@pytest.mark.parametrize('waves', ['4', '2'])
 @pytest.mark.parametrize('wide', [False, True])
-def test_split_kernel_equals_one_lane_kernel(ble, wide):
+def test_split_kernel_equals_one_lane_kernel(ble, wide, waves):
   """The small-batch form of the transition -- one environment on FOUR wavefronts (csrc/ble_step_split.h: vertical dynamics |
   thermal model | sun + power | envelope + ACS, exchanging through LDS once per stride), which ble_step_f32 / ble_step_n_f32
   select up to BLE_SPLIT_MAX_ENVS environments -- against the one-lane-per-environment kernel, forced with BLE_STEP_SPLIT:
@@ -853,7 +854,7 @@ def test_split_kernel_equals_one_lane_kernel(ble, wide):
   noise = torch.from_numpy((np.random.default_rng(4).standard_normal((n, 2)) * 1.5).astype(np.float32)).cuda()
 
   def fly(split):
-    os.environ['BLE_STEP_SPLIT'] = '1' if split else '0'
+    os.environ['BLE_STEP_SPLIT'] = waves if split else '0'      # 4 / 2 wavefronts per environment (csrc/ble_step_split.h) against 1
     try:
       sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(field)
       rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
