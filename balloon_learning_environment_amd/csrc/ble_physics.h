@@ -512,17 +512,24 @@ BLE_FN int power_safety(int action, int32_t now, float battery_wh, int32_t* sunr
   *sunrise_h = sr; *sunset = ss;
   const int paused_action = (action == kDown) ? kStay : action;
   const double batt = battery_wh, cap = capacity_wh;   // (the transition's constants unless the probe says otherwise)
+  // With the vehicle's own capacity (every call site of the transition: this folds at compile time) the two state-of-charge
+  // tests are thresholds on the NUMERATOR: a correctly rounded division is monotone in it, so x / 3058.56 < 0.05 <=> x < the
+  // smallest float32 whose quotient reaches 0.05 (152.92801 = 0x1.31db24p+7), and d / 3058.56 < 0.025 <=> d < the smallest
+  // double whose quotient reaches 0.025 (76.464 = 0x1.31db22d0e5604p+6).  The same decisions (tests/test_kernel_numerics_host.py)
+  // without two ~30-instruction fp64 divisions per agent step.
+  const bool own_capacity = capacity_wh == 3058.56;
   if (ss < sr) {  // daytime
-    double soc = batt / cap;
-    if (*paused && soc < 0.05) return paused_action;
+    const bool low = own_capacity ? battery_wh < 152.92801f : batt / cap < 0.05;
+    if (*paused && low) return paused_action;
     *paused = 0;
     return action;
   }
   if (*paused) return paused_action;
   double hours = (double)(sr - now) / 3600.0;
   double floating_charge = night_load_w * hours;
-  double expected = (batt - floating_charge) / cap;
-  if (expected < 0.025) { *paused = 1; return paused_action; }
+  const double left = batt - floating_charge;
+  const bool short_of = own_capacity ? left < 0x1.31db22d0e5604p+6 : left / cap < 0.025;
+  if (short_of) { *paused = 1; return paused_action; }
   return action;
 }
 

@@ -286,3 +286,32 @@ def test_battery_excess_threshold_is_the_reference_division():
   rng = np.random.default_rng(0)
   b = rng.uniform(3020.0, 3035.0, 200000).astype(np.float32)
   assert np.array_equal(b.astype(np.float64) / 3058.56 > 0.99, b >= thr)
+
+
+def test_power_safety_thresholds_are_the_reference_divisions():
+  """PowerSafetyLayer (power_safety.py:94-115) tests battery_charge / battery_capacity < 0.05 and
+  (battery_charge - floating_charge) / battery_capacity < 0.025 in float64; the kernels compare the numerators with
+  152.92801f and 76.464 (csrc/ble_physics.h::power_safety) when the capacity is the vehicle's 3058.56 Wh.  Monotonicity of the
+  correctly rounded division makes that exact iff it holds at the thresholds and their neighbours."""
+  cap = 3058.56
+  t1 = np.float32(152.92801)
+  assert float(t1).hex() == '0x1.31db240000000p+7'
+  b = np.float32(t1)
+  for _ in range(6):
+    b = np.nextafter(b, np.float32(-np.inf))
+  for _ in range(12):
+    assert (np.float64(b) / cap < 0.05) == bool(b < t1), b
+    b = np.nextafter(b, np.float32(np.inf))
+  t2 = float.fromhex('0x1.31db22d0e5604p+6')
+  assert t2 == 76.464
+  d = t2
+  for _ in range(6):
+    d = np.nextafter(d, -np.inf)
+  for _ in range(12):
+    assert (d / cap < 0.025) == bool(d < t2), d
+    d = np.nextafter(d, np.inf)
+  rng = np.random.default_rng(1)
+  x = rng.uniform(152.0, 154.0, 200000).astype(np.float32)
+  assert np.array_equal(x.astype(np.float64) / cap < 0.05, x < t1)
+  y = rng.uniform(76.0, 77.0, 200000)
+  assert np.array_equal(y / cap < 0.025, y < t2)
