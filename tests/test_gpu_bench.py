@@ -52,6 +52,32 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks_and_gathers_the_partia
   assert out1['config']['exchanges']['gathers_per_timed_region'] == 1 and out1['config']['exchanges']['agent_step_rows_gathered_per_timed_region'] == 20
 
 
+def test_bench_gpus_2_default_legs_run_sharded():
+  """What the driver's N > 1 command runs beyond the headline (no --no-extras): the ground-truth-wind leg, the observation
+  leg with its three consumers of the observation blocks (gather to the learner rank, all_to_all for a data-parallel
+  learner, rank-local), and the configs[3] / configs[4] legs -- two ranks on the box's one GPU over gloo, a small headline
+  batch so that the test stays short."""
+  out = _bench(['--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '3', '--observe', '2', '--envs-per-gpu', '2048'],
+               {'BLE_DIST_BACKEND': 'gloo'}, timeout=900)
+  assert out['n_gpus'] == 2 and out['config']['envs_per_gpu'] == 2048 and out['config']['global_envs'] == 4096
+  gt = out['config']['ground_truth_wind']
+  assert gt is not None and gt['env_steps_per_s'] > 1e4 and gt['global_envs'] == 4096     # (gloo moves the gathers through the host)
+  assert out['roofline']['traffic'] is None and 'N > 1' in out['roofline']['traffic_note']
+  modes = out['observe']['exchange_modes']
+  assert set(modes) == {'gather', 'all_to_all', 'local'}
+  block = 2048 * 1099 * 4
+  assert modes['gather']['bytes_per_link'] == block and modes['gather']['ms_per_step_plus_observation'] > 0
+  assert modes['all_to_all']['bytes_per_link'] == block // 2 and modes['local']['bytes_per_link'] == 0
+  assert modes['local'].get('ms_per_step_plus_observation', 0) > 0          # no exchange: cannot fail on any backend
+  assert 'ms_per_step_plus_observation' in modes['all_to_all'] or 'error' in modes['all_to_all']
+  keys = ' '.join(out['configs'])
+  assert 'configs[3]' in keys and 'configs[4]' in keys
+  for k, v in out['configs'].items():
+    if k.startswith('configs[3]') or k.startswith('configs[4]'):
+      assert v['env_steps_per_s'] > 1e5, k
+  assert 'cpu_baseline' not in out                                            # rank 0 at N = 1 only
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
   env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras'],
