@@ -7,11 +7,12 @@
 // (balloon.py:322-325 commits afterwards), so the groups of state variables are independent inside a stride.  Here a
 // workgroup is 4 waves = the 4 SIMDs of a CU, lane l of EVERY wave is environment 64 b + l, and each wave advances one group:
 //
-//   wave 0  vertical dynamics: p, T(p), ambient temperature, position           (stride_pressure, stride_ambient_advance)
+//   wave 0  vertical dynamics: p, T(p), ambient temperature, position           (stride_pressure, stride_ambient_advance);
+//           per step: atmosphere window, altitude layer, the previous step's reward
 //   wave 1  thermal model: internal temperature                                 (stride_internal_temperature)
 //   wave 2  the sun, one stride AHEAD (it depends on the stride index only): sin el, panel factor, day -- the rare exact
 //           solar chain runs here, off everybody's critical path -- and the envelope: volume, superpressure
-//           (superpressure_volume_f64); per step: wind lookup, solar nodes, reward
+//           (superpressure_volume_f64); per step: wind lookup, first solar node, the sun of stride 0
 //   wave 3  ACS + power: mols of air, battery                                   (stride_acs, stride_power_from_factor)
 //
 // After every stride the waves publish what they own in LDS (double-buffered by stride parity), meet at ONE workgroup
@@ -174,10 +175,6 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     float sun_sin = 0.0f, sun_panel = 0.0f; bool sun_day = false;        // waves 1, 3: the sun of the stride about to run
     uint32_t map_pow_env = 0; int eff = kStay;                           // wave 3
 
-    if (r0) {
-      win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
-      lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
-    }
     if (r1) {
       e0 = ephemeris(t0);
       fl0 = e0.flux; dfl = e0.flux_rate * 10.0f;
@@ -215,6 +212,9 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     if (!r2) { u = sh.u[lane]; v = sh.v[lane]; }
     if (!r1) { e0.eot_min = sh.eot_min[lane]; e0.eot_min_rate = sh.eph[0][lane]; e0.sin_decl = sh.eph[1][lane]; e0.sin_decl_rate = sh.eph[2][lane]; }
     if (r0) {
+      // (after barrier 1: this wave came to it with the previous step's reward, and what gates barrier 2 is wave 2's node)
+      win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
+      lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
       double altitude;
       atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
       uint8_t f0 = s.alt_fsm, f1 = s.alt_fsm, f2 = s.alt_fsm;
@@ -330,11 +330,11 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       s.t_elapsed += 10 * k_done;
       s.status = (uint8_t)status;
       if (r1) flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;
-      if (r2) {
+      if (r0) {       // (the vertical wave: its per-step part is the lightest)
         s.acs_power = sh.acs_w[rd][lane];
         // solar_atmospheric_attenuation's range check (solar.py:194-197); p moves < 3 kPa per step
         flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
-        // the sun at the end of the step = what this wave published at the lane's last stride: sun_at_stride(k_done); the reward
+        // the sun at the end of the step = what the sun wave published at the lane's last stride: sun_at_stride(k_done); the reward
         // needs sin el and day (attenuation) and the panel factor (solar_power == solar_power_from_factor o solar_panel_factor)
         SunState sun_end = {};
         sun_end.sin_el = sh.sin_el[rd][lane]; sun_end.day = sh.day[rd][lane] != 0u;
@@ -357,7 +357,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         if (a.effective_action) a.effective_action[o] = (uint8_t)eff;
       }
     } else if (in_range) {  // balloon.py:288-290 raises; a vectorised env freezes the lane instead
-      if (r2) { a.reward[o] = 0.0f; a.terminal[o] = 1; }
+      if (r0) { a.reward[o] = 0.0f; a.terminal[o] = 1; }
       if (r3 && a.effective_action) a.effective_action[o] = a.action[o];
     }
 #ifndef BLE_SPLIT_TIMING
