@@ -783,8 +783,11 @@ BLE_FN SunSC sun_from_one_minus_sin(float oms) {
 
 // Atmospheric refraction (solar.py:141-157) applied as a small rotation of (S, C).
 // Branch-free: the three formulas are evaluated and selected (they share 1/S).
-BLE_FN SunSC sun_refract(SunSC unc) {
-  const float kSin85 = 0.99619472027f, kSin5 = 0.08715574443f, kSinM0575 = -0.01003547478f;
+// `above5`: the uncorrected elevation is above the 5 deg branch point of the reference's formula (solar.py:143-155) -- the one
+// branch point where the two formulas differ by more than their own precision (1.8 arcsec), so the transition decides it on
+// its accurate distance (sun_fast) instead of the fp32 sine
+BLE_FN SunSC sun_refract(SunSC unc, bool above5) {
+  const float kSin85 = 0.99619472027f, kSinM0575 = -0.01003547478f;
   const float s = unc.sin_el, c = unc.cos_el;
   const float ct = c * f_rcp(s), ct2 = ct * ct;                       // 1/tan(el); only used when |s| > 0.01
   const float r_mid = ct * f_fma(ct2, f_fma(ct2, 0.000086f, -0.07f), 58.1f);
@@ -793,7 +796,7 @@ BLE_FN SunSC sun_refract(SunSC unc) {
   const float e = kRadToDeg * s * f_fma(s2, f_fma(s2, f_fma(s2, 15.0f / 336.0f, 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
   const float r_low = f_fma(e, f_fma(e, f_fma(e, f_fma(e, 0.711f, -12.79f), 103.4f), -518.2f), 1735.0f);
   float refr = s > kSinM0575 ? r_low : r_neg;                          // arcseconds
-  refr = s > kSin5 ? r_mid : refr;
+  refr = above5 ? r_mid : refr;
   refr = s > kSin85 ? 0.0f : refr;
   const float dl = refr * (kDegToRad / 3600.0f);
   const float d2 = dl * dl;
@@ -804,6 +807,7 @@ BLE_FN SunSC sun_refract(SunSC unc) {
   r.cos_el = f_fma(c, cd, -s * sd);
   return r;
 }
+BLE_FN SunSC sun_refract(SunSC unc) { return sun_refract(unc, unc.sin_el > 0.08715574443f); }      // sin(5 deg)
 
 // ---------------------------------------------------------------- fp64 asin (fdlibm e_asin.c rational form)
 BLE_FN double d_asin(double x) {
@@ -944,18 +948,39 @@ constexpr float kSinMinSolarEl = -0.07396924496f;  // sin(-4.242 deg), solar.py:
 constexpr float kSinShadow33 = 0.61205375195f;   // sin(37.738149 deg): panels 3.3 m below the envelope
 constexpr float kSinShadow27 = 0.56489306688f;   // sin(34.394865 deg): panels 2.7 m below
 constexpr float kSin5 = 0.08715574443f;
-constexpr float kSunBand = 1.0e-6f;
 struct SunState { float sin_el, cos_el; bool day, sh33, sh27; };
-BLE_FN SunState sun_fast(float oms, bool* near) {
+// Round 4: the four decisions are made on DISTANCES in w = 1 - sin(uncorrected elevation), the quantity the step interpolates.
+// The refraction-corrected elevation is a monotone function of the uncorrected one, so "el_corrected > -4.242 deg" is
+// "w < kOmsDay" with kOmsDay the (fp64, solved offline from solar.py:141-157) w of the uncorrected elevation whose corrected
+// value is the threshold -- likewise the two shadow elevations; the 5 deg branch point is on the uncorrected elevation itself.
+// A step carries d_j = (float)(w(0) - threshold_j), the difference taken in fp64 BEFORE rounding, and a stride adds the
+// quadratic's increment q(k) = k (c2 k + c1): near a threshold both are small, the sum is exact (Sterbenz) and its error is
+// the increment's own rounding, ~2e-9 -- against the 1.7e-7 of comparing an fp32 sin(el) that is O(1).  What is left is the
+// quadratic interpolation itself (<= 1.8e-8, see sun_one_minus_sin_f64), so the band inside which a stride is re-decided on the
+// reference's fp64 chain (sun_exact) shrinks from 1e-6 to 6e-8: 17x fewer of the 1 200-instruction cold chains (they were the
+// tail of every one-step launch, r03_step_launch.md), and decisions that no longer depend on an fp32 rounding.
+constexpr double kOmsDay = 1.0752991363576547;        // uncorrected -4.318410158082298 deg -> corrected -4.242 deg (solar.py:38)
+constexpr double kOmsShadow33 = 0.38823376985560987;  // uncorrected 37.71732276171744 deg -> corrected 37.738149050524044 deg
+constexpr double kOmsShadow27 = 0.4354459419249166;   // uncorrected 34.371330036126224 deg -> corrected 34.39486500086289 deg
+constexpr double kOmsRefr5 = 0.9128442572523419;      // 1 - sin(5 deg)
+constexpr float kSunBand = 6.0e-8f;
+struct SunThresholds { float d_day, d_s33, d_s27, d_r5; };
+BLE_FN SunThresholds sun_thresholds(double w0) {      // w0 = 1 - sin(uncorrected elevation) at the first node of the step, fp64
+  SunThresholds t;
+  t.d_day = (float)(w0 - kOmsDay); t.d_s33 = (float)(w0 - kOmsShadow33); t.d_s27 = (float)(w0 - kOmsShadow27); t.d_r5 = (float)(w0 - kOmsRefr5);
+  return t;
+}
+// oms = c0 + q: the interpolated 1 - sin(uncorrected elevation) of the stride, q its increment over the step's first node
+BLE_FN SunState sun_fast(float oms, float q, const SunThresholds& t, bool* near) {
   const SunSC unc = sun_from_one_minus_sin(oms);
-  const SunSC cor = sun_refract(unc);
+  const float d_day = t.d_day + q, d_s33 = t.d_s33 + q, d_s27 = t.d_s27 + q, d_r5 = t.d_r5 + q;
+  const SunSC cor = sun_refract(unc, d_r5 < 0.0f);
   SunState r;
   r.sin_el = cor.sin_el; r.cos_el = cor.cos_el;
-  r.day = cor.sin_el > kSinMinSolarEl;
-  r.sh33 = cor.sin_el >= kSinShadow33;
-  r.sh27 = cor.sin_el >= kSinShadow27;
-  *near = f_min(f_min(fabsf(cor.sin_el - kSinMinSolarEl), fabsf(cor.sin_el - kSinShadow33)),
-                f_min(fabsf(cor.sin_el - kSinShadow27), fabsf(unc.sin_el - kSin5))) < kSunBand;
+  r.day = d_day < 0.0f;          // el > -4.242  (sun_exact's comparisons, mapped)
+  r.sh33 = d_s33 <= 0.0f;        // el >= 37.738...
+  r.sh27 = d_s27 <= 0.0f;        // el >= 34.394...
+  *near = f_min(f_min(fabsf(d_day), fabsf(d_s33)), f_min(fabsf(d_s27), fabsf(d_r5))) < kSunBand;
   return r;
 }
 // solar.solar_calculator on BalloonState.latlng in fp64 (the oracle's chain op for op), cold.

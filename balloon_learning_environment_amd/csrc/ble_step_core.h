@@ -214,27 +214,31 @@ BLE_FN double solar_node(const SolarNodes& n, double sl0, double cl0, float x_m,
   if (j == 1) return sun_one_minus_sin_f64(sl0, cl0, x0 + dx, y0 + dy, n.sb1, n.cb1, n.sd0 + n.hsd, n.cd0 + n.hcd);
   return sun_one_minus_sin_f64(sl0, cl0, x0 + 2.0 * dx, y0 + 2.0 * dy, n.sb2, n.cb2, n.sd0 + 2.0 * n.hsd, n.cd0 + 2.0 * n.hcd);
 }
-// the quadratic through the three nodes, in the stride index
-BLE_FN void solar_node_coefs(double f0, double f1, double f2, int substeps, float* oms_c0, float* oms_c1, float* oms_c2) {
+// the quadratic through the three nodes, in the stride index, and the first node's distances to the solar thresholds
+struct SunQuadratic { float c0, c1, c2; SunThresholds thr; };
+BLE_FN SunQuadratic solar_node_coefs(double f0, double f1, double f2, int substeps) {
   const double m = 0.5 * (double)substeps;
-  *oms_c0 = (float)f0;
-  *oms_c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
-  *oms_c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+  SunQuadratic sq;
+  sq.c0 = (float)f0;
+  sq.c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
+  sq.c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+  sq.thr = sun_thresholds(f0);
+  return sq;
 }
-BLE_FN void solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps,
-                             float* oms_c0, float* oms_c1, float* oms_c2) {
+BLE_FN SunQuadratic solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps) {
   const double f0 = solar_node<0>(n, sl0, cl0, x_m, y_m, u, v, substeps);
   const double f1 = solar_node<1>(n, sl0, cl0, x_m, y_m, u, v, substeps);
   const double f2 = solar_node<2>(n, sl0, cl0, x_m, y_m, u, v, substeps);
-  solar_node_coefs(f0, f1, f2, substeps, oms_c0, oms_c1, oms_c2);
+  return solar_node_coefs(f0, f1, f2, substeps);
 }
 // Sun at stride kk of a step: the quadratic through the three fp64 nodes, fp32; the reference's own fp64 chain on the (rare)
 // strides where a solar threshold is within the fp32 floor.  (x_start, y_start, t_start: position and time at the START of the step.)
-BLE_FN SunState sun_at_stride(int kk, float oms_c0, float oms_c1, float oms_c2, const EnvConst& c, float u, float v, float x_start,
+BLE_FN SunState sun_at_stride(int kk, const SunQuadratic& sq, const EnvConst& c, float u, float v, float x_start,
                               float y_start, int32_t t_start) {
   const float fkk = (float)kk;
   bool near;
-  SunState r = sun_fast(f_fma(fkk, f_fma(fkk, oms_c2, oms_c1), oms_c0), &near);
+  const float q = fkk * f_fma(fkk, sq.c2, sq.c1);        // the increment over the first node: 0 at stride 0
+  SunState r = sun_fast(sq.c0 + q, q, sq.thr, &near);
   if (__builtin_expect(near, 0)) {
     BLE_STEP_EVENT(0);
     const double dk = 10.0 * (double)kk;
@@ -300,17 +304,14 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   BLE_STEP_TICK(3);
   // Solar geometry: 1 - sin(el_uncorrected) at substep indices 0, n/2, n in fp64, then a
   // quadratic in k evaluated in fp32 inside the loop (see sun_one_minus_sin_f64).
-  float oms_c0, oms_c1, oms_c2;
-  {
-    const SolarNodes nodes = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
-    solar_nodes_site(nodes, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps, &oms_c0, &oms_c1, &oms_c2);
-  }
+  const SolarNodes nodes = solar_nodes_time(e0, t0, c.lng0_deg, step_s);
+  const SunQuadratic sq = solar_nodes_site(nodes, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
   BLE_STEP_TICK(4);
   // (position and time at the START of the step, by value: the reward below calls this after s has been advanced)
   const float x_start = s.x, y_start = s.y;
   const int32_t t_start = s.t_elapsed;
   auto sun_at = [&](int kk) -> SunState {
-    return sun_at_stride(kk, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
+    return sun_at_stride(kk, sq, c, u, v, x_start, y_start, t_start);
   };
   const double q_earth = hc.q_earth;
   *flags |= hc.flags;

@@ -171,7 +171,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     // role state
     AtmWindow win = {}; LayerCursor lc = {}; double t_at_p = 0.0;       // wave 0
     float fl0 = 0.0f, dfl = 0.0f; Ephemeris e0 = {};                     // wave 1 (e0: the part solar_nodes_time reads, on waves 1, 2, 3)
-    float oms_c0 = 0.0f, oms_c1 = 0.0f, oms_c2 = 0.0f; double node_f0 = 0.0;   // wave 2
+    SunQuadratic sq = {}; double node_f0 = 0.0;                          // wave 2
     float sun_sin = 0.0f, sun_panel = 0.0f; bool sun_day = false;        // waves 1, 3: the sun of the stride about to run
     uint32_t map_pow_env = 0; int eff = kStay;                           // wave 3
 
@@ -233,7 +233,8 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         node_f0 = solar_node<0>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
         // the sun of stride 0 needs the first node alone: the quadratic at index 0 is its constant term (the other two
         // coefficients are finite), so it is ready at the same barrier as the nodes
-        const SunState sun0 = sun_at_stride(0, (float)node_f0, 0.0f, 0.0f, c, u, v, x_start, y_start, t_start);
+        sq.c0 = (float)node_f0; sq.c1 = 0.0f; sq.c2 = 0.0f; sq.thr = sun_thresholds(node_f0);
+        const SunState sun0 = sun_at_stride(0, sq, c, u, v, x_start, y_start, t_start);
         sun_sin = sun0.sin_el; sun_panel = solar_panel_factor(sun0); sun_day = sun0.day;
         sh.sin_el0[lane] = sun_sin; sh.panel0[lane] = sun_panel; sh.day0[lane] = sun_day ? 1u : 0u;
       }
@@ -241,7 +242,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     BLE_SPLIT_T(0);
     __syncthreads();                                   // ---- barrier 2: the nodes, the sun of stride 0, the altitude layer's map
     BLE_SPLIT_T(1);
-    if (r2) solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps, &oms_c0, &oms_c1, &oms_c2);
+    if (r2) sq = solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps);
     if ((r1 || r3) && !r2) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
     if (r3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
     if (live) flags |= step_flags;
@@ -276,7 +277,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
         if (publish) sh.t_int[wr][lane] = t_int_n;
       }
       if (r2) {
-        const SunState sn = sun_at_stride(k + 1, oms_c0, oms_c1, oms_c2, c, u, v, x_start, y_start, t_start);
+        const SunState sn = sun_at_stride(k + 1, sq, c, u, v, x_start, y_start, t_start);
         sun_sin_n = sn.sin_el; sun_panel_n = solar_panel_factor(sn); sun_day_n = sn.day;
         // step 4: superpressure and volume (balloon.py:470-482): burst above 2 380 Pa, zero pressure at <= 0 (the later check overrides)
         superpressure_volume_f64(n_air, t_int, p, rp, &vol_n, &sp_n);
