@@ -217,11 +217,13 @@ BLE_FN double solar_node(const SolarNodes& n, double sl0, double cl0, float x_m,
 // the quadratic through the three nodes, in the stride index, and the first node's distances to the solar thresholds
 struct SunQuadratic { float c0, c1, c2; SunThresholds thr; };
 BLE_FN SunQuadratic solar_node_coefs(double f0, double f1, double f2, int substeps) {
-  const double m = 0.5 * (double)substeps;
+  // divided differences over the half step m = substeps / 2 strides: / (2 m) and / (2 m^2) through one reciprocal (the float32
+  // coefficients absorb its 2e-15; two true fp64 divisions were ~60 instructions per agent step)
+  const double inv_2m = d_rcp((double)substeps);
   SunQuadratic sq;
   sq.c0 = (float)f0;
-  sq.c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) / (2.0 * m));
-  sq.c2 = (float)((f2 - 2.0 * f1 + f0) / (2.0 * m * m));
+  sq.c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) * inv_2m);
+  sq.c2 = (float)((f2 - 2.0 * f1 + f0) * (2.0 * (inv_2m * inv_2m)));
   sq.thr = sun_thresholds(f0);
   return sq;
 }
