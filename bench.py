@@ -653,9 +653,10 @@ def main():
       size = None
       if cfg == 3 and world == 1:
         size = 8192                                      # one GPU's share of configs[3] on an 8-GPU node
-      # side legs time 64-step regions whatever --steps says (two 32-step launches on one rank): a 20-step region of a
-      # 10 us-per-step shard is 0.2 ms, of which the host's launch + synchronise is 12 %
-      r = make(cfg, n=size, steps=64)
+      # side legs time 192-step regions after 32 warm-up steps whatever --steps / --warmup say (the default run's shape: six
+      # 32-step launches on one rank): a 20-step region of a 10 us-per-step shard is 0.2 ms, of which the host's launch +
+      # synchronise is 12 %, and five warm-up steps leave the first repetitions on a cold clock
+      r = make(cfg, n=size, steps=192, warmup=32)
       s = r.summary(extra_reps)
       key = f'configs[{cfg}]' + (' per-GPU shard (8 192 of 65 536), 1 GPU' if (cfg == 3 and world == 1) else '')
       configs[key] = {k: s[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step', 'decode_ms',
