@@ -27,9 +27,9 @@
 #include "../../include/ble_abi.h"
 #include "ble_reset.h"
 #include "ble_step_core.h"
+#include "ble_noise.h"
 #include "ble_step_split.h"
 #include "ble_observe.h"
-#include "ble_noise.h"
 #include "ble_decode.h"
 
 using namespace ble;
@@ -57,7 +57,6 @@ __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags
 // (wind_field.py:125-145) is evaluated IN the kernel at every step's pre-step position -- the same lane function as
 // ble_wind_noise_f32 (wind_noise_cached), hence the same bits as ble_wind_noise_f32 + ble_step_f32 step by step.  A
 // separate instantiation: the noise-free rollout keeps its register allocation.
-struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* harmonic_cache; };
 template <bool kNoise>
 __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
@@ -172,23 +171,27 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
 }
 
 // The same transition for small batches: one environment on the four wavefronts of a 256-thread workgroup (ble_step_split.h).
+template <bool kNoise>
 __global__ __launch_bounds__(kSplitWaves * kSplitLanes) void ble_step_split_kernel(SplitArgs a) {
   __shared__ SplitShared sh;
+  __shared__ SplitNoiseShared<kNoise> shn;
   uint32_t flags;
   switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {       // (scalar: one role per wave)
-    case 0: flags = split_agent_steps<4, 0>(a, sh); break;
-    case 1: flags = split_agent_steps<4, 1>(a, sh); break;
-    case 2: flags = split_agent_steps<4, 2>(a, sh); break;
-    default: flags = split_agent_steps<4, 3>(a, sh); break;
+    case 0: flags = split_agent_steps<4, 0, kNoise>(a, sh, shn); break;
+    case 1: flags = split_agent_steps<4, 1, kNoise>(a, sh, shn); break;
+    case 2: flags = split_agent_steps<4, 2, kNoise>(a, sh, shn); break;
+    default: flags = split_agent_steps<4, 3, kNoise>(a, sh, shn); break;
   }
   report_flags(flags, a.err_flags);
 }
 // ... and on two: {vertical, thermal} | {sun + envelope, ACS + power}, 128-thread workgroups (two waves per SIMD at 65 536 environments)
+template <bool kNoise>
 __global__ __launch_bounds__(2 * kSplitLanes) void ble_step_pair_kernel(SplitArgs a) {
   __shared__ SplitShared sh;
+  __shared__ SplitNoiseShared<kNoise> shn;
   uint32_t flags;
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) flags = split_agent_steps<2, 0>(a, sh);
-  else flags = split_agent_steps<2, 1>(a, sh);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) flags = split_agent_steps<2, 0, kNoise>(a, sh, shn);
+  else flags = split_agent_steps<2, 1, kNoise>(a, sh, shn);
   report_flags(flags, a.err_flags);
 }
 
@@ -567,7 +570,8 @@ inline int split_waves(int64_t n) {
 inline bool use_split(int64_t n) { return split_waves(n) != 1; }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                         const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
-                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream);
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream,
+                        const ble_noise_gen* noise = nullptr);
 // hipGetLastError is per-thread and sticky: an error left behind by an unrelated runtime call
 // of the host application (torch probes pointers / peers at start-up) must not be reported as
 // ours, so every launch first drains it, and the launch's own status is kept for
@@ -586,15 +590,22 @@ inline int launch_status() {
 inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                         const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
-                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream) {
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream,
+                        const ble_noise_gen* noise) {
   SplitArgs a;
   a.st = *st; a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
   a.reward = reward; a.terminal = terminal; a.effective_action = effective_action; a.err_flags = err_flags;
   a.active_count = active_count; a.n = n; a.substeps = substeps; a.n_steps = n_steps;
-  if (split_waves(n) == 2)
-    BLE_LAUNCH(ble_step_pair_kernel, dim3(blocks(n, kSplitLanes)), dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
-  else
-    BLE_LAUNCH(ble_step_split_kernel, dim3(blocks(n, kSplitLanes)), dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  a.gen = noise ? StepNoise{noise->seed, noise->episode, noise->harmonic_cache} : StepNoise{0ull, nullptr, nullptr};
+  const dim3 grid(blocks(n, kSplitLanes));
+  const bool pair = split_waves(n) == 2;
+  if (noise != nullptr) {
+    if (pair) BLE_LAUNCH(ble_step_pair_kernel<true>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
+    else BLE_LAUNCH(ble_step_split_kernel<true>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  } else {
+    if (pair) BLE_LAUNCH(ble_step_pair_kernel<false>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
+    else BLE_LAUNCH(ble_step_split_kernel<false>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  }
   return launch_status();
 }
 inline bool state_ok(const ble_state_f32* st) {
@@ -645,13 +656,13 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
   if (n == 0) return BLE_OK;
   if (n_steps == 0) return BLE_OK;
   const int lanes = env_lanes();
+  if (use_split(n))          // (with or without the in-kernel noise generator)
+    return launch_split(st, action, wind_grid, grid_env_stride, nullptr, reward, terminal, nullptr, err_flags, active_count, n, substeps,
+                        n_steps, stream, noise);
   if (noise != nullptr) {
     BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
                active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache});
-  } else if (use_split(n)) {
-    return launch_split(st, action, wind_grid, grid_env_stride, nullptr, reward, terminal, nullptr, err_flags, active_count, n, substeps,
-                        n_steps, stream);
   } else {
     BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,

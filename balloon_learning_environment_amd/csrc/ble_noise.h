@@ -22,20 +22,21 @@
 namespace ble {
 
 struct Harmonic { float weight, x_spacing, y_spacing, p_spacing, t_spacing; };
-// simplex_wind_noise.py:50-64 (weight, x km, y km, pressure Pa, time h); comp 0 = u, 1 = v
-BLE_FN Harmonic harmonic_params(int comp, int h) {
-  constexpr Harmonic kU[5] = {{0.1445f, 702.269f, 2116.987f, 2587.802f, 245.0f},
-                              {0.2766f, 1483.570f, 752.124f, 646.208f, 16.39f},
-                              {0.2627f, 276.810f, 147.040f, 587.702f, 3.836f},
-                              {0.2137f, 10214.525f, 1512.216f, 965.629f, 41.780f},
-                              {0.1025f, 181.286f, 420.942f, 8500.0f, 245.0f}};
-  constexpr Harmonic kV[5] = {{0.2716f, 1974.228f, 2028.814f, 713.697f, 26.435f},
-                              {0.2684f, 699.738f, 541.845f, 632.116f, 9.530f},
-                              {0.2348f, 217.750f, 196.522f, 686.825f, 3.546f},
-                              {0.1186f, 47.500f, 43.048f, 66.553f, 8.424f},
-                              {0.1066f, 3663.291f, 232.023f, 7499.741f, 225.0f}};
-  return comp == 0 ? kU[h] : kV[h];
-}
+// simplex_wind_noise.py:50-64 (weight, x km, y km, pressure Pa, time h); harmonic k = 5 comp + h, comp 0 = u, 1 = v.
+// A table in constant memory: as a function-local array indexed at run time it lived on the stack (48 B of scratch per lane
+// in every kernel that evaluates the noise).
+struct HarmonicTable { Harmonic h[10]; };
+BLE_CONST_TABLE HarmonicTable kHarmonics = {{{0.1445f, 702.269f, 2116.987f, 2587.802f, 245.0f},
+                                             {0.2766f, 1483.570f, 752.124f, 646.208f, 16.39f},
+                                             {0.2627f, 276.810f, 147.040f, 587.702f, 3.836f},
+                                             {0.2137f, 10214.525f, 1512.216f, 965.629f, 41.780f},
+                                             {0.1025f, 181.286f, 420.942f, 8500.0f, 245.0f},
+                                             {0.2716f, 1974.228f, 2028.814f, 713.697f, 26.435f},
+                                             {0.2684f, 699.738f, 541.845f, 632.116f, 9.530f},
+                                             {0.2348f, 217.750f, 196.522f, 686.825f, 3.546f},
+                                             {0.1186f, 47.500f, 43.048f, 66.553f, 8.424f},
+                                             {0.1066f, 3663.291f, 232.023f, 7499.741f, 225.0f}}};
+BLE_FN Harmonic harmonic_params(int comp, int h) { return kHarmonics.h[5 * comp + h]; }
 constexpr float kSimplex4Variance = 0.088392f;   // of simplex4() below: measured 0.0889 (tests/test_gpu_noise.py) == the reference's SIMPLEX_VARIANCE (:70)
 constexpr float kNoiseVariance = 1.02f;          // simplex_wind_noise.py:73
 
@@ -103,14 +104,35 @@ BLE_FN HarmonicDraw harmonic_draw(Philox& g) {
 }
 // NoisyWindComponent.get_noise (:190-211): the weighted harmonics of one component, variance-adjusted.
 struct NoiseAccumulator { float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f; };
-BLE_FN void noise_add_harmonic(NoiseAccumulator& a, int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure,
-                               float t_h) {
+// NoisyWindHarmonic.get_noise (:116-146): one harmonic's value at a point -- the expensive part (one 4-D simplex evaluation);
+// the four-wave form of the transition evaluates the ten of them on different wavefronts
+BLE_FN float noise_harmonic_value(int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure, float t_h) {
   BLE_NO_CONTRACT
   const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
   const Harmonic hp = harmonic_params(comp, h);
-  const float nz = magnitude * simplex4(x_km / hp.x_spacing + d.ox, y_km / hp.y_spacing + d.oy, pressure / hp.p_spacing + d.op,
-                                        t_h / hp.t_spacing + d.ot, d.hseed);
+  return magnitude * simplex4(x_km / hp.x_spacing + d.ox, y_km / hp.y_spacing + d.oy, pressure / hp.p_spacing + d.op,
+                              t_h / hp.t_spacing + d.ot, d.hseed);
+}
+BLE_FN void noise_accumulate(NoiseAccumulator& a, int comp, int h, float nz) {
+  BLE_NO_CONTRACT
+  const Harmonic hp = harmonic_params(comp, h);
   a.acc = f_fma(nz, hp.weight, a.acc); a.wsum += hp.weight; a.w2sum = f_fma(hp.weight, hp.weight, a.w2sum);
+}
+BLE_FN void noise_add_harmonic(NoiseAccumulator& a, int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure,
+                               float t_h) {
+  noise_accumulate(a, comp, h, noise_harmonic_value(comp, h, d, x_km, y_km, pressure, t_h));
+}
+// the coordinates the harmonics are sampled at (units.Distance.km, timedelta_to_hours)
+BLE_FN void noise_coords(float x_m, float y_m, int32_t elapsed_s, float* x_km, float* y_km, float* t_h) {
+  BLE_NO_CONTRACT
+  *x_km = x_m * 1e-3f; *y_km = y_m * 1e-3f; *t_h = (float)elapsed_s * (1.0f / 3600.0f);
+}
+BLE_FN HarmonicDraw harmonic_draw_from_rows(const uint32_t* rows, int64_t stride, int k) {     // rows 5 k .. 5 k + 4, `stride` words apart
+  const uint32_t* row = rows + (int64_t)(5 * k) * stride;
+  HarmonicDraw d;
+  d.hseed = row[0]; d.ox = u32_bits_float(row[stride]); d.oy = u32_bits_float(row[2 * stride]); d.op = u32_bits_float(row[3 * stride]);
+  d.ot = u32_bits_float(row[4 * stride]);
+  return d;
 }
 BLE_FN float noise_finish(const NoiseAccumulator& a) {
   BLE_NO_CONTRACT
@@ -142,19 +164,27 @@ BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, 
 BLE_FN void wind_noise_from_rows(float x_m, float y_m, float pressure, int32_t elapsed_s, const uint32_t* rows, int64_t stride,
                                  float* u, float* v) {
   BLE_NO_CONTRACT
-  const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
+  float x_km, y_km, t_h;
+  noise_coords(x_m, y_m, elapsed_s, &x_km, &y_km, &t_h);
   float out[2];
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
     NoiseAccumulator a;
 #pragma unroll 1
-    for (int h = 0; h < 5; ++h) {
-      const uint32_t* row = rows + (int64_t)(5 * (5 * comp + h)) * stride;
-      HarmonicDraw d;
-      d.hseed = row[0]; d.ox = u32_bits_float(row[stride]); d.oy = u32_bits_float(row[2 * stride]); d.op = u32_bits_float(row[3 * stride]);
-      d.ot = u32_bits_float(row[4 * stride]);
-      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
-    }
+    for (int h = 0; h < 5; ++h)
+      noise_add_harmonic(a, comp, h, harmonic_draw_from_rows(rows, stride, 5 * comp + h), x_km, y_km, pressure, t_h);
+    out[comp] = noise_finish(a);
+  }
+  *u = out[0]; *v = out[1];
+}
+// ... and from the ten harmonic values, evaluated elsewhere (`nz`: 10 floats `stride` apart, harmonic k = 5 comp + h)
+BLE_FN void wind_noise_from_values(const float* nz, int64_t stride, float* u, float* v) {
+  float out[2];
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    NoiseAccumulator a;
+#pragma unroll 1
+    for (int h = 0; h < 5; ++h) noise_accumulate(a, comp, h, nz[(int64_t)(5 * comp + h) * stride]);
     out[comp] = noise_finish(a);
   }
   *u = out[0]; *v = out[1];
@@ -176,17 +206,21 @@ BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint32_t episode, uin
 #pragma unroll 1
   for (int k = 0; k < 10; ++k) {
     const HarmonicDraw d = harmonic_draw(g);
-    const uint32_t w[5] = {d.hseed, float_bits_u32(d.ox), float_bits_u32(d.oy), float_bits_u32(d.op), float_bits_u32(d.ot)};
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      dst[(5 * k + q) * dst_stride] = w[q];
-      if (cache != nullptr) cache[env + (int64_t)(5 * k + q) * n] = w[q];
+    const uint32_t w0 = d.hseed, w1 = float_bits_u32(d.ox), w2 = float_bits_u32(d.oy), w3 = float_bits_u32(d.op), w4 = float_bits_u32(d.ot);
+    uint32_t* o = dst + (int64_t)(5 * k) * dst_stride;
+    o[0] = w0; o[dst_stride] = w1; o[2 * dst_stride] = w2; o[3 * dst_stride] = w3; o[4 * dst_stride] = w4;
+    if (cache != nullptr) {
+      uint32_t* cch = cache + env + (int64_t)(5 * k) * n;
+      cch[0] = w0; cch[n] = w1; cch[2 * n] = w2; cch[3 * n] = w3; cch[4 * n] = w4;
     }
   }
   if (cache != nullptr) {
     cache[env + 50 * n] = episode + 1u; cache[env + 51 * n] = (uint32_t)seed; cache[env + 52 * n] = (uint32_t)(seed >> 32);
   }
 }
+
+// the generator of a fused rollout (struct ble_noise_gen of the ABI)
+struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* harmonic_cache; };
 
 // The same with the draws kept in HBM between calls, as the reference keeps them in its NoisyWindHarmonic objects between
 // resets: `cache` is [kNoiseCacheRows][n] 32-bit words (coalesced), rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic k

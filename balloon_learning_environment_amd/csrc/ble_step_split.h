@@ -31,6 +31,7 @@
 // points for n <= BLE_SPLIT_MAX_ENVS = 32 768 (two waves per SIMD: measured 1.4x the one-lane kernel there, 1.9x at <= 16 384
 // environments where every wave has a SIMD to itself; at 65 536 -- four waves per SIMD -- the one-lane kernel wins).
 #pragma once
+#include "ble_noise.h"
 #include "ble_step_core.h"
 
 // Timing build (profiles/build_variant.sh split_timing -DBLE_SPLIT_TIMING): every wave adds the shader-clock cycles it spends in
@@ -83,6 +84,14 @@ BLE_FN int action_apply_any(uint32_t map_alt, uint32_t map_pow_env, int action) 
   return action <= kUp ? known : (known == kUp ? kUp : action);
 }
 
+// the in-kernel wind-noise generator of a fused rollout (ABI 3) in this form: the harmonics' draws of the workgroup's
+// environments (fetched once per launch) and the ten harmonic values of a step, each evaluated by one of the waves
+template <bool kNoise> struct SplitNoiseShared {};
+template <> struct SplitNoiseShared<true> {
+  uint32_t draws[50][kSplitLanes];
+  float nz[10][kSplitLanes];
+};
+
 struct SplitArgs {
   ble_state_f32 st;
   const uint8_t* action;
@@ -96,13 +105,14 @@ struct SplitArgs {
   unsigned long long* active_count;
   int64_t n;
   int substeps, n_steps;
+  StepNoise gen;                     // read by the <kNoise> instantiations only
 };
 
 // One wave of a workgroup of 256 threads = 4 waves x 64 lanes; returns this thread's error flags.  `wave` is a
 // compile-time constant: every role is its own instantiation -- its own registers, its own loops -- and the four agree on
-// the number of barriers per step (two in the per-step part, one per stride) by construction.
-template <int kWaves, int wave>
-BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
+// the number of barriers per step (two in the per-step part -- three with the noise generator --, one per stride) by construction.
+template <int kWaves, int wave, bool kNoise>
+BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNoiseShared<kNoise>& shn) {
   static_assert((kWaves == 4 || kWaves == 2) && wave >= 0 && wave < kWaves, "four waves = one role each, two waves = two roles each");
   // the roles this wave plays: 0 vertical, 1 thermal, 2 sun + envelope, 3 ACS + power (kWaves == 2: {0, 1} and {2, 3})
   constexpr bool r0 = kWaves == 4 ? wave == 0 : wave == 0, r1 = kWaves == 4 ? wave == 1 : wave == 0;
@@ -136,6 +146,10 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
     live = s.status == kOk;
   }
   for (int t = (int)threadIdx.x; t < kAcsPolyDoubles; t += kWaves * kSplitLanes) sh.acs_poly[t] = kAcsPoly.c[t];
+  if constexpr (kNoise) {            // the harmonics' seeds and offsets of the workgroup's environments, once per launch
+    if (wave == 0 && in_range)
+      noise_draws_fetch(a.gen.seed, (uint64_t)i, a.gen.episode ? a.gen.episode[i] : 0u, a.gen.harmonic_cache, n, &shn.draws[0][lane], kSplitLanes);
+  }
   __syncthreads();
   const bool was_live = live;
   int last_act = 0;
@@ -195,13 +209,30 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh) {
       if (live) { s.sunrise_h = sr0; s.sunset = ss0; s.paused = pa0; s.env_fsm = f0; }
       map_pow_env = action_map(q0, q1, q2);
     }
+    if constexpr (kNoise) {
+      // WindField.get_ground_truth's noise term at the pre-step position (wind_field.py:125-145): the ten harmonic values,
+      // each one 4-D simplex evaluation, spread over the waves (harmonic k on wave k mod kWaves); role 2 adds them up below
+      // in the reference's order -- the same functions in the same order as ble_wind_noise_f32
+      if (in_range) {
+        float x_km, y_km, t_h;
+        noise_coords(s.x, s.y, s.t_elapsed, &x_km, &y_km, &t_h);
+#pragma unroll 1
+        for (int k = wave; k < 10; k += kWaves)
+          shn.nz[k][lane] = noise_harmonic_value(k / 5, k % 5, harmonic_draw_from_rows(&shn.draws[0][lane], kSplitLanes, k), x_km, y_km, s.p, t_h);
+      }
+      __syncthreads();                                 // ---- barrier 0 (noise only): the harmonic values are there
+    }
     // role 2: the wind at the PRE-step position/time (balloon_arena.py:194,270-275): WindField.get_ground_truth = forecast + noise
     if (r2) {
       const WindQuery wq = wind_query(s.x, s.y, s.p, s.t_elapsed);
       WindCorners corners;
       wind_gather(a.wind_grid + (in_range ? i : 0) * a.grid_env_stride, wq, &corners);
       float nu = 0.0f, nv = 0.0f;
-      if (a.noise_uv && in_range) { nu = a.noise_uv[2 * i]; nv = a.noise_uv[2 * i + 1]; }
+      if constexpr (kNoise) {
+        if (in_range) wind_noise_from_values(&shn.nz[0][lane], kSplitLanes, &nu, &nv);
+      } else {
+        if (a.noise_uv && in_range) { nu = a.noise_uv[2 * i]; nv = a.noise_uv[2 * i + 1]; }
+      }
       wind_blend_corners(corners, wq, &u, &v);
       u += nu; v += nv;
       sh.u[lane] = u; sh.v[lane] = v;

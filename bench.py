@@ -666,6 +666,13 @@ def main():
                                 else 'ble_step_kernel (one lane per environment)')
       del r
       torch.cuda.empty_cache()
+      if cfg != 4:       # the same leg in the reference's own wind (noise generated in-kernel; the ten harmonics on the four waves)
+        rg = make(cfg, n=size, steps=192, warmup=32, noise_seed=20240917)
+        sg = rg.summary(max(3, extra_reps // 2))
+        configs[key]['env_steps_per_s_ground_truth_wind'] = sg['env_steps_per_s']
+        configs[key]['ms_per_step_ground_truth_wind'] = sg['ms_per_step']
+        del rg
+        torch.cuda.empty_cache()
     if rank == 0:
       try:
         configs['configs[0] counterpart: single-env facade'] = facade_leg()

@@ -785,14 +785,17 @@ def test_fused_rollout_equals_single_steps(ble, wide):
   np.testing.assert_array_equal(term.cpu().numpy(), term_c.cpu().numpy())
 
 
+@pytest.mark.parametrize('waves', ['0', '4', '2'])
 @pytest.mark.parametrize('with_cache', [True, False])
-def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, with_cache):
+def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, with_cache, waves):
   """ABI 3: ble_step_n_f32 with a noise generator flies every step in WindField.get_ground_truth = forecast + SimplexWindNoise
   (wind_field.py:125-145), the noise evaluated INSIDE the kernel at the pre-step position.  Bit for bit what K rounds of
   ble_wind_noise_f32 followed by ble_step_f32(noise_uv) give -- state, rewards, terminals -- for environments in different
   episodes (the generator is keyed by (seed, env, episode)), with and without the harmonic cache; and it is NOT the forecast
-  flight."""
+  flight.  `waves`: the fused launch on the one-lane kernel (in-kernel generator on one lane) or on four / two wavefronts per
+  environment (the ten harmonics evaluated on different waves, summed in the reference's order)."""
   import ctypes
+  import os
   from balloon_learning_environment_amd import _abi, _lib, device as dev, reset_host
   n, k, seed = 4096, 6, 20240917
   init = reset_host.sample_initial_state(n, seed=15)
@@ -805,12 +808,16 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
     s = ble.VecSimulator(n); s.set_state(init); s.set_grid(field); s.episode.copy_(episodes); sims.append(s)
   a, b, c = sims
   rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
-  if with_cache:
-    a.step_n(acts, rew, term, noise_seed=seed)
-  else:                                              # harmonic_cache NULL: the draws are redone by every step
-    gen = _abi.BleNoiseGen(seed, a.episode.data_ptr(), None)
-    _lib.check(a.lib.ble_step_n_f32(ctypes.byref(a._struct), acts.data_ptr(), a.grid.data_ptr(), 0, ctypes.byref(gen), rew.data_ptr(),
-                                    term.data_ptr(), a.err_flags.data_ptr(), None, n, 18, k, dev.stream_ptr(a.device)), 'ble_step_n_f32')
+  os.environ['BLE_STEP_SPLIT'] = waves
+  try:
+    if with_cache:
+      a.step_n(acts, rew, term, noise_seed=seed)
+    else:                                              # harmonic_cache NULL: the draws come straight from the Philox stream
+      gen = _abi.BleNoiseGen(seed, a.episode.data_ptr(), None)
+      _lib.check(a.lib.ble_step_n_f32(ctypes.byref(a._struct), acts.data_ptr(), a.grid.data_ptr(), 0, ctypes.byref(gen), rew.data_ptr(),
+                                      term.data_ptr(), a.err_flags.data_ptr(), None, n, 18, k, dev.stream_ptr(a.device)), 'ble_step_n_f32')
+  finally:
+    del os.environ['BLE_STEP_SPLIT']
   rb, tb = [], []
   for j in range(k):
     noise = b.wind_noise(seed)
