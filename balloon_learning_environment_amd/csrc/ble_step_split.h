@@ -8,7 +8,7 @@
 // workgroup is 4 waves = the 4 SIMDs of a CU, lane l of EVERY wave is environment 64 b + l, and each wave advances one group:
 //
 //   wave 0  vertical dynamics: p, T(p), ambient temperature, position           (stride_pressure, stride_ambient_advance);
-//           per step: atmosphere window, altitude layer, the previous step's reward
+//           per step: atmosphere window, altitude layer; the step's reward, terminal flag and range checks
 //   wave 1  thermal model: internal temperature                                 (stride_internal_temperature)
 //   wave 2  the sun, one stride AHEAD (it depends on the stride index only): sin el, panel factor, day -- the rare exact
 //           solar chain runs here, off everybody's critical path -- and the envelope: volume, superpressure
@@ -19,7 +19,9 @@
 // barrier and read what they need.  The per-step part is spread the same way around two barriers (atmosphere window |
 // ephemeris | wind lookup | power + envelope layers; then the altitude layer and one solar node each on waves 1, 2, 3, wave 2
 // the sun of stride 0 with it); the safety layers publish their action MAPS (a layer is a function of the action alone once
-// its state machine has moved).
+// its state machine has moved).  With a wind-noise generator (ABI 3) a step starts with the ten harmonic values, one 4-D
+// simplex evaluation each, spread over the waves, and one more barrier.  The same template runs as TWO wavefronts per
+// environment ({vertical, thermal} | {sun + envelope, ACS + power}: ble_step_pair_kernel, an experiment knob).
 // Between agent steps every value goes through float32, exactly where ble_step_kernel keeps its state as float32.
 //
 // The stride loops are straight-line: a lane whose episode ended (or was over on entry) keeps computing on a shadow of its
