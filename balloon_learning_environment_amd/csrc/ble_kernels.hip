@@ -171,8 +171,11 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
 }
 
 // The same transition for small batches: one environment on the four wavefronts of a 256-thread workgroup (ble_step_split.h).
+#ifndef BLE_SPLIT_WAVES_PER_EU
+#define BLE_SPLIT_WAVES_PER_EU 2
+#endif
 template <bool kNoise>
-__global__ __launch_bounds__(kSplitWaves * kSplitLanes) void ble_step_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(kSplitWaves * kSplitLanes, BLE_SPLIT_WAVES_PER_EU) void ble_step_split_kernel(SplitArgs a) {
   __shared__ SplitShared sh;
   __shared__ SplitNoiseShared<kNoise> shn;
   uint32_t flags;
