@@ -375,7 +375,8 @@ def policy_in_the_loop_leg(roll, launches=256):
   dt = time.perf_counter() - t0
   sim.check_errors()
   stepped = int(sim.active_count.item()) - c0
-  return {'launches': launches, 'envs': n, 'kernel': 'ble_step_kernel via ble_step_f32 (n_steps = 1)',
+  return {'launches': launches, 'envs': n,
+          'kernel': ('ble_step_split_kernel' if n <= 32768 else 'ble_step_kernel') + ' via ble_step_f32 (n_steps = 1)',
           'us_per_launch_event_median': statistics.median(per), 'us_per_launch_event_min': min(per),
           'us_per_step_back_to_back': e0.elapsed_time(e1) * 1e3 / launches, 'env_steps_per_s': stepped / dt,
           'note': 'one launch per agent step: the per-launch fixed cost (state in/out, per-episode constants, wave launch and '
@@ -664,6 +665,10 @@ def main():
       configs[key]['workload'] = PRESETS[cfg]
       configs[key]['kernel'] = ('ble_step_split_kernel (one environment on four wavefronts: n <= 32 768)' if s['envs_per_gpu'] <= 32768
                                 else 'ble_step_kernel (one lane per environment)')
+      if rank == 0 and world == 1 and cfg in (1, 3):      # the policy-in-the-loop shape (one launch per agent step) at this batch size
+        pl = policy_in_the_loop_leg(r)
+        configs[key]['one_launch_per_step'] = {'us_per_step_back_to_back': pl['us_per_step_back_to_back'], 'env_steps_per_s': pl['env_steps_per_s'],
+                                               'us_per_launch_event_median': pl['us_per_launch_event_median']}
       del r
       torch.cuda.empty_cache()
       if cfg != 4:       # the same leg in the reference's own wind (noise generated in-kernel; the ten harmonics on the four waves)
