@@ -20,6 +20,10 @@ BLE_FN float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f
 BLE_FN float f_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32
 BLE_FN float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// A 64-bit constant kept as ONE value in a vector-register pair.  hipcc materialises a non-inline fp64 literal as two 32-bit halves, shares
+// equal halves between literals and re-assembles (and, for an fma's addend, copies) the pair in front of every use: 2-3 issue slots of the
+// stride loop per constant.  An opaque pair made once per agent step is used in place (StrideK, ble_physics.h).
+BLE_FN double d_vreg(double k) { asm("" : "+v"(k)); return k; }
 BLE_FN double d_rint(double x) { return __builtin_rint(x); }
 BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
 BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)

@@ -85,6 +85,44 @@ BLE_FN double d_sqrt_fast(double x) {   // x > 0
   double sq = x * y;
   return d_fma(0.5 * y, d_fma(-sq, sq, x), sq);
 }
+// The non-inline fp64 constants of a stride's right-hand sides that are ADDENDS of an fma (Horner coefficients, offsets).  The stride
+// loops of the transition kernels make them once per agent step as opaque register pairs (stride_k_vreg, see d_vreg); every other caller
+// passes the literals (stride_k_literal: the default argument) -- the same values, the same arithmetic.
+struct StrideK {
+  double prandtl0, five, eleven, absorb0;              // thermal_increment_f64
+  double dry_mass;                                     // stride_pressure
+  double lg5, lg4, lg3, ex4, ex3;                      // atm_temperature_advance
+  double acs_x0, forty;                                // acs_down_poly
+  // ... and multiplicands / offsets whose scalar-register pairs the stride loop had to re-assemble (more constants than scalar registers)
+  double t110, tenth;                                  // thermal_increment_f64
+  double m_over_r;                                     // stride_pressure
+  double lg6, ex5;                                     // atm_temperature_advance
+  double lift, v0;                                     // superpressure_volume_f64
+};
+BLE_FN StrideK stride_k_literal() {
+  StrideK k;
+  k.prandtl0 = 0.804; k.five = 5.0; k.eleven = 11.0; k.absorb0 = 0.04587 - 0.000232 * 210.0;
+  k.dry_mass = kDryMassD;
+  k.lg5 = 0.2; k.lg4 = -0.25; k.lg3 = 1.0 / 3.0; k.ex4 = 1.0 / 24.0; k.ex3 = 1.0 / 6.0;
+  k.acs_x0 = 0.05; k.forty = 40.0;
+  k.t110 = 110.4; k.tenth = 0.1;
+  k.m_over_r = kAirMolarMassD / kGasConstantD;
+  k.lg6 = -1.0 / 6.0; k.ex5 = 1.0 / 120.0;
+  k.lift = 6830.0; k.v0 = 1804.0;
+  return k;
+}
+BLE_FN StrideK stride_k_vreg() {
+  StrideK k = stride_k_literal();
+  k.prandtl0 = d_vreg(k.prandtl0); k.five = d_vreg(k.five); k.eleven = d_vreg(k.eleven); k.absorb0 = d_vreg(k.absorb0);
+  k.dry_mass = d_vreg(k.dry_mass);
+  k.lg5 = d_vreg(k.lg5); k.lg4 = d_vreg(k.lg4); k.lg3 = d_vreg(k.lg3); k.ex4 = d_vreg(k.ex4); k.ex3 = d_vreg(k.ex3);
+  k.acs_x0 = d_vreg(k.acs_x0); k.forty = d_vreg(k.forty);
+  k.t110 = d_vreg(k.t110); k.tenth = d_vreg(k.tenth);
+  k.m_over_r = d_vreg(k.m_over_r);
+  k.lg6 = d_vreg(k.lg6); k.ex5 = d_vreg(k.ex5);
+  k.lift = d_vreg(k.lift); k.v0 = d_vreg(k.v0);
+  return k;
+}
 // ln(x), x > 0 normal: x = m 2^e, m in [sqrt(.5), sqrt(2)); ln m = 2 atanh((m-1)/(m+1)).
 BLE_FN double d_log_fast(double x) {
   double m = d_frexp_mant(x);
@@ -395,11 +433,11 @@ BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, doub
 }
 // T(p1) from T(p0) inside one layer: T1 = T0 (p1/p0)^k, k = -R_d L / g, |p1/p0 - 1| < 2e-2.
 // rp0 = 1/p0.  Series in fp64 (log1p to x^6, expm1 to y^5): relative error < 2e-14.
-BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p1, double lapse) {
+BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p1, double lapse, const StrideK& K = stride_k_literal()) {
   double x = (p1 - p0) * rp0;
-  double lg = x * d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, -1.0 / 6.0, 0.2), -0.25), 1.0 / 3.0), -0.5), 1.0);
+  double lg = x * d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, K.lg6, K.lg5), K.lg4), K.lg3), -0.5), 1.0);
   double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
-  double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, 1.0 / 120.0, 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0);
+  double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, K.ex5, K.ex4), K.ex3), 0.5), 1.0);
   return d_fma(t0, em1, t0);
 }
 // three-way pick on VALUES (kept in registers; a select between struct members makes the
@@ -426,12 +464,12 @@ BLE_FN double atm_height_rel_boundary_f64(double q, double pb, double r_pb, doub
 // replaces the difference of two ~17 km heights; when p and p + d lie on different sides
 // of a layer transition both heights are measured from that transition.
 BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double cur_hi, double cur_lo,
-                                       double p, double rp, double d, double t_p) {
+                                       double p, double rp, double d, double t_p, const StrideK& K = stride_k_literal()) {
   const double x = d * rp;                      // |x| ~ 1e-4: log1p to x^3 (next term 2.5e-13 relative)
-  const double lg = x * d_fma(x, d_fma(x, 1.0 / 3.0, -0.5), 1.0);
+  const double lg = x * d_fma(x, d_fma(x, K.lg3, -0.5), 1.0);
   const bool iso = lapse == 0.0;
   const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;   // |y| ~ 2e-5: expm1 to y^3
-  const double em1 = y * d_fma(y, d_fma(y, 1.0 / 6.0, 0.5), 1.0);
+  const double em1 = y * d_fma(y, d_fma(y, K.ex3, 0.5), 1.0);
   // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
   // one reciprocal, selected operands (same values as the two-branch form, no divergence)
   double inv = (iso ? 1.0 : lapse) * d_rcp(t_p * (iso ? (-kAirSpecificGasD / 9.80665) * lg : em1));
@@ -1032,15 +1070,15 @@ constexpr float kSolarAbsorptivityTotal =
 // a^(-1/4) and a^(-1/10) for a > 0 (fp32-representable): fp32 hardware seed (~2e-7) + one
 // Newton step of y <- y (n + 1 - a y^n) / n, quadratic: ~1e-13 relative.  No fp64 division,
 // no libm.  Used by the fp64 convection model below.
-BLE_FN double d_inv_root4(double a) {
+BLE_FN double d_inv_root4(double a, double five = 5.0) {
   const double y = (double)f_sqrt(f_rsqrt((float)a));
   const double y2 = y * y;
-  return y * d_fma(-a * y2, y2, 5.0) * 0.25;
+  return y * d_fma(-a * y2, y2, five) * 0.25;
 }
-BLE_FN double d_inv_root10(double a) {
+BLE_FN double d_inv_root10(double a, double eleven = 11.0, double tenth = 0.1) {
   const double y = (double)f_exp2(-0.1f * f_log2((float)a));
   const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
-  return y * d_fma(-a * y5, y5, 11.0) * 0.1;
+  return y * d_fma(-a * y5, y5, eleven) * tenth;
 }
 // Increment of the internal temperature over one 10 s stride, fp64:
 //   10 s * d_balloon_temperature_dt(V, 68.5, T_int, T_amb, p, el, flux, IR)     (thermal.py:175-230,
@@ -1065,22 +1103,22 @@ BLE_FN double earth_heat_per_area_f64(double upwelling_ir, uint32_t* flags) {   
 }
 template <bool kExactTwelfthRoot = false>
 BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double t_amb, double p, double q_solar_area,
-                                    double q_earth_area) {
+                                    double q_earth_area, const StrideK& K = stride_k_literal()) {
   constexpr double kR2 = 0.38483473658887897;          // (3 / (4 pi))^(2/3)
   constexpr double kR1 = 0.62035049089940009;          // (3 / (4 pi))^(1/3)
   const double v23 = vol * yc;
   // emitted (thermal.py:214-217)
   const double t2 = t_int * t_int;
-  const double q_emit = (kStefanBoltzmannD * (t2 * t2)) * total_absorptivity_d(d_fma(0.000232, t_int, 0.04587 - 0.000232 * 210.0));
+  const double q_emit = (kStefanBoltzmannD * (t2 * t2)) * total_absorptivity_d(d_fma(0.000232, t_int, K.absorb0));
   // convection
   const double rt = d_rsqrt(t_amb), rt2 = rt * rt, rt4 = rt2 * rt2;
-  const double rv = (p * (t_amb + 110.4)) * (rt4 * rt);                                   // x M/(R 1.458e-6) folded below
+  const double rv = (p * (t_amb + K.t110)) * (rt4 * rt);                                   // x M/(R 1.458e-6) folded below
   const double dt = t_amb - t_int;
   constexpr double kGr = 9.80665 * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (6.0 / kPiD);
-  const double prandtl = d_fma(-3.25e-4, t_amb, 0.804);
+  const double prandtl = d_fma(-3.25e-4, t_amb, K.prandtl0);
   double ra = (prandtl * kGr) * ((rv * rv) * (vol * rt2)) * __builtin_fabs(dt);
   ra = d_max(ra, 1e-30);
-  const double y4 = d_inv_root4(ra);
+  const double y4 = d_inv_root4(ra, K.five);
   const double ra14 = (ra * y4) * (y4 * y4);
   // (the cold-start Newton of the reset / observation kernels converges on differences of this function:
   // there the twelfth root is fp64 too)
@@ -1094,7 +1132,7 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
   }
   const double nusselt = d_fma(0.457, ra14, 2.0 + tw);
   constexpr double kCond = 0.0241 * 0.006415624181362592;   // 0.0241 / 273.15^0.9
-  const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb)) * yc)) * dt;
+  const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb, K.eleven, K.tenth)) * yc)) * dt;
   const double q = (q_solar_area + q_earth_area) + (q_conv - q_emit);
   return (q * v23) * (10.0 * 4.0 * kPiD * kR2 / (1500.0 * 68.5));
 }
@@ -1113,17 +1151,18 @@ BLE_FN void superpressure_volume(float mols_air, float t_int, float p, float* vo
 
 // fp64 variant for the vertical-dynamics chain (see ble_step_core.h): the buoyancy
 // difference rho V - m is an unstable map near float equilibrium, so V must be good to ~1e-9.
-BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, double rp, double* volume, double* sp) {
+BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, double rp, double* volume, double* sp,
+                                     const StrideK& K = stride_k_literal()) {
   // rp = 1/p.  Fully inflated branch: V from the quadratic (balloon.py:596-604); the
   // superpressure then follows from the envelope model V = V0 + dV/dp * sp, which is the
   // same root written without the division p Vu / V (relative difference ~1e-14).
-  double vu = ((6830.0 + mols_air) * kGasConstantD * t_int) * rp;
-  double b = -(1804.0 - 0.0199 * p);
+  double vu = ((K.lift + mols_air) * kGasConstantD * t_int) * rp;
+  double b = -(K.v0 - 0.0199 * p);
   double c4 = 4.0 * 0.0199 * vu * p;
   double v = 0.5 * (d_sqrt_rs(d_fma(b, b, c4)) - b);
-  bool slack = vu <= 1804.0;
+  bool slack = vu <= K.v0;
   *volume = slack ? vu : v;
-  *sp = slack ? 0.0 : (v - 1804.0) * (1.0 / 0.0199);
+  *sp = slack ? 0.0 : (v - K.v0) * (1.0 / 0.0199);
 }
 
 // ---------------------------------------------------------------- ACS
@@ -1198,10 +1237,10 @@ constexpr AcsPolyTable make_acs_poly_table() {
 }
 constexpr AcsPolyTable kAcsPolyValues = make_acs_poly_table();
 BLE_CONST_TABLE AcsPolyTable kAcsPoly = kAcsPolyValues;
-BLE_FN void acs_down_poly(const double* poly, double prm1, double* power_w, double* mdot) {
-  int i = (int)((prm1 - 0.05) * 40.0);             // truncation: [-1, 1) -> 0
+BLE_FN void acs_down_poly(const double* poly, double prm1, double* power_w, double* mdot, const StrideK& K = stride_k_literal()) {
+  int i = (int)((prm1 - K.acs_x0) * K.forty);      // truncation: [-1, 1) -> 0
   i = i < 0 ? 0 : (i > 11 ? 11 : i);
-  const double t = d_max(d_min(prm1 - d_fma(0.025, (double)i, 0.05), 0.025), 0.0);
+  const double t = d_max(d_min(prm1 - d_fma(0.025, (double)i, K.acs_x0), 0.025), 0.0);
   const double* c = poly + 6 * i;
   *mdot = d_fma(d_fma(d_fma(c[3], t, c[2]), t, c[1]), t, c[0]);
   *power_w = d_fma(c[5], t, c[4]);

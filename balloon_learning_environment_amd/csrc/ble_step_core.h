@@ -113,31 +113,32 @@ struct LayerCursor {
 // d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error in the increment itself is amplified past the
 // parity bar within a few substeps.  rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
 BLE_FN double stride_pressure(const AtmWindow& win, const LayerCursor& lc, double p, double rp, double vol, double n_air,
-                              double t_amb, double t_at_p, double yc) {
-  const double mass = d_fma(kAirMolarMassD, n_air, kDryMassD);
-  const double num = d_fma(p * vol, kAirMolarMassD / kGasConstantD, -mass * t_amb);
+                              double t_amb, double t_at_p, double yc, const StrideK& K) {
+  const double mass = d_fma(kAirMolarMassD, n_air, K.dry_mass);
+  const double num = d_fma(p * vol, K.m_over_r, -mass * t_amb);
   const double dir = num >= 0.0 ? 1.0 : -1.0;
   // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
   const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
   const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
-  const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p);
+  const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p, K);
   return d_fma(inv_dh * dh_dt, 10.0, p);                                  // dir * dir == 1
 }
 // step 3: internal temperature (balloon.py:451-467)
 BLE_FN double stride_internal_temperature(double vol, double yc, double t_int, double t_amb, double p, float flux, float att,
-                                          double q_earth) {
-  return t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth);
+                                          double q_earth, const StrideK& K) {
+  return t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth, K);
 }
 // step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the mass flow changes rho V - m by
 // ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified like the thermal increment's.
-BLE_FN void stride_acs(const double* acs_poly, int eff, double sp, double p, double rp, double t_int, float* acs_w, double* mdot_d) {
+BLE_FN void stride_acs(const double* acs_poly, int eff, double sp, double p, double rp, double t_int, float* acs_w, double* mdot_d,
+                       const StrideK& K) {
   constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
   // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
   const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
   const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
   const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
   double w_down, mdot_down;
-  acs_down_poly(acs_poly, prm1, &w_down, &mdot_down);
+  acs_down_poly(acs_poly, prm1, &w_down, &mdot_down, K);
   *acs_w = eff == kDown ? (float)w_down : 0.0f;
   *mdot_d = eff == kUp ? mdot_up : (eff == kDown ? mdot_down : 0.0);
 }
@@ -155,7 +156,8 @@ BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* cha
 }
 // T(p_new) for the next stride: advance inside the layer; if a transition was crossed (cold branch) re-anchor at it first --
 // no transcendental either way (see AtmWindow).  Updates the cursor.
-BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, double p, double rp, double t_at_p, double p_new) {
+BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, double p, double rp, double t_at_p, double p_new,
+                                     const StrideK& K) {
   const double kInf = (double)__builtin_huge_valf();
   double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
   if (__builtin_expect(p_new > lc.cur_hi || !(p_new > lc.cur_lo), 0)) {
@@ -170,7 +172,7 @@ BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, doub
     lc.cur_hi = lay_new < 0 ? kInf : (lay_new == 0 ? win.pb : win.pt);
     lc.cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
   }
-  return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.lapse_cur);
+  return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.lapse_cur, K);
 }
 
 // Solar geometry of one agent step: 1 - sin(el_uncorrected) at stride indices 0, n/2, n in fp64 (sun_one_minus_sin_f64), then a
@@ -329,6 +331,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   float acs_w = s.acs_power, mdot = s.mdot, charge = s.charge, load = s.load;
   int status = kOk;
 
+  const StrideK K = stride_k_vreg();     // (once per agent step: see d_vreg)
   int k = 0;
 #pragma unroll 1
   for (; k < substeps; ++k) {
@@ -341,21 +344,21 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
 
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445)
     const double yc = inv_cbrt_volume(vol);
-    const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
+    const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc, K);
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-    const double t_int_new = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth);
+    const double t_int_new = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth, K);
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
-    superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new);
+    superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new, K);
     // balloon.py:479-482: burst above 2 380 Pa, zero pressure at <= 0 (the status code is formed after the loop)
     bool terminal = !(sp_new <= 2380.0) || sp_new <= 0.0;
 
     // ---- step 5: ACS (balloon.py:487-519)
     double mdot_d;
-    stride_acs(acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
+    stride_acs(acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d, K);
     mdot = (float)mdot_d;
     const double n_air_new = stride_mols_air(n_air, mdot_d);
 
@@ -367,7 +370,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     x = f_fma(u, kStride, x);            // step 1 (balloon.py:394-395)
     y = f_fma(v, kStride, y);
     t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
-    t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new);
+    t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new, K);
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (terminal) { ++k; break; }          // balloon.py:327-328
   }

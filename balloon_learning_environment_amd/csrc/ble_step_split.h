@@ -283,6 +283,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
     // ================================================================ the strides
     bool active = live;
     int k_done = 0, last_rd = 0, status = kOk;        // strides this lane ran; the exchange parity and the status of its last one
+    const StrideK K = stride_k_vreg();                // (a role keeps the members its right-hand sides read; see d_vreg)
 #pragma unroll 1
     for (int k = 0; k < substeps; ++k) {
       if (__ballot(active) == 0ull) break;            // (the same decision in all four waves: `active` derives from shared words)
@@ -296,24 +297,24 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
       const double rp = d_rcp(p);
       if (r0) {
         const double yc = inv_cbrt_volume(vol);
-        p_n = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc);
+        p_n = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc, K);
         x_n = f_fma(u, kStride, x); y_n = f_fma(v, kStride, y);        // step 1 (balloon.py:394-395)
         t_amb_n = t_at_p;                                               // ambient_temperature' = T(p_old)  (balloon.py:457)
-        t_at_p_n = stride_ambient_advance(win, lc, p, rp, t_at_p, p_n);
+        t_at_p_n = stride_ambient_advance(win, lc, p, rp, t_at_p, p_n, K);
         if (publish) { sh.p[wr][lane] = p_n; sh.t_amb[wr][lane] = t_amb_n; sh.x[wr][lane] = x_n; sh.y[wr][lane] = y_n; }
       }
       if (r1) {
         const float flux = f_fma((float)k, dfl, fl0);
         const double yc = inv_cbrt_volume(vol);
         const float att = solar_attenuation(sun_sin, (float)p, sun_day);
-        t_int_n = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth);
+        t_int_n = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth, K);
         if (publish) sh.t_int[wr][lane] = t_int_n;
       }
       if (r2) {
         const SunState sn = sun_at_stride(k + 1, sq, c, u, v, x_start, y_start, t_start);
         sun_sin_n = sn.sin_el; sun_panel_n = solar_panel_factor(sn); sun_day_n = sn.day;
         // step 4: superpressure and volume (balloon.py:470-482): burst above 2 380 Pa, zero pressure at <= 0 (the later check overrides)
-        superpressure_volume_f64(n_air, t_int, p, rp, &vol_n, &sp_n);
+        superpressure_volume_f64(n_air, t_int, p, rp, &vol_n, &sp_n, K);
         const uint32_t code = sp_n <= 0.0 ? (uint32_t)kZeroPressure : (!(sp_n <= 2380.0) ? (uint32_t)kBurst : 0u);
         if (publish) {
           sh.sin_el[wr][lane] = sun_sin_n; sh.panel[wr][lane] = sun_panel_n; sh.day[wr][lane] = sun_day_n ? 1u : 0u;
@@ -323,7 +324,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
       if (r3) {
         const float att = solar_attenuation(sun_sin, (float)p, sun_day);
         double mdot_d;
-        stride_acs(sh.acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d);
+        stride_acs(sh.acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d, K);
         mdot = (float)mdot_d;
         n_air_n = stride_mols_air(n_air, mdot_d);
         stride_power_from_factor(sun_day, sun_panel, att, acs_w, &charge, &load, &batt_n);
