@@ -24,6 +24,9 @@ BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c
 // equal halves between literals and re-assembles (and, for an fma's addend, copies) the pair in front of every use: 2-3 issue slots of the
 // stride loop per constant.  An opaque pair made once per agent step is used in place (StrideK, ble_physics.h).
 BLE_FN double d_vreg(double k) { asm("" : "+v"(k)); return k; }
+// true if the predicate holds on any lane of the wavefront: a rare per-lane path guarded by `if (wave_any(c)) if (c) {...}` costs the common
+// case a compare and ONE scalar branch (s_cbranch_vccnz) instead of an exec-mask save / branch / restore
+BLE_FN bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 BLE_FN double d_rint(double x) { return __builtin_rint(x); }
 BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
 BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)

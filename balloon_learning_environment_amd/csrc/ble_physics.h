@@ -85,40 +85,49 @@ BLE_FN double d_sqrt_fast(double x) {   // x > 0
   double sq = x * y;
   return d_fma(0.5 * y, d_fma(-sq, sq, x), sq);
 }
+// thermal.py's constants in the folded form thermal_increment_f64 evaluates (see there)
+constexpr double kThermalMu = 1.458e-6 / (0.028964922481160 / 8.3144621);          // 1.458e-6 R / M
+constexpr double kRayleighScale = 9.80665 * (1.0 / kThermalMu) * (1.0 / kThermalMu) * (6.0 / 3.14159265358979323846);
+constexpr double kRayleighT = -3.25e-4 * kRayleighScale, kRayleighT0 = 0.804 * kRayleighScale;     // Prandtl(T) x the scale
+constexpr double kEmitRho = 1.0 / (1.0 - 0.0291), kEmitC1 = 0.000232, kEmitC0 = 0.04587 - 0.000232 * 210.0;
+constexpr double kEmitA = 0.000000056704 * (-kEmitRho * kEmitC1 * kEmitC1);
+constexpr double kEmitB = 0.000000056704 * (2.0 * kEmitC1 - 2.0 * kEmitRho * kEmitC1 * kEmitC0);
+constexpr double kEmitC = 0.000000056704 * (2.0 * kEmitC0 - kEmitRho * kEmitC0 * kEmitC0);
+constexpr double kCondTenth = 0.1 * (0.0241 * 0.006415624181362592) / (2.0 * 0.62035049089940009);   // 0.1 x k(273.15 K) / 273.15^0.9 / (2 (3/(4 pi))^(1/3))
 // The non-inline fp64 constants of a stride's right-hand sides that are ADDENDS of an fma (Horner coefficients, offsets).  The stride
 // loops of the transition kernels make them once per agent step as opaque register pairs (stride_k_vreg, see d_vreg); every other caller
 // passes the literals (stride_k_literal: the default argument) -- the same values, the same arithmetic.
 struct StrideK {
-  double prandtl0, five, eleven, absorb0;              // thermal_increment_f64
+  double ra_t0, five, eleven, emit_b, emit_c;          // thermal_increment_f64
   double dry_mass;                                     // stride_pressure
   double lg5, lg4, lg3, ex4, ex3;                      // atm_temperature_advance
   double acs_x0, forty;                                // acs_down_poly
   // ... and multiplicands / offsets whose scalar-register pairs the stride loop had to re-assemble (more constants than scalar registers)
-  double t110, tenth;                                  // thermal_increment_f64
-  double m_over_r;                                     // stride_pressure
+  double t110, cond_tenth;                             // thermal_increment_f64
+  double m_over_r, ten;                                // stride_pressure
   double lg6, ex5;                                     // atm_temperature_advance
   double lift, v0;                                     // superpressure_volume_f64
 };
 BLE_FN StrideK stride_k_literal() {
   StrideK k;
-  k.prandtl0 = 0.804; k.five = 5.0; k.eleven = 11.0; k.absorb0 = 0.04587 - 0.000232 * 210.0;
+  k.ra_t0 = kRayleighT0; k.five = 5.0; k.eleven = 11.0; k.emit_b = kEmitB; k.emit_c = kEmitC;
   k.dry_mass = kDryMassD;
   k.lg5 = 0.2; k.lg4 = -0.25; k.lg3 = 1.0 / 3.0; k.ex4 = 1.0 / 24.0; k.ex3 = 1.0 / 6.0;
   k.acs_x0 = 0.05; k.forty = 40.0;
-  k.t110 = 110.4; k.tenth = 0.1;
-  k.m_over_r = kAirMolarMassD / kGasConstantD;
+  k.t110 = 110.4; k.cond_tenth = kCondTenth;
+  k.m_over_r = kAirMolarMassD / kGasConstantD; k.ten = 10.0;
   k.lg6 = -1.0 / 6.0; k.ex5 = 1.0 / 120.0;
   k.lift = 6830.0; k.v0 = 1804.0;
   return k;
 }
 BLE_FN StrideK stride_k_vreg() {
   StrideK k = stride_k_literal();
-  k.prandtl0 = d_vreg(k.prandtl0); k.five = d_vreg(k.five); k.eleven = d_vreg(k.eleven); k.absorb0 = d_vreg(k.absorb0);
+  k.ra_t0 = d_vreg(k.ra_t0); k.five = d_vreg(k.five); k.eleven = d_vreg(k.eleven); k.emit_b = d_vreg(k.emit_b); k.emit_c = d_vreg(k.emit_c);
   k.dry_mass = d_vreg(k.dry_mass);
   k.lg5 = d_vreg(k.lg5); k.lg4 = d_vreg(k.lg4); k.lg3 = d_vreg(k.lg3); k.ex4 = d_vreg(k.ex4); k.ex3 = d_vreg(k.ex3);
   k.acs_x0 = d_vreg(k.acs_x0); k.forty = d_vreg(k.forty);
-  k.t110 = d_vreg(k.t110); k.tenth = d_vreg(k.tenth);
-  k.m_over_r = d_vreg(k.m_over_r);
+  k.t110 = d_vreg(k.t110); k.cond_tenth = d_vreg(k.cond_tenth);
+  k.m_over_r = d_vreg(k.m_over_r); k.ten = d_vreg(k.ten);
   k.lg6 = d_vreg(k.lg6); k.ex5 = d_vreg(k.ex5);
   k.lift = d_vreg(k.lift); k.v0 = d_vreg(k.v0);
   return k;
@@ -431,12 +440,13 @@ BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, doub
   *height = h;
   *temperature = w.tb + lapse * (h - w.hb);
 }
-// T(p1) from T(p0) inside one layer: T1 = T0 (p1/p0)^k, k = -R_d L / g, |p1/p0 - 1| < 2e-2.
+// T(p1) from T(p0) inside one layer: T1 = T0 (p1/p0)^k, k = -R_d L / g = kl, |p1/p0 - 1| < 2e-2.
 // rp0 = 1/p0.  Series in fp64 (log1p to x^6, expm1 to y^5): relative error < 2e-14.
-BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p1, double lapse, const StrideK& K = stride_k_literal()) {
+// (kl = (-R_d / g) * lapse: constant inside a layer, carried by the caller)
+BLE_FN double atm_temperature_advance(double t0, double p0, double rp0, double p1, double kl, const StrideK& K = stride_k_literal()) {
   double x = (p1 - p0) * rp0;
   double lg = x * d_fma(x, d_fma(x, d_fma(x, d_fma(x, d_fma(x, K.lg6, K.lg5), K.lg4), K.lg3), -0.5), 1.0);
-  double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;
+  double y = kl * lg;
   double em1 = y * d_fma(y, d_fma(y, d_fma(y, d_fma(y, K.ex5, K.ex4), K.ex3), 0.5), 1.0);
   return d_fma(t0, em1, t0);
 }
@@ -463,21 +473,22 @@ BLE_FN double atm_height_rel_boundary_f64(double q, double pb, double r_pb, doub
 //   dH = (T(p)/L) expm1(k log1p(d/p)),  k = -R_d L / g
 // replaces the difference of two ~17 km heights; when p and p + d lie on different sides
 // of a layer transition both heights are measured from that transition.
-BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double cur_hi, double cur_lo,
+BLE_FN double atm_inv_delta_height_f64(const AtmWindow& w, int j, double lapse, double kl, double cur_hi, double cur_lo,
                                        double p, double rp, double d, double t_p, const StrideK& K = stride_k_literal()) {
   const double x = d * rp;                      // |x| ~ 1e-4: log1p to x^3 (next term 2.5e-13 relative)
   const double lg = x * d_fma(x, d_fma(x, K.lg3, -0.5), 1.0);
   const bool iso = lapse == 0.0;
-  const double y = (-kAirSpecificGasD / 9.80665) * lapse * lg;   // |y| ~ 2e-5: expm1 to y^3
+  const double y = kl * lg;                     // kl = (-R_d / g) lapse; |y| ~ 2e-5: expm1 to y^3
   const double em1 = y * d_fma(y, d_fma(y, K.ex3, 0.5), 1.0);
-  // dH = t_p em1 / L  (or -(R/g) t_p lg when L == 0)  ->  1/dH
-  // one reciprocal, selected operands (same values as the two-branch form, no divergence)
-  double inv = (iso ? 1.0 : lapse) * d_rcp(t_p * (iso ? (-kAirSpecificGasD / 9.80665) * lg : em1));
+  // dH = t_p em1 / L  ->  1/dH; in an isothermal layer (the one at 47-51 km: no balloon flies there, the reference's atmosphere has it)
+  // dH = -(R/g) t_p lg, rare path (the common expression gives NaN there: 0 * 1/0, replaced)
+  double inv = lapse * d_rcp(t_p * em1);
+  if (__builtin_expect(wave_any(iso), 0)) if (iso) inv = d_rcp(t_p * ((-kAirSpecificGasD / 9.80665) * lg));
   const double q = p + d;
   // cur_hi / cur_lo: the transition pressures that bound the layer of p (+-inf if unknown/far)
   const bool below = q > cur_hi;            // q in the layer with higher pressure
   const bool above = !(q > cur_lo);
-  if (__builtin_expect(below || above, 0)) {
+  if (__builtin_expect(wave_any(below || above), 0)) if (below || above) {
     BLE_STEP_EVENT(2);
     // transition that separates p and q, and the lapse rate on q's side
     const bool at_pb = (j == 0) ? below : (j < 0);
@@ -1075,10 +1086,11 @@ BLE_FN double d_inv_root4(double a, double five = 5.0) {
   const double y2 = y * y;
   return y * d_fma(-a * y2, y2, five) * 0.25;
 }
-BLE_FN double d_inv_root10(double a, double eleven = 11.0, double tenth = 0.1) {
+// (scale: 0.1, the Newton step's own factor, times whatever constant the caller multiplies the root by)
+BLE_FN double d_inv_root10(double a, double eleven = 11.0, double scale = 0.1) {
   const double y = (double)f_exp2(-0.1f * f_log2((float)a));
   const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
-  return y * d_fma(-a * y5, y5, eleven) * tenth;
+  return y * d_fma(-a * y5, y5, eleven) * scale;
 }
 // Increment of the internal temperature over one 10 s stride, fp64:
 //   10 s * d_balloon_temperature_dt(V, 68.5, T_int, T_amb, p, el, flux, IR)     (thermal.py:175-230,
@@ -1107,16 +1119,15 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
   constexpr double kR2 = 0.38483473658887897;          // (3 / (4 pi))^(2/3)
   constexpr double kR1 = 0.62035049089940009;          // (3 / (4 pi))^(1/3)
   const double v23 = vol * yc;
-  // emitted (thermal.py:214-217)
+  // emitted (thermal.py:214-217): sigma T^4 a (2 - a / (1 - r)), a = 0.04587 + 0.000232 (T - 210), expanded in T
   const double t2 = t_int * t_int;
-  const double q_emit = (kStefanBoltzmannD * (t2 * t2)) * total_absorptivity_d(d_fma(0.000232, t_int, K.absorb0));
-  // convection
-  const double rt = d_rsqrt(t_amb), rt2 = rt * rt, rt4 = rt2 * rt2;
-  const double rv = (p * (t_amb + K.t110)) * (rt4 * rt);                                   // x M/(R 1.458e-6) folded below
+  const double q_emit = (t2 * t2) * d_fma(d_fma(kEmitA, t_int, K.emit_b), t_int, K.emit_c);
+  // convection.  Ra = g beta |dT| (2 r)^3 (rho / mu)^2 Pr with rho / mu = p (M/R) (T + 110.4) T^(-5/2) / 1.458e-6, beta = 1 / T,
+  // (2 r)^3 = 6 V / pi:  Ra = [scale Pr(T)] (p (T + 110.4))^2 V |dT| T^(-6)
+  const double rt = d_rcp(t_amb), rt2 = rt * rt, rt3 = rt2 * rt;
+  const double pw = p * (t_amb + K.t110);
   const double dt = t_amb - t_int;
-  constexpr double kGr = 9.80665 * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (kAirMolarMassD / kGasConstantD / 1.458e-6) * (6.0 / kPiD);
-  const double prandtl = d_fma(-3.25e-4, t_amb, K.prandtl0);
-  double ra = (prandtl * kGr) * ((rv * rv) * (vol * rt2)) * __builtin_fabs(dt);
+  double ra = (d_fma(kRayleighT, t_amb, K.ra_t0) * (pw * pw)) * ((vol * (rt3 * rt3)) * __builtin_fabs(dt));
   ra = d_max(ra, 1e-30);
   const double y4 = d_inv_root4(ra, K.five);
   const double ra14 = (ra * y4) * (y4 * y4);
@@ -1131,8 +1142,8 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
     tw = d_fma(-tw * (1.0 / 12.0), d_fma(y8 * y4r, d_rcp(tw_arg), -1.0), tw);       // y - y (y^12 / x - 1) / 12
   }
   const double nusselt = d_fma(0.457, ra14, 2.0 + tw);
-  constexpr double kCond = 0.0241 * 0.006415624181362592;   // 0.0241 / 273.15^0.9
-  const double q_conv = ((nusselt * (kCond / (2.0 * kR1))) * ((t_amb * d_inv_root10(t_amb, K.eleven, K.tenth)) * yc)) * dt;
+  // k(T) / (2 r) = 0.0241 (T / 273.15)^0.9 V^(-1/3) / (2 (3 / (4 pi))^(1/3)): the constants ride on the tenth root's Newton factor
+  const double q_conv = ((nusselt * (t_amb * d_inv_root10(t_amb, K.eleven, K.cond_tenth))) * yc) * dt;
   const double q = (q_solar_area + q_earth_area) + (q_conv - q_emit);
   return (q * v23) * (10.0 * 4.0 * kPiD * kR2 / (1500.0 * 68.5));
 }
@@ -1156,9 +1167,10 @@ BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, do
   // rp = 1/p.  Fully inflated branch: V from the quadratic (balloon.py:596-604); the
   // superpressure then follows from the envelope model V = V0 + dV/dp * sp, which is the
   // same root written without the division p Vu / V (relative difference ~1e-14).
-  double vu = ((K.lift + mols_air) * kGasConstantD * t_int) * rp;
+  const double w = ((K.lift + mols_air) * kGasConstantD) * t_int;       // p Vu = n R T
+  double vu = w * rp;
   double b = -(K.v0 - 0.0199 * p);
-  double c4 = 4.0 * 0.0199 * vu * p;
+  double c4 = (4.0 * 0.0199) * w;                                       // 4 dV/dp (p Vu)
   double v = 0.5 * (d_sqrt_rs(d_fma(b, b, c4)) - b);
   bool slack = vu <= K.v0;
   *volume = slack ? vu : v;

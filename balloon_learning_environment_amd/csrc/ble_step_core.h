@@ -107,6 +107,7 @@ BLE_FN double inv_cbrt_volume(double vol) {
 struct LayerCursor {
   int lay;                 // -1, 0, +1 relative to the window's centre layer
   double lapse_cur;        // its lapse rate
+  double kl_cur;           // (-R_d / g) x the lapse rate: the exponent of T(p) inside the layer
   double cur_hi, cur_lo;   // the transition pressures that bound it (+-inf beyond the window)
 };
 // step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445), fp64 throughout: near float equilibrium
@@ -120,8 +121,8 @@ BLE_FN double stride_pressure(const AtmWindow& win, const LayerCursor& lc, doubl
   // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
   const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
   const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
-  const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p, K);
-  return d_fma(inv_dh * dh_dt, 10.0, p);                                  // dir * dir == 1
+  const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.kl_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p, K);
+  return d_fma(inv_dh * dh_dt, K.ten, p);                                 // dir * dir == 1
 }
 // step 3: internal temperature (balloon.py:451-467)
 BLE_FN double stride_internal_temperature(double vol, double yc, double t_int, double t_amb, double p, float flux, float att,
@@ -160,7 +161,8 @@ BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, doub
                                      const StrideK& K) {
   const double kInf = (double)__builtin_huge_valf();
   double anchor_p = p, anchor_rp = rp, anchor_t = t_at_p;
-  if (__builtin_expect(p_new > lc.cur_hi || !(p_new > lc.cur_lo), 0)) {
+  const bool crossed = p_new > lc.cur_hi || !(p_new > lc.cur_lo);
+  if (__builtin_expect(wave_any(crossed), 0)) if (crossed) {
     BLE_STEP_EVENT(1);
     const int lay_new = atm_window_layer(win, p_new);
     const bool low_pair = (lc.lay + lay_new) < 0;            // crossing pb (else pt)
@@ -169,10 +171,11 @@ BLE_FN double stride_ambient_advance(const AtmWindow& win, LayerCursor& lc, doub
     anchor_t = low_pair ? win.tb : win.tt;
     lc.lay = lay_new;
     lc.lapse_cur = pick3(lay_new, win.lapse_m1, win.lapse_0, win.lapse_p1);
+    lc.kl_cur = (-kAirSpecificGasD / 9.80665) * lc.lapse_cur;
     lc.cur_hi = lay_new < 0 ? kInf : (lay_new == 0 ? win.pb : win.pt);
     lc.cur_lo = lay_new < 0 ? win.pb : (lay_new == 0 ? win.pt : -kInf);
   }
-  return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.lapse_cur, K);
+  return atm_temperature_advance(anchor_t, anchor_p, anchor_rp, p_new, lc.kl_cur, K);
 }
 
 // Solar geometry of one agent step: 1 - sin(el_uncorrected) at stride indices 0, n/2, n in fp64 (sun_one_minus_sin_f64), then a
@@ -243,7 +246,7 @@ BLE_FN SunState sun_at_stride(int kk, const SunQuadratic& sq, const EnvConst& c,
   bool near;
   const float q = fkk * f_fma(fkk, sq.c2, sq.c1);        // the increment over the first node: 0 at stride 0
   SunState r = sun_fast(sq.c0 + q, q, sq.thr, &near);
-  if (__builtin_expect(near, 0)) {
+  if (__builtin_expect(wave_any(near), 0)) if (near) {
     BLE_STEP_EVENT(0);
     const double dk = 10.0 * (double)kk;
     r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
@@ -288,7 +291,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   double altitude, t_at_p;
   atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
   LayerCursor lc;                                // p is in the window's centre layer by construction
-  lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
+  lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.kl_cur = (-kAirSpecificGasD / 9.80665) * win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
   int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);

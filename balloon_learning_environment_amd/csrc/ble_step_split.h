@@ -247,7 +247,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
     if (r0) {
       // (after barrier 1: this wave came to it with the previous step's reward, and what gates barrier 2 is wave 2's node)
       win = atm_window_from(hc.atm, (double)c.alpha, p, &step_flags);
-      lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
+      lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.kl_cur = (-kAirSpecificGasD / 9.80665) * win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
       double altitude;
       atm_at_pressure_f64(win, (double)c.alpha, p, &altitude, &t_at_p);
       uint8_t f0 = s.alt_fsm, f1 = s.alt_fsm, f2 = s.alt_fsm;

@@ -28,7 +28,7 @@ run(); torch.cuda.synchronize()
 snap = {k: t.clone() for k, t in sim.state.items()}
 ts = []
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-for r in range(15):
+for r in range(int(os.environ.get("AB_REPS", "15"))):
   for k, t in sim.state.items(): t.copy_(snap[k])
   torch.cuda.synchronize(); e0.record(); run(); e1.record(); torch.cuda.synchronize()
   ts.append(e0.elapsed_time(e1) * 1e3 / K)
