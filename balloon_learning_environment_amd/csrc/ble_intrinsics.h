@@ -27,6 +27,9 @@ BLE_FN double d_vreg(double k) { asm("" : "+v"(k)); return k; }
 // true if the predicate holds on any lane of the wavefront: a rare per-lane path guarded by `if (wave_any(c)) if (c) {...}` costs the common
 // case a compare and ONE scalar branch (s_cbranch_vccnz) instead of an exec-mask save / branch / restore
 BLE_FN bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// an integer the optimiser cannot see through: used inside rarely taken blocks so that the common path does not carry their
+// induction variables (10 k, (double)k, (k + 1) << 8 ...)
+BLE_FN int i_opaque(int v) { asm("" : "+v"(v)); return v; }
 BLE_FN double d_rint(double x) { return __builtin_rint(x); }
 BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
 BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   __shared__ double acs_poly[kAcsPolyDoubles];
   // kNoise: the harmonics' seeds and offsets of this wave's environments, fetched once per launch ([50][64] words)
   __shared__ uint32_t noise_draws[kNoise ? 50 * kBlock : 1];
+  __shared__ float term_save[kTermSaveRows * kTermSaveStride];       // where a lane parks the state its episode ended with (agent_step)
   const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
   const bool in_range = i < n && (int)threadIdx.x < lanes;
   uint32_t flags = 0;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
         asm volatile("" : "+v"(nu), "+v"(nv));
       } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
-      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, &r, &flags);
+      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, term_save + threadIdx.x, &r, &flags);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
         flags |= kFlagNonFinite;
       reward[o] = r;

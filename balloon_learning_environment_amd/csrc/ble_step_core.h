@@ -248,6 +248,7 @@ BLE_FN SunState sun_at_stride(int kk, const SunQuadratic& sq, const EnvConst& c,
   SunState r = sun_fast(sq.c0 + q, q, sq.thr, &near);
   if (__builtin_expect(wave_any(near), 0)) if (near) {
     BLE_STEP_EVENT(0);
+    kk = i_opaque(kk);                   // (otherwise the common path carries 10 kk and (double)kk as induction variables for this block)
     const double dk = 10.0 * (double)kk;
     r = sun_exact((double)c.lat0_deg, (double)c.lng0_deg, d_fma(dk, (double)u, (double)x_start), d_fma(dk, (double)v, (double)y_start),
                   c.start_unix + (int64_t)(t_start + 10 * kk));
@@ -276,12 +277,13 @@ BLE_FN float step_reward(int action, float x, float y, float p, float batt, floa
   return r;
 }
 
+constexpr int kTermSaveRows = 14, kTermSaveStride = 64;   // agent_step's parking area: 13 state / output floats + (status | strides << 8), one column per lane
 // Returns the effective action (after the safety layers).  `reward` gets the post-step
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
 // The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
 // blend happens after the per-step constants so that the gather's latency is covered.
 BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int action, const WindCorners& corners, const WindQuery& wq,
-                      float noise_u, float noise_v, int substeps, const double* acs_poly, float* reward,
+                      float noise_u, float noise_v, int substeps, const double* acs_poly, float* term_save, float* reward,
                       uint32_t* flags) {
   BLE_STEP_TICK(0);
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
@@ -335,9 +337,14 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   int status = kOk;
 
   const StrideK K = stride_k_vreg();     // (once per agent step: see d_vreg)
-  int k = 0;
+  // The stride loop is wave-uniform: every lane runs all `substeps` strides and the loop index is a scalar.  A lane whose episode ends
+  // inside the step (balloon.py:327-328 breaks there; about one stride in 300 of a wave) parks the state it ended with in LDS
+  // (term_save: kTermSaveRows floats per lane, row stride kTermSaveStride) on a rare path, keeps computing on a state nobody reads, and
+  // takes the parked values back after the loop -- a divergent `break` cost the common stride 20 instructions of exec-mask bookkeeping.
+  float* const term_word = term_save + (kTermSaveRows - 1) * kTermSaveStride;   // status | strides run << 8; 0 while the episode runs
+  *term_word = 0.0f;
 #pragma unroll 1
-  for (; k < substeps; ++k) {
+  for (int k = 0; k < substeps; ++k) {
     const float pf = (float)p;
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
@@ -375,20 +382,36 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     t_amb = t_at_p;                      // ambient_temperature' = T(p_old)  (balloon.py:457)
     t_at_p = stride_ambient_advance(win, lc, p, rp, t_at_p, p_new, K);
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
-    if (terminal) { ++k; break; }          // balloon.py:327-328
+    if (__builtin_expect(wave_any(terminal), 0)) if (terminal && __builtin_bit_cast(int, *term_word) == 0) {          // balloon.py:327-328
+      // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments).  The burst
+      // test is `!(sp <= 2380)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
+      // frozen for the remaining steps of a fused launch instead of stepping on NaN state.
+      int st = kOk;
+      if (!(sp <= 2380.0)) st = kBurst;
+      if (sp <= 0.0) st = kZeroPressure;
+      if (batt <= 0.0f) st = kOutOfPower;
+      const float parked[kTermSaveRows - 1] = {x, y, (float)p, (float)t_amb, (float)t_int, (float)vol, (float)sp, (float)n_air, batt,
+                                               acs_w, mdot, charge, load};
+#pragma unroll
+      for (int j = 0; j < kTermSaveRows - 1; ++j) term_save[j * kTermSaveStride] = parked[j];
+      const int strides = i_opaque(k + 1);          // (otherwise the common path carries (k + 1) << 8 as an induction variable for this block)
+      *term_word = __builtin_bit_cast(float, st | (strides << 8));
+    }
   }
   BLE_STEP_TICK(5);
-  // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments;
-  // k >= 1 here: substeps >= 1 is checked by the host entry point).  The burst test is the loop's own
-  // `!(sp_new <= 2380)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
-  // frozen for the remaining steps of a fused launch instead of stepping on NaN state.
-  if (!(sp <= 2380.0)) status = kBurst;
-  if (sp <= 0.0) status = kZeroPressure;
-  if (batt <= 0.0f) status = kOutOfPower;
-
   s.x = x; s.y = y; s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
   s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;
   s.acs_power = acs_w; s.mdot = mdot; s.charge = charge; s.load = load;
+  int k = substeps;                      // strides this lane ran (>= 1: the host entry point checks substeps >= 1)
+  const int word = __builtin_bit_cast(int, *term_word);
+  const bool done = word != 0;
+  if (__builtin_expect(wave_any(done), 0)) if (done) {
+    s.x = term_save[0]; s.y = term_save[kTermSaveStride]; s.p = term_save[2 * kTermSaveStride]; s.t_amb = term_save[3 * kTermSaveStride];
+    s.t_int = term_save[4 * kTermSaveStride]; s.vol = term_save[5 * kTermSaveStride]; s.sp = term_save[6 * kTermSaveStride];
+    s.n_air = term_save[7 * kTermSaveStride]; s.batt = term_save[8 * kTermSaveStride]; s.acs_power = term_save[9 * kTermSaveStride];
+    s.mdot = term_save[10 * kTermSaveStride]; s.charge = term_save[11 * kTermSaveStride]; s.load = term_save[12 * kTermSaveStride];
+    status = word & 0xff; k = word >> 8;
+  }
   s.t_elapsed += 10 * k;
   s.status = (uint8_t)status;
   *flags |= (s.t_int < 12.3f) ? kFlagAbsorptivity : 0u;

@@ -35,7 +35,8 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
       wind_gather(wind_grid, wq, &wc);
     }
     uint32_t flags = 0; float r;
-    int eff = agent_step(s, c, hoist_constants(c), action[i], wc, wq, nu, nv, substeps, acs_poly, &r, &flags);
+    float term_save[kTermSaveRows * kTermSaveStride];       // (the kernel's LDS parking area of a lane whose episode ends inside the step)
+    int eff = agent_step(s, c, hoist_constants(c), action[i], wc, wq, nu, nv, substeps, acs_poly, term_save, &r, &flags);
     flags_all |= flags;
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
     st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;

@@ -22,6 +22,7 @@ BLE_FN float f_fma(float a, float b, float c) { return fmaf(a, b, c); }
 BLE_FN double d_fma(double a, double b, double c) { return fma(a, b, c); }
 BLE_FN double d_vreg(double k) { return k; }
 BLE_FN bool wave_any(bool c) { return c; }
+BLE_FN int i_opaque(int v) { return v; }
 BLE_FN double d_rint(double x) { return rint(x); }
 BLE_FN double d_sqrt(double x) { return sqrt(x); }
 BLE_FN double d_min(double a, double b) { return fmin(a, b); }
