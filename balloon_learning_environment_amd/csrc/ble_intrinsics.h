@@ -32,6 +32,7 @@ BLE_FN bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 BLE_FN int i_opaque(int v) { asm("" : "+v"(v)); return v; }
 BLE_FN double d_rint(double x) { return __builtin_rint(x); }
 BLE_FN double d_sqrt(double x) { return __builtin_sqrt(x); }
+BLE_FN float f_minnum(float a, float b) { return __builtin_fminf(a, b); }   // v_min_f32 / v_min3_f32 (f_min in ble_physics.h is a compare + select)
 BLE_FN double d_min(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64 (operands are never NaN here)
 BLE_FN double d_max(double a, double b) { return __builtin_fmax(a, b); }
 BLE_FN double d_rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }   // v_rcp_f64: 4.3e-8 relative (measured)

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   }
   if (kNoise && in_range)
     noise_draws_fetch(gen.seed, (uint64_t)i, gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n, noise_draws + threadIdx.x, kBlock);
+  const StrideK K = stride_k_vreg();      // the stride loop's fp64 constants as register pairs, once per launch (see d_vreg)
   BLE_STEP_MARK(3);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
         asm volatile("" : "+v"(nu), "+v"(nv));
       } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
-      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, term_save + threadIdx.x, &r, &flags);
+      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, K, term_save + threadIdx.x, &r, &flags);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
         flags |= kFlagNonFinite;
       reward[o] = r;

@@ -69,6 +69,21 @@ enum : uint32_t { kFlagPressureRange = 1u, kFlagAbsorptivity = 2u, kFlagSolarRan
 // 5.0e-8 relative on gfx950) + ONE Newton step -> ~2e-15 / 4e-15 relative.  That is five
 // orders below what the vertical chain needs (1e-10) and avoids both the second step and the
 // v_div_scale/v_div_fixup ladder (inputs here are normal, positive, far from overflow).
+// x / b for a CONSTANT b, correctly rounded like the division instruction sequence (which is ~12 issue slots in fp32, ~30 in fp64):
+// q0 = RN(x rb), rb = RN(1 / b); the remainder r = x - q0 b is exact in an fma; RN(q0 + r rb) is the correctly rounded quotient
+// (Markstein's final division step) while the quotient is a normal number -- a subnormal one (|x_m| < 1e-35 m) may sit one subnormal
+// step off, which the forecast's `x_km + 500` cannot see.  Checked against the true division exhaustively over the ranges the callers
+// use: tests/test_kernel_numerics_host.py::test_constant_divisions_are_correctly_rounded.
+BLE_FN float f_div_const(float x, float b, float rb) {
+  BLE_NO_CONTRACT
+  const float q0 = x * rb;
+  return f_fma(f_fma(-q0, b, x), rb, q0);
+}
+BLE_FN double d_div_const(double x, double b, double rb) {
+  BLE_NO_CONTRACT
+  const double q0 = x * rb;
+  return d_fma(d_fma(-q0, b, x), rb, q0);
+}
 BLE_FN double d_rcp(double x) {
   double r = d_rcp_seed(x);
   return d_fma(d_fma(-x, r, 1.0), r, r);
@@ -429,16 +444,17 @@ BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
 }
 // height and temperature at p inside layer i0 of the window (standard_atmosphere.py:135-150)
 BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, double* height, double* temperature) {
-  const double g = 9.80665;
   (void)alpha;
+  // T = T_b (p / p_b)^k, k = -R_d L / g; h = h_b + (T - T_b) / L -- the reference's (pow - 1) T_b / L + h_b and T_b + L (h - h_b) with the
+  // division by L taken once, as a refined reciprocal, and none by g; the isothermal layer (L = 0: T = T_b, h from the logarithm) by
+  // selection (k = 0 gives pow = 1 there; 0 x 1/0 is discarded)
   const double lapse = w.lapse_0;
-  double h;
-  if (lapse == 0.0)
-    h = ((-kAirSpecificGasD * w.tb / g) * d_log_fast(p * d_rcp(w.pb)) + w.hb);
-  else
-    h = ((d_pow_fast(p * d_rcp(w.pb), -kAirSpecificGasD * lapse / g) - 1) * w.tb / lapse + w.hb);
-  *height = h;
-  *temperature = w.tb + lapse * (h - w.hb);
+  const double lg = d_log_fast(p * w.r_pb);
+  const double t = w.tb * d_exp_fast(((-kAirSpecificGasD / 9.80665) * lapse) * lg);
+  const double h_iso = d_fma((-kAirSpecificGasD / 9.80665) * w.tb, lg, w.hb);
+  const double h_lapse = d_fma(t - w.tb, d_rcp(lapse), w.hb);
+  *height = lapse == 0.0 ? h_iso : h_lapse;
+  *temperature = t;
 }
 // T(p1) from T(p0) inside one layer: T1 = T0 (p1/p0)^k, k = -R_d L / g = kl, |p1/p0 - 1| < 2e-2.
 // rp0 = 1/p0.  Series in fp64 (log1p to x^6, expm1 to y^5): relative error < 2e-14.
@@ -574,7 +590,7 @@ BLE_FN int power_safety(int action, int32_t now, float battery_wh, int32_t* sunr
     return action;
   }
   if (*paused) return paused_action;
-  double hours = (double)(sr - now) / 3600.0;
+  double hours = d_div_const((double)(sr - now), 3600.0, 1.0 / 3600.0);       // == (double)(sr - now) / 3600.0
   double floating_charge = night_load_w * hours;
   const double left = batt - floating_charge;
   const bool short_of = own_capacity ? left < 0x1.31db22d0e5604p+6 : left / cap < 0.025;
@@ -597,7 +613,7 @@ BLE_FN void wind_axis(float q, float g0, float inv_step, float step, int n, int*
 }
 // float32 time coordinate of a query [h] (grid_based_wind_field.py:164-181: boomerang beyond 48 h, then float32)
 BLE_FN float wind_time_coord(int32_t elapsed_s) {
-  if (elapsed_s < 48 * 3600) return (float)elapsed_s / 3600.0f;
+  if (elapsed_s < 48 * 3600) return f_div_const((float)elapsed_s, 3600.0f, 1.0f / 3600.0f);   // == (float)elapsed_s / 3600.0f
   // _boomerang(t, 48): fp64 like the reference, then float32
   double t = (double)elapsed_s / 3600.0;
   long long cyc = (long long)(t / 48.0);
@@ -609,8 +625,8 @@ BLE_FN float wind_time_coord(int32_t elapsed_s) {
 BLE_FN WindQuery wind_query(float x_m, float y_m, float pressure, int32_t elapsed_s) {
   WindQuery wq;
   // x.kilometers -> clip -> float32 (correctly rounded fp32 division == fp64 division then cast)
-  float x_km = f_clamp(x_m / 1000.0f, -500.0f, 500.0f);
-  float y_km = f_clamp(y_m / 1000.0f, -500.0f, 500.0f);
+  float x_km = f_clamp(f_div_const(x_m, 1000.0f, 1.0f / 1000.0f), -500.0f, 500.0f);      // == x_m / 1000.0f
+  float y_km = f_clamp(f_div_const(y_m, 1000.0f, 1.0f / 1000.0f), -500.0f, 500.0f);
   float p = f_clamp(pressure, 5000.0f, 14000.0f);
   const float t_h = wind_time_coord(elapsed_s);
   wind_axis(x_km, -500.0f, 1.0f / 50.0f, 50.0f, 21, &wq.ix, &wq.wx);
@@ -626,7 +642,8 @@ BLE_FN WindQuery wind_query(float x_m, float y_m, float pressure, int32_t elapse
 struct WindQueryD { int ix, iy, it; double wx, wy, wt; };
 BLE_FN WindQueryD wind_query_xyt_f64(float x_m, float y_m, int32_t elapsed_s) {
   const WindQuery q = wind_query(x_m, y_m, 5000.0f, elapsed_s);
-  const float x_km = f_clamp(x_m / 1000.0f, -500.0f, 500.0f), y_km = f_clamp(y_m / 1000.0f, -500.0f, 500.0f);
+  const float x_km = f_clamp(f_div_const(x_m, 1000.0f, 1.0f / 1000.0f), -500.0f, 500.0f);
+  const float y_km = f_clamp(f_div_const(y_m, 1000.0f, 1.0f / 1000.0f), -500.0f, 500.0f);
   const float t_h = wind_time_coord(elapsed_s);
   WindQueryD d;
   d.ix = q.ix; d.iy = q.iy; d.it = q.it;
@@ -1029,7 +1046,7 @@ BLE_FN SunState sun_fast(float oms, float q, const SunThresholds& t, bool* near)
   r.day = d_day < 0.0f;          // el > -4.242  (sun_exact's comparisons, mapped)
   r.sh33 = d_s33 <= 0.0f;        // el >= 37.738...
   r.sh27 = d_s27 <= 0.0f;        // el >= 34.394...
-  *near = f_min(f_min(fabsf(d_day), fabsf(d_s33)), f_min(fabsf(d_s27), fabsf(d_r5))) < kSunBand;
+  *near = f_minnum(f_minnum(fabsf(d_day), fabsf(d_s33)), f_minnum(fabsf(d_s27), fabsf(d_r5))) < kSunBand;
   return r;
 }
 // solar.solar_calculator on BalloonState.latlng in fp64 (the oracle's chain op for op), cold.
@@ -1065,9 +1082,10 @@ BLE_FN float solar_panel_factor(const SunState& sun) {
   const float kCos65 = 0.42261826174f, kSin65 = 0.90630778704f;
   float sh33 = sun.sh33 ? 0.4392f : 1.0f;
   float sh27 = sun.sh27 ? 0.4392f : 1.0f;
-  float c35 = f_fma(sun.cos_el, kCos35, sun.sin_el * kSin35);
-  float c65 = f_fma(sun.cos_el, kCos65, sun.sin_el * kSin65);
-  return f_fma(4.0f * c35, sh33, 2.0f * c65 * sh27);
+  // 4 c35 and 2 c65 with the factors inside the constants (powers of two: the same bits as scaling the sums)
+  float c35x4 = f_fma(sun.cos_el, 4.0f * kCos35, sun.sin_el * (4.0f * kSin35));
+  float c65x2 = f_fma(sun.cos_el, 2.0f * kCos65, sun.sin_el * (2.0f * kSin65));
+  return f_fma(c35x4, sh33, c65x2 * sh27);
 }
 BLE_FN float solar_power_from_factor(float panel_factor, float attenuation) { return 210.0f * attenuation * panel_factor; }
 BLE_FN float solar_power(const SunState& sun, float attenuation) {

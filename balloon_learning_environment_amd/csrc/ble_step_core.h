@@ -137,7 +137,7 @@ BLE_FN void stride_acs(const double* acs_poly, int eff, double sp, double p, dou
   // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
   const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
   const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
-  const double prm1 = d_max(sp, 0.0) * rp;                // pressure_ratio - 1 (balloon.py:247-250)
+  const double prm1 = d_max(sp * rp, 0.0);                // pressure_ratio - 1 = max(sp, 0) / p (balloon.py:247-250; rp > 0)
   double w_down, mdot_down;
   acs_down_poly(acs_poly, prm1, &w_down, &mdot_down, K);
   *acs_w = eff == kDown ? (float)w_down : 0.0f;
@@ -283,8 +283,8 @@ constexpr int kTermSaveRows = 14, kTermSaveStride = 64;   // agent_step's parkin
 // The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
 // blend happens after the per-step constants so that the gather's latency is covered.
 BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int action, const WindCorners& corners, const WindQuery& wq,
-                      float noise_u, float noise_v, int substeps, const double* acs_poly, float* term_save, float* reward,
-                      uint32_t* flags) {
+                      float noise_u, float noise_v, int substeps, const double* acs_poly, const StrideK& K, float* term_save,
+                      float* reward, uint32_t* flags) {
   BLE_STEP_TICK(0);
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   const float p0_in = s.p;
@@ -336,7 +336,6 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   float acs_w = s.acs_power, mdot = s.mdot, charge = s.charge, load = s.load;
   int status = kOk;
 
-  const StrideK K = stride_k_vreg();     // (once per agent step: see d_vreg)
   // The stride loop is wave-uniform: every lane runs all `substeps` strides and the loop index is a scalar.  A lane whose episode ends
   // inside the step (balloon.py:327-328 breaks there; about one stride in 300 of a wave) parks the state it ended with in LDS
   // (term_save: kTermSaveRows floats per lane, row stride kTermSaveStride) on a rare path, keeps computing on a state nobody reads, and

@@ -36,7 +36,7 @@ extern "C" int emul_step_f32(const ble_state_f32* st, const uint8_t* action, con
     }
     uint32_t flags = 0; float r;
     float term_save[kTermSaveRows * kTermSaveStride];       // (the kernel's LDS parking area of a lane whose episode ends inside the step)
-    int eff = agent_step(s, c, hoist_constants(c), action[i], wc, wq, nu, nv, substeps, acs_poly, term_save, &r, &flags);
+    int eff = agent_step(s, c, hoist_constants(c), action[i], wc, wq, nu, nv, substeps, acs_poly, stride_k_literal(), term_save, &r, &flags);
     flags_all |= flags;
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
     st->internal_temperature[i] = s.t_int; st->envelope_volume[i] = s.vol; st->superpressure[i] = s.sp;
@@ -143,4 +143,24 @@ extern "C" void emul_decode_flow(int64_t n, const float* flow, float* grid) {
       decode_flow_point(flow + e * 4410 + f, ij / 21, ij % 21, tap0, w1, &u, &v);
       grid[(e * 39690 + idx) * 2] = u; grid[(e * 39690 + idx) * 2 + 1] = v;
     }
+}
+
+// f_div_const / d_div_const against the true divisions over the ranges the transition uses them on (every float32 position from
+// 2^-100 m to 600 km and zero, every whole second of the forecast's 48 h, every whole second of a night): the number of disagreeing inputs
+extern "C" long long emul_check_constant_divisions() {
+  long long bad = 0;
+  const float top = 6.0e5f;
+  uint32_t top_bits; __builtin_memcpy(&top_bits, &top, 4);
+  const float low = 0x1p-100f;             // (below it x / 1000 is subnormal and the corrected quotient may sit one subnormal step off)
+  uint32_t low_bits; __builtin_memcpy(&low_bits, &low, 4);
+  bad += f_div_const(0.0f, 1000.0f, 1.0f / 1000.0f) != 0.0f;
+  for (uint32_t b = low_bits; b <= top_bits; ++b) {
+    float x; __builtin_memcpy(&x, &b, 4);
+    const float q = f_div_const(x, 1000.0f, 1.0f / 1000.0f), t = x / 1000.0f;
+    const float qn = f_div_const(-x, 1000.0f, 1.0f / 1000.0f);
+    bad += (q != t) + (qn != -t);
+  }
+  for (int32_t s = 0; s < 48 * 3600; ++s) bad += f_div_const((float)s, 3600.0f, 1.0f / 3600.0f) != (float)s / 3600.0f;
+  for (int32_t s = -2 * 86400; s <= 2 * 86400; ++s) bad += d_div_const((double)s, 3600.0, 1.0 / 3600.0) != (double)s / 3600.0;
+  return bad;
 }

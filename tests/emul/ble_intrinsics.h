@@ -25,6 +25,7 @@ BLE_FN bool wave_any(bool c) { return c; }
 BLE_FN int i_opaque(int v) { return v; }
 BLE_FN double d_rint(double x) { return rint(x); }
 BLE_FN double d_sqrt(double x) { return sqrt(x); }
+BLE_FN float f_minnum(float a, float b) { return fminf(a, b); }
 BLE_FN double d_min(double a, double b) { return fmin(a, b); }
 BLE_FN double d_max(double a, double b) { return fmax(a, b); }
 BLE_FN double d_rcp_seed(double x) { return (double)(1.0f / (float)x); }

@@ -315,3 +315,13 @@ def test_power_safety_thresholds_are_the_reference_divisions():
   assert np.array_equal(x.astype(np.float64) / cap < 0.05, x < t1)
   y = rng.uniform(76.0, 77.0, 200000)
   assert np.array_equal(y / cap < 0.025, y < t2)
+
+
+def test_constant_divisions_are_correctly_rounded():
+  """f_div_const / d_div_const (csrc/ble_physics.h: product with the rounded reciprocal + one fma-exact remainder correction) give
+  the bits of the division they replace on every input the transition can hand them: all float32 positions from 2^-100 m to 600 km
+  and zero (the forecast clips at 500 km; below 2^-100 m the quotient is subnormal), every whole second of the forecast's 48 hours, every whole second of a night."""
+  import ctypes
+  lib = _load_emul().lib()
+  lib.emul_check_constant_divisions.restype = ctypes.c_longlong
+  assert lib.emul_check_constant_divisions() == 0
