@@ -37,6 +37,11 @@ using namespace ble;
 namespace {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
+// ble_step_kernel's workgroup: BLE_STEP_BLOCK / 64 independent wavefronts (they share the ACS table's LDS copy and one barrier at entry)
+#ifndef BLE_STEP_BLOCK
+#define BLE_STEP_BLOCK 64
+#endif
+constexpr int kStepBlock = BLE_STEP_BLOCK;
 
 __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags) {
   // wave-level OR, one atomic per wave at most (normally none)
@@ -58,7 +63,7 @@ __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags
 // ble_wind_noise_f32 (wind_noise_cached), hence the same bits as ble_wind_noise_f32 + ble_step_f32 step by step.  A
 // separate instantiation: the noise-free rollout keeps its register allocation.
 template <bool kNoise>
-__global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
+__global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
                                                           int64_t grid_env_stride,
                                                           const float* __restrict__ noise_uv,
@@ -71,10 +76,11 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   __shared__ double acs_poly[kAcsPolyDoubles];
   // kNoise: the harmonics' seeds and offsets of this wave's environments, fetched once per launch ([50][64] words)
-  __shared__ uint32_t noise_draws[kNoise ? 50 * kBlock : 1];
-  __shared__ float term_save[kTermSaveRows * kTermSaveStride];       // where a lane parks the state its episode ended with (agent_step)
-  const int64_t i = (int64_t)blockIdx.x * lanes + threadIdx.x;
-  const bool in_range = i < n && (int)threadIdx.x < lanes;
+  __shared__ uint32_t noise_draws[kNoise ? 50 * kStepBlock : 1];
+  __shared__ float term_save[kTermSaveRows * kStepBlock];       // where a lane parks the state its episode ended with (agent_step): one block per wave
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * (kStepBlock / 64) + wave) * lanes + lane;
+  const bool in_range = i < n && lane < lanes;
   uint32_t flags = 0;
   EnvRegs s;
   EnvConst c;
@@ -96,8 +102,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     live = s.status == kOk;
   }
   // the ACS table's piecewise cubics: a compile-time table, constant memory -> LDS (the loop reads it by a per-lane index)
-  acs_poly[threadIdx.x] = kAcsPoly.c[threadIdx.x];
-  if (threadIdx.x < kAcsPolyDoubles - kBlock) acs_poly[kBlock + threadIdx.x] = kAcsPoly.c[kBlock + threadIdx.x];
+  for (int j = (int)threadIdx.x; j < kAcsPolyDoubles; j += kStepBlock) acs_poly[j] = kAcsPoly.c[j];
   BLE_STEP_MARK(1);
   __syncthreads();
   BLE_STEP_MARK(2);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
     }
   }
   if (kNoise && in_range)
-    noise_draws_fetch(gen.seed, (uint64_t)i, gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n, noise_draws + threadIdx.x, kBlock);
+    noise_draws_fetch(gen.seed, (uint64_t)i, gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n, noise_draws + threadIdx.x, kStepBlock);
   const StrideK K = stride_k_vreg();      // the stride loop's fp64 constants as register pairs, once per launch (see d_vreg)
   BLE_STEP_MARK(3);
 #pragma unroll 1
@@ -129,13 +134,13 @@ __global__ __launch_bounds__(kBlock) void ble_step_kernel(ble_state_f32 st, cons
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
       float nu = 0.0f, nv = 0.0f;
       if (kNoise) {
-        wind_noise_from_rows(s.x, s.y, s.p, s.t_elapsed, noise_draws + threadIdx.x, kBlock, &nu, &nv);
+        wind_noise_from_rows(s.x, s.y, s.p, s.t_elapsed, noise_draws + threadIdx.x, kStepBlock, &nu, &nv);
         // the noise is a VALUE here as it is between ble_wind_noise_f32 and ble_step_f32: without this the compiler is free to
         // fuse the generator's last multiplication into agent_step's `u += noise_u` (one rounding instead of two)
         asm volatile("" : "+v"(nu), "+v"(nv));
       } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
-      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, K, term_save + threadIdx.x, &r, &flags);
+      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, K, term_save + wave * (kTermSaveRows * kTermSaveStride) + lane, &r, &flags);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
         flags |= kFlagNonFinite;
       reward[o] = r;
@@ -646,7 +651,7 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
     return launch_split(st, action, wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags, active_count, n,
                         substeps, 1, stream);
   const int lanes = env_lanes();
-  BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+  BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
                      active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr});
   return launch_status();
@@ -665,11 +670,11 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
     return launch_split(st, action, wind_grid, grid_env_stride, nullptr, reward, terminal, nullptr, err_flags, active_count, n, substeps,
                         n_steps, stream, noise);
   if (noise != nullptr) {
-    BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+    BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
                active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache});
   } else {
-    BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes)), dim3(kBlock), 0, (hipStream_t)stream, *st, action,
+    BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
                active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr});
   }
