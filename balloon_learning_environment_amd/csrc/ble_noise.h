@@ -37,6 +37,22 @@ BLE_CONST_TABLE HarmonicTable kHarmonics = {{{0.1445f, 702.269f, 2116.987f, 2587
                                              {0.1186f, 47.500f, 43.048f, 66.553f, 8.424f},
                                              {0.1066f, 3663.291f, 232.023f, 7499.741f, 225.0f}}};
 BLE_FN Harmonic harmonic_params(int comp, int h) { return kHarmonics.h[5 * comp + h]; }
+// RN(1 / spacing) of the same table: coordinate / spacing is evaluated as f_div_const (ble_physics.h: reciprocal product + one exact-remainder
+// correction = the bits of the division, 3 issue slots instead of 12; four divisions per harmonic, forty per env-step)
+struct HarmonicRcp { float x, y, p, t; };
+struct HarmonicRcpTable { HarmonicRcp h[10]; };
+constexpr HarmonicRcp harmonic_rcp_of(float xs, float ys, float ps, float ts) { return HarmonicRcp{1.0f / xs, 1.0f / ys, 1.0f / ps, 1.0f / ts}; }
+BLE_CONST_TABLE HarmonicRcpTable kHarmonicRcp = {{harmonic_rcp_of(702.269f, 2116.987f, 2587.802f, 245.0f),
+                                                  harmonic_rcp_of(1483.570f, 752.124f, 646.208f, 16.39f),
+                                                  harmonic_rcp_of(276.810f, 147.040f, 587.702f, 3.836f),
+                                                  harmonic_rcp_of(10214.525f, 1512.216f, 965.629f, 41.780f),
+                                                  harmonic_rcp_of(181.286f, 420.942f, 8500.0f, 245.0f),
+                                                  harmonic_rcp_of(1974.228f, 2028.814f, 713.697f, 26.435f),
+                                                  harmonic_rcp_of(699.738f, 541.845f, 632.116f, 9.530f),
+                                                  harmonic_rcp_of(217.750f, 196.522f, 686.825f, 3.546f),
+                                                  harmonic_rcp_of(47.500f, 43.048f, 66.553f, 8.424f),
+                                                  harmonic_rcp_of(3663.291f, 232.023f, 7499.741f, 225.0f)}};
+BLE_FN HarmonicRcp harmonic_rcp(int comp, int h) { return kHarmonicRcp.h[5 * comp + h]; }
 constexpr float kSimplex4Variance = 0.088392f;   // of simplex4() below: measured 0.0889 (tests/test_gpu_noise.py) == the reference's SIMPLEX_VARIANCE (:70)
 constexpr float kNoiseVariance = 1.02f;          // simplex_wind_noise.py:73
 
@@ -110,8 +126,9 @@ BLE_FN float noise_harmonic_value(int comp, int h, const HarmonicDraw& d, float 
   BLE_NO_CONTRACT
   const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
   const Harmonic hp = harmonic_params(comp, h);
-  return magnitude * simplex4(x_km / hp.x_spacing + d.ox, y_km / hp.y_spacing + d.oy, pressure / hp.p_spacing + d.op,
-                              t_h / hp.t_spacing + d.ot, d.hseed);
+  const HarmonicRcp hr = harmonic_rcp(comp, h);
+  return magnitude * simplex4(f_div_const(x_km, hp.x_spacing, hr.x) + d.ox, f_div_const(y_km, hp.y_spacing, hr.y) + d.oy,
+                              f_div_const(pressure, hp.p_spacing, hr.p) + d.op, f_div_const(t_h, hp.t_spacing, hr.t) + d.ot, d.hseed);
 }
 BLE_FN void noise_accumulate(NoiseAccumulator& a, int comp, int h, float nz) {
   BLE_NO_CONTRACT

@@ -160,6 +160,19 @@ extern "C" long long emul_check_constant_divisions() {
     const float qn = f_div_const(-x, 1000.0f, 1.0f / 1000.0f);
     bad += (q != t) + (qn != -t);
   }
+  // the wind noise's coordinate / spacing: every mantissa (two binades: the corrected quotient of normal numbers does not depend on the
+  // exponent) against each of the forty spacings
+  for (int k = 0; k < 10; ++k) {
+    const Harmonic hp = kHarmonics.h[k]; const HarmonicRcp hr = kHarmonicRcp.h[k];
+    const float b[4] = {hp.x_spacing, hp.y_spacing, hp.p_spacing, hp.t_spacing}, rb[4] = {hr.x, hr.y, hr.p, hr.t};
+    for (int a = 0; a < 4; ++a) {
+      bad += rb[a] != 1.0f / b[a];
+      for (uint32_t m = 0x3f800000u; m < 0x40800000u; ++m) {
+        float x; __builtin_memcpy(&x, &m, 4);
+        bad += f_div_const(x, b[a], rb[a]) != x / b[a];
+      }
+    }
+  }
   for (int32_t s = 0; s < 48 * 3600; ++s) bad += f_div_const((float)s, 3600.0f, 1.0f / 3600.0f) != (float)s / 3600.0f;
   for (int32_t s = -2 * 86400; s <= 2 * 86400; ++s) bad += d_div_const((double)s, 3600.0, 1.0 / 3600.0) != (double)s / 3600.0;
   return bad;
