@@ -72,11 +72,16 @@ BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
 BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h) {
   BLE_NO_CONTRACT
   float t = 0.6f - x * x - y * y - z * z - w * w;
-  if (t < 0.0f) return 0.0f;
+  // a corner farther than sqrt(0.6) contributes nothing: t clamped to 0 makes its term (+-)0, which leaves the sum's bits alone -- no
+  // branch (with 64 environments in a wave some lane always takes the other side)
+  t = t < 0.0f ? 0.0f : t;
   const uint32_t g = h >> 27;                      // 5 bits
   const uint32_t zero = g >> 3;
-  float a = zero == 0 ? y : x, b = zero <= 1 ? z : y, c = zero <= 2 ? w : z;
-  a = (g & 1u) ? -a : a; b = (g & 2u) ? -b : b; c = (g & 4u) ? -c : c;
+  const float a0 = zero == 0 ? y : x, b0 = zero <= 1 ? z : y, c0 = zero <= 2 ? w : z;
+  // (g & 1) ? -a : a ... as sign-bit arithmetic: bit k of g moved to bit 31 and xor-ed in (no compare, no select)
+  const float a = u32_bits_float(float_bits_u32(a0) ^ (g << 31));
+  const float b = u32_bits_float(float_bits_u32(b0) ^ ((g << 30) & 0x80000000u));
+  const float c = u32_bits_float(float_bits_u32(c0) ^ ((g << 29) & 0x80000000u));
   t *= t;
   return t * t * (a + b + c);
 }
