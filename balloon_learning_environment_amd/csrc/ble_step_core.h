@@ -342,8 +342,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   // takes the parked values back after the loop -- a divergent `break` cost the common stride 20 instructions of exec-mask bookkeeping.
   float* const term_word = term_save + (kTermSaveRows - 1) * kTermSaveStride;   // status | strides run << 8; 0 while the episode runs
   *term_word = 0.0f;
-#pragma unroll 1
-  for (int k = 0; k < substeps; ++k) {
+  auto stride = [&](const int k) __attribute__((always_inline)) {
     const float pf = (float)p;
     const double rp = d_rcp(p);
     // ---- sun position at (x, y, date_time) of the OLD state (balloon.py:451-452)
@@ -396,7 +395,12 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
       const int strides = i_opaque(k + 1);          // (otherwise the common path carries (k + 1) << 8 as an induction variable for this block)
       *term_word = __builtin_bit_cast(float, st | (strides << 8));
     }
-  }
+  };
+  // two strides per iteration: the loop-carried values alternate between two sets of registers instead of being copied
+  int ks = 0;
+#pragma unroll 1
+  for (; ks + 1 < substeps; ks += 2) { stride(ks); stride(ks + 1); }
+  if (ks < substeps) stride(ks);
   BLE_STEP_TICK(5);
   s.x = x; s.y = y; s.p = (float)p; s.t_amb = (float)t_amb; s.t_int = (float)t_int; s.vol = (float)vol;
   s.sp = (float)sp; s.n_air = (float)n_air; s.batt = batt;
