@@ -8,6 +8,7 @@ tests/helpers.py (fields such as x, y or acs_power pass through zero).
 Identical inputs: the oracle is handed exactly the float32 values the kernel reads.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -565,6 +566,25 @@ def test_wide_domain_states_every_env(ble):
   total, outliers, worst = _sampled_batch_parity(ble, n, steps=3, seed=77, threads=16, init=wide_domain_states(n, 77))
   print(f'wide-domain states: {total} env-steps, worst relative error {worst:.3g}')
   assert total > 25000 and outliers == 0
+
+
+def test_one_lane_kernel_episodes_ending_inside_a_step_match_oracle(ble):
+  """The one-lane kernel's stride loop is wave-uniform: a lane whose episode ends inside an agent step parks its final state in LDS on a
+  rare path and takes it back after the loop (csrc/ble_step_core.h, agent_step).  Forced here (BLE_STEP_SPLIT=0: the host would pick the
+  four-wave kernel at this size) on a batch in which a good part of the environments run out of power or burst inside the rollout, every
+  environment against the oracle from the kernel's own pre-step state: status, strides run (time_elapsed_s), state, reward, terminal."""
+  from balloon_learning_environment_amd import reset_host
+  n = 4096
+  init = reset_host.sample_initial_state(n, seed=4242)
+  init['battery_charge'][: n // 4] = np.linspace(0.05, 30.0, n // 4).astype(np.float32)          # out of power within a few strides .. steps
+  init['superpressure'][n // 4: n // 4 + 256] = np.linspace(2300.0, 2379.0, 256).astype(np.float32)   # close to the burst limit
+  os.environ['BLE_STEP_SPLIT'] = '0'
+  try:
+    total, outliers, worst = _sampled_batch_parity(ble, n, 6, seed=4243, threads=8, init=init)
+  finally:
+    del os.environ['BLE_STEP_SPLIT']
+  assert outliers == 0, (outliers, total, worst)
+  assert total < 6 * n - 200                       # (episodes did end: the live count of later steps is smaller)
 
 
 def test_config_4096_envs_random_policy(ble):
