@@ -1,7 +1,7 @@
 // ble_kernels.hip -- gfx950 (MI355X, CDNA4) kernels and the C ABI of libble_hip.so.
 //
-// Execution model: one wavefront lane per environment, 64-thread workgroups (one wave),
-// so N = 65 536 environments is 1 024 workgroups = one wave on every SIMD of the 256 CUs.
+// Execution model: one wavefront lane per environment, 256-thread workgroups of four independent waves,
+// so N = 65 536 environments is 256 workgroups = one per CU, one wave on every SIMD of the 256 CUs.
 // The state is struct-of-arrays: every load/store below is a fully coalesced
 // 64-lane x 4 B (or 1 B) transaction.  The 317 KB wind grid is shared by all lanes and is
 // served from the per-XCD L2 after first touch; each lane gathers its 16 corners as
@@ -37,9 +37,11 @@ using namespace ble;
 namespace {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
-// ble_step_kernel's workgroup: BLE_STEP_BLOCK / 64 independent wavefronts (they share the ACS table's LDS copy and one barrier at entry)
+// ble_step_kernel's workgroup: BLE_STEP_BLOCK / 64 independent wavefronts (they share the ACS table's LDS copy and one barrier at entry).
+// 256 = one workgroup per CU at 65 536 environments, a wave on each of its SIMDs: a quarter of the dispatches of 64-thread workgroups --
+// measured 15.5-15.7 against 15.7-15.9 us per fused step and 23.6-23.8 against 24.2 us per one-step launch (profiles/r04_raw/step_block_ab.txt)
 #ifndef BLE_STEP_BLOCK
-#define BLE_STEP_BLOCK 64
+#define BLE_STEP_BLOCK 256
 #endif
 constexpr int kStepBlock = BLE_STEP_BLOCK;
 
