@@ -26,7 +26,11 @@ BLE_FN double d_fma(double a, double b, double c) { return __builtin_fma(a, b, c
 BLE_FN double d_vreg(double k) { asm("" : "+v"(k)); return k; }
 // true if the predicate holds on any lane of the wavefront: a rare per-lane path guarded by `if (wave_any(c)) if (c) {...}` costs the common
 // case a compare and ONE scalar branch (s_cbranch_vccnz) instead of an exec-mask save / branch / restore
+#ifdef BLE_NO_VOTE      // (A/B knob: the compiler's own exec-mask form of the rare paths)
+BLE_FN bool wave_any(bool c) { return c; }
+#else
 BLE_FN bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+#endif
 // an integer the optimiser cannot see through: used inside rarely taken blocks so that the common path does not carry their
 // induction variables (10 k, (double)k, (k + 1) << 8 ...)
 BLE_FN int i_opaque(int v) { asm("" : "+v"(v)); return v; }
