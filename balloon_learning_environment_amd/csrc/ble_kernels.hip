@@ -12,7 +12,7 @@
 #include <stdlib.h>
 
 // Instrumentation hooks of ble_step_kernel: empty in the product build.  A profiling build
-// (profiles/build_variant.sh ... -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
+// (profiles/build_variant.sh ... -DBLE_STEP_BLOCK=64 -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
 // marks from that header, which is not part of the package.
 #ifdef BLE_STEP_INSTR_HEADER
 #include BLE_STEP_INSTR_HEADER

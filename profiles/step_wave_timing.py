@@ -1,5 +1,6 @@
 """Where the time of ONE ble_step_kernel launch goes, wave by wave (profiling build, see profiles/instr/ble_step_instr.h):
-   bash profiles/build_variant.sh step_timing '-DBLE_STEP_INSTR_HEADER="../../profiles/instr/ble_step_instr.h"'
+   bash profiles/build_variant.sh step_timing -DBLE_STEP_BLOCK=64 '-DBLE_STEP_INSTR_HEADER="../../profiles/instr/ble_step_instr.h"'
+   (one wave per workgroup: the marks are indexed by blockIdx.x; the product build runs four waves per workgroup)
    BLE_HIP_LIB=build_ab/libble_step_timing.so python profiles/step_wave_timing.py [n_envs]
 Launches of K = 1 and K = 32 agent steps; every wave records its entry / exit wall clock (100 MHz) and the shader-clock length
 of its phases.  Prints the launch span (first entry -> last exit), the dispatch ramp, the finish dispersion and the phases."""
