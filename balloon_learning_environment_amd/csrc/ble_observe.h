@@ -26,10 +26,12 @@
 //              (= K* K^-1 y), deviation = (s^2 - v^2 / d) / s^2
 //   phase 5    (uncertainty, bearing, magnitude) triples centred on the balloon's level
 //
-// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 58 KB (factor) + 8.7 KB (block
-// inverses, aliased with the solar table) + 12 KB = 79 KB and <= 256 registers: two workgroups per CU,
-// which is what hides the latency-bound single-wave phases.  DESIGN.md 3b has the cycle budget.
+// All GP algebra is fp64 like the reference's (cond(K) ~ 3e4).  LDS: 12 KB of row vectors and tables FIRST (inside the
+// 16-bit offset of ds_read / ds_write), 8.7 KB (block inverses, aliased with the solar table), then the 58 KB factor
+// = 79 KB and <= 256 registers: two workgroups per CU, which is what hides the latency-bound single-wave phases.
+// DESIGN.md 3b has the cycle budget.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "ble_reset.h"
@@ -84,12 +86,29 @@ struct GpHistory {
   int64_t chol_stride; // doubles between consecutive environments' slabs (>= kCholStride, checked by the host entry point)
 };
 
-struct ObsShared {
-  double l_guard[16];                    // zeros in front of L: the sweep pads the factor at the TOP (virtual identity rows
-                                         // 0 .. pad - 1 of the MFMA tiles), so "columns" -pad .. -1 of the first rows are read
-  double L[kCholTri];                    // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
-                                         // below the diagonal, d on it
-  union {
+// LDS layout: everything the sweep addresses with a per-lane base + a compile-time offset sits in the first 24 KB,
+// inside the 16-bit immediate of ds_read / ds_write; the 58 KB factor comes last.  (With the factor first -- rounds 1-4 --
+// the small arrays lay above 64 KB: every access took a v_mov of its base and a v_add, ~250 of the 850 vector instructions of
+// a wave's sum pass and tail.)
+struct alignas(16) ObsShared {
+  double exp2_frac[64];                  // s^2 2^(k / 64): the kernel matrix's exp table (gp_exp_neg_scaled)
+  double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column, in units of (ln2 / 32)^2
+  double loc[kGpRows][4];                // x, y, p * (32 / ln2) / 326 Pa, t of the observations in the window
+  double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
+  double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
+  double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
+  double column[20];                     // the (x, y, t)-blended forecast at the 10 pressure nodes, (u, v) interleaved
+  double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
+  double lev[20], pot[20];
+  double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
+  double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
+  double el_now, flux_now, el_next, p_floor;
+  int lo_idx, hi_idx;                    // first / last reachable level of the 181
+  int n_obs;
+  int range_ok;
+  double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
+  alignas(16) double pb[kGpMax][2];      // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
+  alignas(16) union {
     struct {
       double el_table[kElevTable];       // phases 0-1: solar elevation at now + 180 s * (k - 240)
       double pad0;
@@ -98,63 +117,52 @@ struct ObsShared {
     };
     double dinv[kGpRows / 16][138];      // [136]: a zero, read by the lanes above the diagonal of the packed triangle
   };
-  double pb[kGpMax][2];                  // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
-  double loc[kGpRows][4];                // x, y, p / 326 Pa, t of the observations in the window
-  double a[kGpRows];                     // scaled squared (x, y, t) distance to the query column
-  double z[4][kGpRows];                  // 0, 1: error components, then Lt^-1 y;  2: Lt^-1 k_new;  3: Lt^-1 e_0
-  double eph[6][3];                      // (sin decl, cos decl, equation-of-time term) at 6 nodes spanning the elevation table
-  double site[3];                        // sin lat, cos lat, lng [deg] of the balloon (computed by one wave)
-  double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
-  double exp2_frac[64];                  // s^2 2^(-j / 64): s^2 exp(-r) = 2^-k * (s^2 2^(-j/64)) * P4(rem), |rem| <= ln2 / 128
-  double zeros16[16];                    // the off-diagonal part of a virtual identity row inside a diagonal block
-  double last[4];                        // new row: zeta_u, zeta_v of the newest observation, its d, (Lt^-1 e_0) there
-  double inv_diag[kGpRows];              // 1 / d[i]  (1 / L[i][i] while the refit Cholesky runs)
-  double lev[20], pot[20];
-  double el_now, flux_now, el_next, p_floor;
-  int lo_idx, hi_idx;                    // first / last reachable level of the 181
-  double column[20];                     // the (x, y, t)-blended forecast at the 10 pressure nodes, (u, v) interleaved
-  int n_obs;
-  int range_ok;
+  alignas(16) double l_guard[16];        // zeros in front of L: the sweep pads the factor at the TOP (virtual identity rows
+                                         // 0 .. pad - 1 of the MFMA tiles), so "columns" -pad .. -1 of the first rows are read
+  double L[kCholTri];                    // K + noise = Lt D Lt^T, packed lower triangle of rows 0 .. 119: unit-lower Lt
+                                         // below the diagonal, d on it
   BLE_OBS_INSTR_SHARED
 };
+static_assert(offsetof(ObsShared, L) % 16 == 0 && offsetof(ObsShared, pb) % 16 == 0 && offsetof(ObsShared, pb3) % 16 == 0 &&
+              offsetof(ObsShared, loc) % 16 == 0, "double2 views of L, pb, pb3 need 16-byte alignment");
+static_assert(offsetof(ObsShared, l_guard) + sizeof(double[16]) == offsetof(ObsShared, L), "the zero guard sits directly in front of L");
 static_assert(sizeof(ObsShared) <= 80 * 1024, "two workgroups per CU need <= 80 KB of LDS each");
 
-// s^2 exp(-r), r >= 0, for the kernel matrix K* (the table carries the scale s^2 and the sign: tab[j] = s^2 2^(-j/64)):
-// r = (64 k + j) ln2 / 64 - rem, |rem| <= ln2 / 128, degree-4 Taylor in rem (truncation 4e-14 relative: with
-// cond(K) ~ 3e4 that is 1e-9 on the posterior, four orders below the parity bar; the 32-entry / degree-5 form it
-// replaces was 2e-15 and one FMA longer).  One fused reduction step: n ln2/64 is exact inside the FMA and n <= ~3000,
-// so the rounding of the constant costs <= 3e-15 absolute.
-// 10 fp64 instructions (the table-free d_exp_fast: 20 + 16 constants) -- the sweep evaluates it 64 times per lane.
-__device__ __forceinline__ double exp_neg_tab(double r, const double* tab) {
-  const double n = d_rint(r * 92.33248261689365806);                  // 64 / ln 2
-  const double rem = d_fma(n, 1.08304246962491454596e-02, -r);        // ln2 / 64
-  const int ni = (int)n;
-  const double t = tab[ni & 63];
-  const double pr = d_fma(rem, d_fma(rem, d_fma(rem, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
-  return d_ldexp(d_fma(t * rem, pr, t), -(ni >> 6));
+// ---- the kernel matrix entry s^2 exp(-sqrt(a + dp^2)) on PRE-SCALED inputs (round 5: 22 -> 17 vector instructions per entry).
+// Distances are carried in units of ln2 / 32 (kGpKappa = 32 / ln 2: the squared (x, y, t) distance `a` times kappa^2, pressures
+// times kappa / 326 Pa), so that twice the square root IS the exponent in units of ln2 / 64 and no multiplication by 64 / ln2
+// is left on the chain.
+//   rs = 2 sqrt(X) = g (3 - g y),  y = rsq(X), g = X y     -- one Newton step written on the product: 4 instructions (the coupled
+//        (g, h) form took 5); second-order error 3/8 (1 - X y^2)^2 ~ 4e-15 relative, rounding <= 3e-16
+//   f = fract(rs) in [0, 1),  nn = trunc(-rs) = -floor(rs)  -- v_fract_f64 + v_cvt_i32_f64 with a free negation (no v_rndne, no
+//        n ln2/64 - r fma, no integer negation)
+//   s^2 exp(-r) = 2^(-rs / 64) s^2 = 2^(nn >> 6) * (s^2 2^((nn & 63) / 64)) * 2^(-f / 64)
+// tab[k] = s^2 2^(k / 64); 2^(-f / 64) on [0, 1] by its degree-4 minimax polynomial (Remez, |error| <= 2.5e-15 relative; the
+// centred Taylor form it replaces was 4e-14 and took the same five instructions).
+constexpr double kGpKappa = 46.16624130844683;            // 32 / ln 2
+constexpr double kGpInvKappa = 0.02166084939249829;       // ln 2 / 32
+constexpr double kGpTwoKappa = 92.33248261689366;         // 64 / ln 2
+__device__ __forceinline__ double two_sqrt(double X) {     // 2 sqrt(X), X >= 1e-300
+  const double y = d_rsq_seed(X);
+  const double g = X * y;
+  return g * d_fma(-g, y, 3.0);
 }
-// The same in two stages, so that the table read of stage A can fly under other work (the sweep puts a row block's
-// MFMAs between them): A = reduction + table request, B = polynomial, scale, exponent.
-struct ExpStage { double rem, t; int ni; };
-__device__ __forceinline__ ExpStage exp_neg_stage_a(double r, const double* tab) {
+struct ExpStage { double f, t; int nn; };
+// stage A = reduction + table request, stage B = polynomial, scale, exponent (the sweep puts a row block's MFMAs between
+// them so that the table read flies under other work)
+__device__ __forceinline__ ExpStage exp_scaled_stage_a(double rs, const double* tab) {
   ExpStage e;
-  const double n = d_rint(r * 92.33248261689365806);
-  e.rem = d_fma(n, 1.08304246962491454596e-02, -r);
-  e.ni = (int)n;
-  e.t = tab[e.ni & 63];
+  e.f = __builtin_amdgcn_fract(rs);
+  e.nn = (int)(-rs);
+  e.t = tab[e.nn & 63];
   return e;
 }
-__device__ __forceinline__ double exp_neg_stage_b(const ExpStage& e) {
-  const double pr = d_fma(e.rem, d_fma(e.rem, d_fma(e.rem, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
-  return d_ldexp(d_fma(e.t * e.rem, pr, e.t), -(e.ni >> 6));
+__device__ __forceinline__ double exp_scaled_stage_b(const ExpStage& e) {
+  const double q = d_fma(e.f, d_fma(e.f, d_fma(e.f, d_fma(e.f, 5.701900737872891e-10, -2.117286661914034e-07), 5.864904858491492e-05),
+                               -0.010830424696128488), 0.9999999999999976);
+  return d_ldexp(e.t * q, e.nn >> 6);
 }
-// sqrt(x), x >= 1e-300: one coupled Newton step on (g, h) = (x y, y / 2) from the 5e-8 seed y = rsq(x): 4e-15 relative,
-// five instructions
-__device__ __forceinline__ double sqrt_coupled(double x) {
-  const double y = d_rsq_seed(x);
-  const double g = x * y, h = 0.5 * y;
-  return d_fma(g, d_fma(-g, h, 0.5), g);
-}
+__device__ __forceinline__ double gp_exp_neg_scaled(double rs, const double* tab) { return exp_scaled_stage_b(exp_scaled_stage_a(rs, tab)); }
 
 // inclusive prefix sum over the 64 lanes of a wave on DPP moves (no LDS round trips, unlike __shfl_up): Hillis-Steele
 // inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of a row into the next row (row_bcast:15 on rows 1
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   if (wave == 2) {
     // (this wave has the shortest role: it also fills the exp table and writes the state-only ambient features)
-    sh.exp2_frac[lane] = kGpSigma2 * d_exp_fast((double)lane * (-6.93147180559945286227e-01 / 64.0));
+    sh.exp2_frac[lane] = kGpSigma2 * d_exp_fast((double)lane * (6.93147180559945286227e-01 / 64.0));     // s^2 2^(k / 64)
     if (lane < 16) { sh.zeros16[lane] = 0.0; sh.l_guard[lane] = 0.0; }
     if (lane == 63) {
       // -- the ambient features that need only the state (features.py:400-470);   Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
@@ -582,13 +590,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   if (wave < 2 && valid) {
     const int at = pos + (wave == 1 ? count_w0 : 0) - drop;
     if (at >= 0) {
-      sh.loc[at][2] = (double)op * (1.0 / 326.0);
+      sh.loc[at][2] = (double)op * (kGpKappa / 326.0);
       if (!incremental) {        // positions, times and raw errors: only the refit builds K and solves for zeta
         sh.loc[at][0] = (double)ox; sh.loc[at][1] = (double)oy; sh.loc[at][3] = (double)ot;
         sh.z[0][at] = (double)oeu; sh.z[1][at] = (double)oev;
       }
-      const double dx = ((double)ox - x) * (1.0 / 357000.0), dy = ((double)oy - y) * (1.0 / 357000.0),
-                   dt = ((double)ot - (double)elapsed) * (1.0 / 34560.0);
+      const double dx = ((double)ox - x) * (kGpKappa / 357000.0), dy = ((double)oy - y) * (kGpKappa / 357000.0),
+                   dt = ((double)ot - (double)elapsed) * (kGpKappa / 34560.0);          // (units of ln2 / 32: gp_exp_neg_scaled)
       sh.a[at] = dx * dx + dy * dy + dt * dt + 1e-300;     // (the guard keeps rsq finite when an observation sits at the query)
     }
   }
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       if (i < n_obs) {
         // (a - b) / length_scale as a multiplication by the rounded reciprocal: 1e-16 relative
         const double d0 = (sh.loc[i][0] - sh.loc[j][0]) * (1.0 / 357000.0), d1 = (sh.loc[i][1] - sh.loc[j][1]) * (1.0 / 357000.0),
-                     d2 = sh.loc[i][2] - sh.loc[j][2], d3 = (sh.loc[i][3] - sh.loc[j][3]) * (1.0 / 34560.0);
+                     d2 = (sh.loc[i][2] - sh.loc[j][2]) * kGpInvKappa, d3 = (sh.loc[i][3] - sh.loc[j][3]) * (1.0 / 34560.0);
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         const double r = r2 > 0.0 ? r2 * d_rsqrt(r2) : 0.0;
         k_ij = kGpSigma2 * d_exp_fast(-r) + (i == j ? kGpNoise2 : 0.0);
@@ -1050,16 +1058,26 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     if (kFirst && wave == 0 && jq == c_new) level[0] = p;     // column c_new: the newest observation's own pressure
     double level_s[NT];                             // in units of the pressure length scale
 #pragma unroll
-    for (int t = 0; t < NT; ++t) level_s[t] = level[t] * (1.0 / 326.0);
+    for (int t = 0; t < NT; ++t) level_s[t] = level[t] * (kGpKappa / 326.0);
     const double y_last_u = (double)err_u, y_last_v = (double)err_v;   // raw errors of the newest observation (when has_last)
     const int spec_sel = jq == c_e0 ? 3 : (jq < 2 ? jq : 0);        // refit: columns 0, 1 = y_u, y_v from z[0], z[1]
     const bool use_spec = jq < kSpecial && jq != c_new;
+    // Row blocks below the first: the kernel-matrix value of a special column is multiplied away (R = K * mask0 - acc: the fma
+    // replaces the subtraction, so the common path pays nothing -- the selects and the per-block loads of the right-hand sides
+    // cost every wave 12 vector instructions per row block until round 4).  With a carried factor the only special right-hand
+    // side left on the sweep is e_0, non-zero in factor row 0 alone, i.e. in row block 0; the refit's y_u, y_v are added under
+    // a scalar branch.
+    const double mask0 = (kFirst && wave == 0 && use_spec) ? 0.0 : 1.0;
+    const bool refit_rhs = kFirst && wave == 0 && __builtin_amdgcn_readfirstlane((int)incremental) == 0;       // scalar
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int c0 = pad_top >> 2;          // K-steps 0 .. c0 - 1 of block column 0 hold only virtual rows: skipped
     // factor row of MFMA row m is m - pad_top; virtual rows (block 0 only) read the all-zero slot 127 of the row vectors
     // (as one per-lane offset computed once: slot of MFMA row 4 v + g of block 0, and g - pad_top for the blocks below,
     // whose rows are all real -- their indices are then compile-time offsets from it)
     const int off_rest = g - pad_top;
+    const int r0 = jq - pad_top;
+    const double* arow_base = sh.L + ((r0 * (r0 + 1)) >> 1) - pad_top + g;        // (r0 (r0 + 1) is even for negative r0 too)
+    const int arow_step = 16 * r0;
     // packed lower triangle of a block inverse: the lanes above the diagonal read the zero at [136] (an offset chosen
     // once per lane, not a compare + select per load)
     int doff[4];
@@ -1073,11 +1091,14 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
         d4 acc[NT];
         // (row blocks I >= 1 hold real rows only; their virtual columns -pad_top .. -1 read the guard in front of L or
         // finite entries of the row above, against the zero rows of V)
-        const double* arow = sh.L + (I > 0 ? tri(16 * I + jq - pad_top) - pad_top : 0) + g;
+        // (tri(16 I + r0) = tri(r0) + 16 I r0 + 8 I (16 I + 1), r0 = jq - pad_top: one multiply-add per row block on a per-lane
+        // base and step instead of the ten instructions of the triangle index)
+        const double* arow = I > 0 ? arow_base + I * arow_step + 8 * I * (16 * I + 1) : sh.L + g;
         // right-hand sides of the special columns (tile 0): requested here, consumed after the products below --
         // read next to their use, each of the 32 loads was a full LDS round trip of the slowest wave
-        double spec[4] = {0.0, 0.0, 0.0, 0.0};
-        if (kFirst && wave == 0) {
+        double spec[4];
+        const bool need_spec = kFirst && wave == 0 && (I == 0 || refit_rhs);                 // scalar
+        if (need_spec) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) spec[v] = sh.z[spec_sel][row_slot(I, v)];
         }
@@ -1088,6 +1109,19 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           a_rows[v] = sh.a[row_slot(I, v)]; p_rows[v] = sh.loc[row_slot(I, v)][2];
           dpk[v] = sh.dinv[I][doff[v]];
         }
+        // The A operands of the products (rows of the factor): block columns 0 and 1 are requested here, column J + 1 in front
+        // of column J's products (round 5).  The compiler read each pair of operands right in front of the MFMAs that consume it,
+        // into the same registers: ~56 exposed LDS round trips per wave and sweep, a quarter of the sweep core's cycles.
+        double a_col0[4] = {0.0, 0.0, 0.0, 0.0}, a_next[4] = {0.0, 0.0, 0.0, 0.0};
+        if (I > 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a_col0[c] = arow[4 * c];          // (virtual columns: the zero guard or finite entries, unused)
+        }
+        if (I > 1) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a_next[c] = arow[16 + 4 * c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // kernel matrix of the block, stage A (distance, square root, exp reduction, table request) BEFORE the block's
         // products: the table reads land under the MFMAs; stage B (polynomial) after them
         // (block 0: the rows 4 v + g of a register v < c0 are all virtual -- their K-steps of the block inverse are skipped
@@ -1099,13 +1133,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const double dp = level_s[t] - p_rows[v];
-              kst[t][v] = exp_neg_stage_a(sqrt_coupled(d_fma(dp, dp, a_rows[v])), sh.exp2_frac);
+              kst[t][v] = exp_scaled_stage_a(two_sqrt(d_fma(dp, dp, a_rows[v])), sh.exp2_frac);
             }
           }
         // one K-step of the block row: acc (+)= L[I][J](:, 4c .. 4c+3) V[J](4c .. 4c+3, :)
         auto kstep = [&](auto j_tag, auto c_tag, auto first_tag) {
           constexpr int J = decltype(j_tag)::value, c = decltype(c_tag)::value;
-          const double a = arow[16 * J + 4 * c];
+          const double a = a_col0[c];
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], decltype(first_tag)::value ? zero4 : acc[t], 0, 0, 0);
@@ -1122,14 +1156,23 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           else { kstep(J0{}, C3{}, T{}); }
         }
 #pragma unroll
-        for (int J = 1; J < I; ++J)
+        for (int J = 1; J < I; ++J) {
+          double a_cur[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a_cur[c] = a_next[c];
+          if (J + 1 < I) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a_next[c] = arow[16 * (J + 1) + 4 * c];
+          }
+          __builtin_amdgcn_sched_barrier(0);          // the next block column's operands are requested BEFORE this one's products
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const double a = arow[16 * J + 4 * c];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[t][J][c], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[c], V[t][J][c], acc[t], 0, 0, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         d4 R[NT];
 #pragma unroll
         for (int v = 0; v < 4; ++v) if (I > 0 || v >= c0) {
@@ -1138,22 +1181,29 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
           for (int t = 0; t < NT; ++t) {
             // branch-free: every lane evaluates the kernel (columns past the last reachable level are unused);
             // s^2 is folded into the exp table; a_row carries a 1e-300 guard for r2 == 0
-            R[t][v] = exp_neg_stage_b(kst[t][v]);
+            R[t][v] = exp_scaled_stage_b(kst[t][v]);
           }
-          const bool real_row = I > 0 || row >= pad_top;
-          if (I == 0 && pad_top > 0) {                        // scalar: only the first block holds virtual rows
+          if (I == 0) {
+            const bool real_row = row >= pad_top;
+            if (pad_top > 0) {                                // scalar: only the first block holds virtual rows
 #pragma unroll
-            for (int t = 0; t < NT; ++t) R[t][v] = real_row ? R[t][v] : 0.0;
-          }
-          if (kFirst && wave == 0) {                          // scalar branch: tile 0 holds the special columns
-            // unconditional LDS reads + selects (a load under a per-lane condition becomes an exec-mask branch);
-            // z[3] holds e_0 until the solved column overwrites it
-            R[0][v] = use_spec ? (real_row ? spec[v] : 0.0) : R[0][v];
-          }
-          if (I > 0) {
+              for (int t = 0; t < NT; ++t) R[t][v] = real_row ? R[t][v] : 0.0;
+            }
+            if (kFirst && wave == 0) {                        // scalar branch: tile 0 holds the special columns
+              // unconditional LDS reads + selects (a load under a per-lane condition becomes an exec-mask branch);
+              // z[3] holds e_0 until the solved column overwrites it
+              R[0][v] = use_spec ? (real_row ? spec[v] : 0.0) : R[0][v];
+            }
+          } else {
+            R[0][v] = d_fma(R[0][v], mask0, -acc[0][v]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) R[t][v] -= acc[t][v];
+            for (int t = 1; t < NT; ++t) R[t][v] -= acc[t][v];
           }
+        }
+        if (I > 0 && need_spec) {                                      // (refit only: y_u, y_v in every row)
+          asm volatile("; refit right-hand sides");                    // keeps this ONE scalar branch per row block (the optimiser
+#pragma unroll                                                         // flattened it into five selects and adds per register for
+          for (int v = 0; v < 4; ++v) R[0][v] += use_spec ? spec[v] : 0.0;      // every wave)
         }
         // V[I] = Dinv[I] R.  Block 0: the K-steps that hold only virtual rows (zero rows of R against identity columns)
         // are skipped like those of block column 0 above
@@ -1287,8 +1337,8 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
       const int level_idx = lo_idx + col_m - kSpecial;
       if (g < NT && col_m >= kSpecial && level_idx <= hi_idx) {
         // the newest observation's row: K*(level, newest) = s^2 exp(-|level - p| / 326) (same x, y, t as the query)
-        const double dpl = (level_m - p) * (1.0 / 326.0);
-        const double val_last = exp_neg_tab(__builtin_fabs(dpl), sh.exp2_frac) - cross_m;        // (s^2 is in the table)
+        const double dpl = (level_m - p) * (kGpTwoKappa / 326.0);
+        const double val_last = gp_exp_neg_scaled(__builtin_fabs(dpl), sh.exp2_frac) - cross_m;        // (s^2 is in the table)
         const double ss = d_fma(val_last * val_last, inv_dn, ssq_m);
         const double mu = d_fma(val_last, zl_u, mean_u_m), mv = d_fma(val_last, zl_v, mean_v_m);
         // forecast at this level from the blended column
