@@ -22,7 +22,7 @@ _SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_
                                                           'ble_observe.h', 'ble_noise.h', 'ble_decode.h', 'ble_step_split.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH, FLAG_DAY_CYCLE = 64, 128, 256
@@ -30,8 +30,8 @@ OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
 NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
-           'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32',
+EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
+           'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
            'ble_probe_f64_prims')
 
@@ -96,12 +96,14 @@ def lib():
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_atmosphere_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_latlng_f64.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_power_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_thermal_f32.argtypes = [_vp] * 9 + [_i64, _vp]
   l.ble_probe_sp_volume_f32.argtypes = [_vp] * 5 + [_i64, _vp]
   l.ble_probe_acs_f32.argtypes = [_vp] * 4 + [_i64, _vp]
   l.ble_probe_safety_f32.argtypes = [_int, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_f64_prims.argtypes = [_vp, _vp, _int, _i64, _vp]
+  l.ble_set_step_form.argtypes = [_int]
   for name in EXPORTS:
     getattr(l, name).restype = _int
   _lib = l
@@ -112,3 +114,29 @@ def check(code: int, what: str) -> None:
   if code != BLE_OK:
     hip = _lib.ble_last_hip_error() if _lib is not None else 0
     raise BleLibraryError(f'{what} failed with BLE error {code} (hipError_t {hip})')
+
+
+class step_form:
+  """`with _lib.step_form(waves): ...` forces the transition kernel's form (0 automatic, 1 one lane per environment,
+  4 / 2 wavefronts per environment: `ble_set_step_form`) for the launches inside the block and restores the previous
+  setting.  A/B runs and the bit-identity tests; the automatic choice is by batch size (BLE_SPLIT_MAX_ENVS)."""
+
+  def __init__(self, waves_per_env: int):
+    self.waves = int(waves_per_env)
+
+  def __enter__(self):
+    self.before = lib().ble_set_step_form(self.waves)
+    if self.before < 0:
+      raise ValueError(f'step form must be 0, 1, 2 or 4, not {self.waves}')
+    return self
+
+  def __exit__(self, *exc):
+    lib().ble_set_step_form(self.before)
+    return False
+
+
+def set_step_form(mode) -> int:
+  """`ble_set_step_form` with the spelling of the former BLE_STEP_SPLIT switch: None / 'auto' -> automatic, '0' -> one lane per
+  environment, '1' / '4' -> four wavefronts, '2' -> two.  Returns the previous setting."""
+  waves = {None: 0, 'auto': 0, '0': 1, '1': 4, '4': 4, '2': 2}[mode if mode is None else str(mode)]
+  return lib().ble_set_step_form(waves)

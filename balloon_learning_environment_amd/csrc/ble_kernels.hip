@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <atomic>
 
 // Instrumentation hooks of ble_step_kernel: empty in the product build.  A profiling build
 // (profiles/build_variant.sh ... -DBLE_STEP_BLOCK=64 -DBLE_STEP_INSTR_HEADER='"../../profiles/instr/ble_step_instr.h"') takes per-wave clock
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
   __shared__ double acs_poly[kAcsPolyDoubles];
   // kNoise: the harmonics' seeds and offsets of this wave's environments, fetched once per launch ([50][64] words)
   __shared__ uint32_t noise_draws[kNoise ? 50 * kStepBlock : 1];
+  __shared__ __attribute__((aligned(16))) float grad_lut[kNoise ? kGradLutFloats : 4];      // the noise primitive's gradient weights
   __shared__ float term_save[kTermSaveRows * kStepBlock];       // where a lane parks the state its episode ended with (agent_step): one block per wave
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int64_t i = ((int64_t)blockIdx.x * (kStepBlock / 64) + wave) * lanes + lane;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
   }
   // the ACS table's piecewise cubics: a compile-time table, constant memory -> LDS (the loop reads it by a per-lane index)
   for (int j = (int)threadIdx.x; j < kAcsPolyDoubles; j += kStepBlock) acs_poly[j] = kAcsPoly.c[j];
+  if (kNoise) grad_lut_fill(grad_lut, (int)threadIdx.x, kStepBlock);
   BLE_STEP_MARK(1);
   __syncthreads();
   BLE_STEP_MARK(2);
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
       wind_gather(wind_grid + i * grid_env_stride, wq, &corners);
       float nu = 0.0f, nv = 0.0f;
       if (kNoise) {
-        wind_noise_from_rows(s.x, s.y, s.p, s.t_elapsed, noise_draws + threadIdx.x, kStepBlock, &nu, &nv);
+        wind_noise_from_rows(s.x, s.y, s.p, s.t_elapsed, noise_draws + threadIdx.x, kStepBlock, grad_lut, &nu, &nv);
         // the noise is a VALUE here as it is between ble_wind_noise_f32 and ble_step_f32: without this the compiler is free to
         // fuse the generator's last multiplication into agent_step's `u += noise_u` (one rounding instead of two)
         asm volatile("" : "+v"(nu), "+v"(nv));
@@ -304,6 +307,18 @@ __global__ __launch_bounds__(256) void probe_solar_kernel(const float* lat0, con
   el_deg[i] = atan2f(sun.sin_el, sun.cos_el) * kRadToDeg;
   flux[i] = e.flux;
 }
+// BalloonState.latlng (balloon.py:217-220 -> spherical_geometry.py:44-76): the latlng_f64 the observation and the exact solar
+// chain evaluate, as degrees
+__global__ __launch_bounds__(256) void probe_latlng_kernel(const float* lat0, const float* lng0, const float* x, const float* y,
+                                                           double* lat_deg, double* lng_deg, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double sl, cl, lng;
+  latlng_f64((double)lat0[i], (double)lng0[i], (double)x[i], (double)y[i], &sl, &cl, &lng);
+  lat_deg[i] = asin(sl) * (180.0 / kPiD);          // (libm: the probe reports degrees to 1e-12; the kernels use sin / cos directly)
+  lng = lng - 360.0 * floor((lng + 180.0) * (1.0 / 360.0));             // s2 LatLng.normalized(): [-180, 180)
+  lng_deg[i] = lng;
+}
 __global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_deg, const float* pressure, float* att,
                                                                 float* power, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -456,17 +471,20 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
                                                              const int32_t* __restrict__ elapsed, unsigned long long seed,
                                                              const uint32_t* __restrict__ episode, int mode,
                                                              uint32_t* harmonic_cache, float* __restrict__ noise_uv, int64_t n) {
+  __shared__ __attribute__((aligned(16))) float grad_lut[kGradLutFloats];
+  grad_lut_fill(grad_lut, (int)threadIdx.x, 256);
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float u, v;
   if (mode == 0) {
     const uint32_t ep = episode ? episode[i] : 0u;
     if (harmonic_cache != nullptr)
-      wind_noise_cached(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, harmonic_cache, n, &u, &v);
+      wind_noise_cached(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, harmonic_cache, n, grad_lut, &u, &v);
     else
-      wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, &u, &v);
+      wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, grad_lut, &u, &v);
   } else {
-    u = simplex4(x[i], y[i], pressure[i], (float)elapsed[i] * (1.0f / 3600.0f), (uint32_t)seed);
+    u = simplex4(x[i], y[i], pressure[i], (float)elapsed[i] * (1.0f / 3600.0f), (uint32_t)seed, grad_lut);
     v = 0.0f;
   }
   noise_uv[2 * i] = u; noise_uv[2 * i + 1] = v;
@@ -567,17 +585,35 @@ __global__ __launch_bounds__(256) void probe_f64_kernel(const double* x, double*
 namespace {
 inline int env_lanes() { return kBlock; }   // one environment per lane, all 64 lanes (32 was measured: slower)
 // Below BLE_SPLIT_MAX_ENVS environments the one-lane kernel leaves most SIMDs idle (n / 64 waves on 1 024 SIMDs) and the
-// four-wave kernel still fits one wave per SIMD: it is the faster one (bit-identical results).  BLE_STEP_SPLIT=0 / 1 in the
-// environment forces one or the other (A/B runs and the parity test).
-// returns the number of waves per environment: 1 (ble_step_kernel), 2 (ble_step_pair_kernel) or 4 (ble_step_split_kernel)
-inline int split_waves(int64_t n) {
+// four-wave kernel still fits one wave per SIMD: it is the faster one (bit-identical results).  ble_set_step_form() forces a
+// form (A/B runs and the parity test); BLE_STEP_SPLIT=0 / 1 / 2 / 4 in the process environment is read ONCE, when the
+// library first needs it, as that switch's initial value (it used to be re-read by getenv on every launch: host work on the
+// 3 us launch path and a data race with a concurrent setenv).
+// g_step_form: -1 not initialised, 0 automatic, 1 / 2 / 4 wavefronts per environment.
+std::atomic<int> g_step_form{-1};
+inline int step_form_from_environment() {
   const char* e = getenv("BLE_STEP_SPLIT");
-  if (e != nullptr && e[1] == 0) {
+  if (e != nullptr && e[0] != 0 && e[1] == 0) {
     if (e[0] == '0') return 1;
     if (e[0] == '1' || e[0] == '4') return 4;
     if (e[0] == '2') return 2;
   }
-  return n <= BLE_SPLIT_MAX_ENVS ? 4 : 1;
+  return 0;
+}
+inline int step_form() {
+  int f = g_step_form.load(std::memory_order_relaxed);
+  if (f < 0) {
+    int expected = -1;
+    const int init = step_form_from_environment();
+    g_step_form.compare_exchange_strong(expected, init, std::memory_order_relaxed);
+    f = g_step_form.load(std::memory_order_relaxed);
+  }
+  return f;
+}
+// returns the number of waves per environment: 1 (ble_step_kernel), 2 (ble_step_pair_kernel) or 4 (ble_step_split_kernel)
+inline int split_waves(int64_t n) {
+  const int f = step_form();
+  return f != 0 ? f : (n <= BLE_SPLIT_MAX_ENVS ? 4 : 1);
 }
 inline bool use_split(int64_t n) { return split_waves(n) != 1; }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
@@ -635,6 +671,13 @@ extern "C" {
 int ble_abi_version(void) { return BLE_ABI_VERSION; }
 
 int ble_last_hip_error(void) { return g_last_hip_error; }
+
+int ble_set_step_form(int waves_per_env) {
+  if (waves_per_env != 0 && waves_per_env != 1 && waves_per_env != 2 && waves_per_env != 4) return BLE_E_INVALID_ARG;
+  const int before = step_form();
+  g_step_form.store(waves_per_env, std::memory_order_relaxed);
+  return before;
+}
 
 int ble_device_count(void) {
   int n = 0;
@@ -765,6 +808,15 @@ int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(probe_solar_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, center_lat_deg,
                      center_lng_deg, x_m, y_m, unix_s, el_deg, flux, n);
+  return launch_status();
+}
+
+int ble_probe_latlng_f64(const float* center_lat_deg, const float* center_lng_deg, const float* x_m, const float* y_m,
+                         double* lat_deg, double* lng_deg, int64_t n, void* stream) {
+  if (!center_lat_deg || !center_lng_deg || !x_m || !y_m || !lat_deg || !lng_deg || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(probe_latlng_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, center_lat_deg, center_lng_deg, x_m,
+             y_m, lat_deg, lng_deg, n);
   return launch_status();
 }
 

@@ -67,25 +67,39 @@ BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
   h = (h ^ (uint32_t)l) * 0x27D4EB2Fu; h ^= h >> 15;
   return h;
 }
-// One corner: (0.6 - |d|^2)^4 * (gradient . d), gradient = one of the 32 midpoints of the edges of
-// the 4-cube (one zero component, the other three +-1).
-BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h) {
+// The 32 gradients -- the midpoints of the edges of the 4-cube: one zero component (g >> 3 says which), the other three +-1
+// (bits 0, 1, 2 of g are the signs of the first, second, third non-zero component in x, y, z, w order) -- as a table of
+// (wx, wy, wz, ww) weights: 512 B that every kernel which evaluates the noise keeps in LDS (grad_lut_fill).  Round 5: the dot
+// product through the table is one 16-byte LDS read + 4 multiplies + 3 adds; picking the three components and their signs with
+// compares, selects and sign-bit arithmetic was 16 vector instructions per corner, 80 per harmonic (of 333).  Same bits: a weight
+// of +-1 is an exact product, the zero weight adds a zero, and the additions keep the order ((x' + y') + z') + w' that
+// (a + b) + c had.
+constexpr int kGradLutFloats = 32 * 4;
+BLE_FN void grad_lut_entry(int g, float* w4) {
+  const int zero = g >> 3;
+  int bit = 0;
+  for (int comp = 0; comp < 4; ++comp) {
+    if (comp == zero) { w4[comp] = 0.0f; continue; }
+    w4[comp] = ((g >> bit) & 1) ? -1.0f : 1.0f;
+    ++bit;
+  }
+}
+BLE_FN void grad_lut_fill(float* lut, int tid, int n_threads) {      // followed by a barrier of the filling threads
+  for (int g = tid; g < 32; g += n_threads) grad_lut_entry(g, lut + 4 * g);
+}
+// One corner: (0.6 - |d|^2)^4 * (gradient . d).  `lut`: the table above, 16-byte aligned.
+BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h, const float* lut) {
   BLE_NO_CONTRACT
   float t = 0.6f - x * x - y * y - z * z - w * w;
   // a corner farther than sqrt(0.6) contributes nothing: t clamped to 0 makes its term (+-)0, which leaves the sum's bits alone -- no
   // branch (with 64 environments in a wave some lane always takes the other side)
   t = t < 0.0f ? 0.0f : t;
-  const uint32_t g = h >> 27;                      // 5 bits
-  const uint32_t zero = g >> 3;
-  const float a0 = zero == 0 ? y : x, b0 = zero <= 1 ? z : y, c0 = zero <= 2 ? w : z;
-  // (g & 1) ? -a : a ... as sign-bit arithmetic: bit k of g moved to bit 31 and xor-ed in (no compare, no select)
-  const float a = u32_bits_float(float_bits_u32(a0) ^ (g << 31));
-  const float b = u32_bits_float(float_bits_u32(b0) ^ ((g << 30) & 0x80000000u));
-  const float c = u32_bits_float(float_bits_u32(c0) ^ ((g << 29) & 0x80000000u));
+  const float* gw = static_cast<const float*>(__builtin_assume_aligned(lut + ((h >> 27) << 2), 16));
+  const float dot = ((gw[0] * x + gw[1] * y) + gw[2] * z) + gw[3] * w;
   t *= t;
-  return t * t * (a + b + c);
+  return t * t * dot;
 }
-BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed) {
+BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed, const float* lut) {
   BLE_NO_CONTRACT
   const float F4 = 0.30901699437494745f, G4 = 0.1381966011250105f;
   const float s = (x + y + z + w) * F4;
@@ -99,17 +113,17 @@ BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed) {
   if (y0 > z0) ry++; else rz++;
   if (y0 > w0) ry++; else rw++;
   if (z0 > w0) rz++; else rw++;
-  float n = simplex_corner(x0, y0, z0, w0, lattice_hash(i, j, k, l, seed));
+  float n = simplex_corner(x0, y0, z0, w0, lattice_hash(i, j, k, l, seed), lut);
 #pragma unroll
   for (int c = 1; c <= 3; ++c) {
     const int th = 4 - c;                          // corner c adds 1 to the axes of rank >= 4 - c
     const int di = rx >= th, dj = ry >= th, dk = rz >= th, dl = rw >= th;
     const float off = (float)c * G4;
     n += simplex_corner(x0 - (float)di + off, y0 - (float)dj + off, z0 - (float)dk + off, w0 - (float)dl + off,
-                        lattice_hash(i + di, j + dj, k + dk, l + dl, seed));
+                        lattice_hash(i + di, j + dj, k + dk, l + dl, seed), lut);
   }
   n += simplex_corner(x0 - 1.0f + 4.0f * G4, y0 - 1.0f + 4.0f * G4, z0 - 1.0f + 4.0f * G4, w0 - 1.0f + 4.0f * G4,
-                      lattice_hash(i + 1, j + 1, k + 1, l + 1, seed));
+                      lattice_hash(i + 1, j + 1, k + 1, l + 1, seed), lut);
   return 27.0f * n;
 }
 
@@ -127,13 +141,14 @@ BLE_FN HarmonicDraw harmonic_draw(Philox& g) {
 struct NoiseAccumulator { float acc = 0.0f, wsum = 0.0f, w2sum = 0.0f; };
 // NoisyWindHarmonic.get_noise (:116-146): one harmonic's value at a point -- the expensive part (one 4-D simplex evaluation);
 // the four-wave form of the transition evaluates the ten of them on different wavefronts
-BLE_FN float noise_harmonic_value(int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure, float t_h) {
+BLE_FN float noise_harmonic_value(int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure, float t_h,
+                                  const float* lut) {
   BLE_NO_CONTRACT
   const float magnitude = sqrtf(kNoiseVariance / kSimplex4Variance);
   const Harmonic hp = harmonic_params(comp, h);
   const HarmonicRcp hr = harmonic_rcp(comp, h);
   return magnitude * simplex4(f_div_const(x_km, hp.x_spacing, hr.x) + d.ox, f_div_const(y_km, hp.y_spacing, hr.y) + d.oy,
-                              f_div_const(pressure, hp.p_spacing, hr.p) + d.op, f_div_const(t_h, hp.t_spacing, hr.t) + d.ot, d.hseed);
+                              f_div_const(pressure, hp.p_spacing, hr.p) + d.op, f_div_const(t_h, hp.t_spacing, hr.t) + d.ot, d.hseed, lut);
 }
 BLE_FN void noise_accumulate(NoiseAccumulator& a, int comp, int h, float nz) {
   BLE_NO_CONTRACT
@@ -141,8 +156,8 @@ BLE_FN void noise_accumulate(NoiseAccumulator& a, int comp, int h, float nz) {
   a.acc = f_fma(nz, hp.weight, a.acc); a.wsum += hp.weight; a.w2sum = f_fma(hp.weight, hp.weight, a.w2sum);
 }
 BLE_FN void noise_add_harmonic(NoiseAccumulator& a, int comp, int h, const HarmonicDraw& d, float x_km, float y_km, float pressure,
-                               float t_h) {
-  noise_accumulate(a, comp, h, noise_harmonic_value(comp, h, d, x_km, y_km, pressure, t_h));
+                               float t_h, const float* lut) {
+  noise_accumulate(a, comp, h, noise_harmonic_value(comp, h, d, x_km, y_km, pressure, t_h, lut));
 }
 // the coordinates the harmonics are sampled at (units.Distance.km, timedelta_to_hours)
 BLE_FN void noise_coords(float x_m, float y_m, int32_t elapsed_s, float* x_km, float* y_km, float* t_h) {
@@ -163,7 +178,7 @@ BLE_FN float noise_finish(const NoiseAccumulator& a) {
 
 // Both components at one point, the harmonics' seeds and offsets drawn on the spot (50 Philox draws).
 BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env,
-                                  uint32_t episode, float* u, float* v) {
+                                  uint32_t episode, const float* lut, float* u, float* v) {
   BLE_NO_CONTRACT
   Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
   const float x_km = x_m * 1e-3f, y_km = y_m * 1e-3f, t_h = (float)elapsed_s * (1.0f / 3600.0f);
@@ -174,7 +189,7 @@ BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, 
 #pragma unroll 1
     for (int h = 0; h < 5; ++h) {
       const HarmonicDraw d = harmonic_draw(g);
-      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h);
+      noise_add_harmonic(a, comp, h, d, x_km, y_km, pressure, t_h, lut);
     }
     out[comp] = noise_finish(a);
   }
@@ -184,7 +199,7 @@ BLE_FN void wind_noise(float x_m, float y_m, float pressure, int32_t elapsed_s, 
 // Both components from draws that lie in memory as 50 words `stride` apart (rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic
 // k = 5 comp + h): the HBM cache below, or the copy ble_step_kernel<noise> keeps in LDS for the steps of a launch.
 BLE_FN void wind_noise_from_rows(float x_m, float y_m, float pressure, int32_t elapsed_s, const uint32_t* rows, int64_t stride,
-                                 float* u, float* v) {
+                                 const float* lut, float* u, float* v) {
   BLE_NO_CONTRACT
   float x_km, y_km, t_h;
   noise_coords(x_m, y_m, elapsed_s, &x_km, &y_km, &t_h);
@@ -194,7 +209,7 @@ BLE_FN void wind_noise_from_rows(float x_m, float y_m, float pressure, int32_t e
     NoiseAccumulator a;
 #pragma unroll 1
     for (int h = 0; h < 5; ++h)
-      noise_add_harmonic(a, comp, h, harmonic_draw_from_rows(rows, stride, 5 * comp + h), x_km, y_km, pressure, t_h);
+      noise_add_harmonic(a, comp, h, harmonic_draw_from_rows(rows, stride, 5 * comp + h), x_km, y_km, pressure, t_h, lut);
     out[comp] = noise_finish(a);
   }
   *u = out[0]; *v = out[1];
@@ -249,7 +264,7 @@ struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* h
 // = 5 comp + h, rows 50 .. 52 the key (episode + 1, seed lo, seed hi) the entry was drawn for; an entry drawn for another
 // (seed, episode) -- or an all-zero, fresh one -- is redrawn and stored.  Same values as wind_noise(), bit for bit.
 BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint32_t episode,
-                              uint32_t* cache, int64_t n, float* u, float* v) {
+                              uint32_t* cache, int64_t n, const float* lut, float* u, float* v) {
   BLE_NO_CONTRACT
   uint32_t* mine = cache + env;
   const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
@@ -264,7 +279,7 @@ BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elap
     }
     mine[50 * n] = k0; mine[51 * n] = k1; mine[52 * n] = k2;
   }
-  wind_noise_from_rows(x_m, y_m, pressure, elapsed_s, mine, n, u, v);
+  wind_noise_from_rows(x_m, y_m, pressure, elapsed_s, mine, n, lut, u, v);
 }
 
 }  // namespace ble

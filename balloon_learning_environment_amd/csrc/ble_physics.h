@@ -1029,11 +1029,19 @@ constexpr double kOmsDay = 1.0752991363576547;        // uncorrected -4.31841015
 constexpr double kOmsShadow33 = 0.38823376985560987;  // uncorrected 37.71732276171744 deg -> corrected 37.738149050524044 deg
 constexpr double kOmsShadow27 = 0.4354459419249166;   // uncorrected 34.371330036126224 deg -> corrected 34.39486500086289 deg
 constexpr double kOmsRefr5 = 0.9128442572523419;      // 1 - sin(5 deg)
-constexpr float kSunBand = 6.0e-8f;
-struct SunThresholds { float d_day, d_s33, d_s27, d_r5; };
-BLE_FN SunThresholds sun_thresholds(double w0) {      // w0 = 1 - sin(uncorrected elevation) at the first node of the step, fp64
+constexpr float kSunBand = 6.0e-8f;                    // at the reference's 18 strides per step
+// The quadratic's error is |S'''| h^3 0.064 with h the half step: 1.8e-8 at 18 strides, and it grows with the cube of the step
+// length (6e-8 near 27 strides, 6.6e-7 at BLE_MAX_SUBSTEPS = 60), so the band does too: a fixed 6e-8 would let the four decisions
+// differ from sun_exact's on long steps without the fp64 chain being taken.  Wave-uniform: `substeps` is a kernel argument.
+BLE_FN float sun_band(int substeps) {
+  const float r = (float)substeps * (1.0f / 18.0f);
+  return substeps <= 18 ? kSunBand : kSunBand * (r * r * r);
+}
+struct SunThresholds { float d_day, d_s33, d_s27, d_r5, band; };
+BLE_FN SunThresholds sun_thresholds(double w0, int substeps) {      // w0 = 1 - sin(uncorrected elevation) at the first node of the step, fp64
   SunThresholds t;
   t.d_day = (float)(w0 - kOmsDay); t.d_s33 = (float)(w0 - kOmsShadow33); t.d_s27 = (float)(w0 - kOmsShadow27); t.d_r5 = (float)(w0 - kOmsRefr5);
+  t.band = sun_band(substeps);
   return t;
 }
 // oms = c0 + q: the interpolated 1 - sin(uncorrected elevation) of the stride, q its increment over the step's first node
@@ -1046,7 +1054,7 @@ BLE_FN SunState sun_fast(float oms, float q, const SunThresholds& t, bool* near)
   r.day = d_day < 0.0f;          // el > -4.242  (sun_exact's comparisons, mapped)
   r.sh33 = d_s33 <= 0.0f;        // el >= 37.738...
   r.sh27 = d_s27 <= 0.0f;        // el >= 34.394...
-  *near = f_minnum(f_minnum(fabsf(d_day), fabsf(d_s33)), f_minnum(fabsf(d_s27), fabsf(d_r5))) < kSunBand;
+  *near = f_minnum(f_minnum(fabsf(d_day), fabsf(d_s33)), f_minnum(fabsf(d_s27), fabsf(d_r5))) < t.band;
   return r;
 }
 // solar.solar_calculator on BalloonState.latlng in fp64 (the oracle's chain op for op), cold.

@@ -229,7 +229,7 @@ BLE_FN SunQuadratic solar_node_coefs(double f0, double f1, double f2, int subste
   sq.c0 = (float)f0;
   sq.c1 = (float)((-f2 + 4.0 * f1 - 3.0 * f0) * inv_2m);
   sq.c2 = (float)((f2 - 2.0 * f1 + f0) * (2.0 * (inv_2m * inv_2m)));
-  sq.thr = sun_thresholds(f0);
+  sq.thr = sun_thresholds(f0, substeps);
   return sq;
 }
 BLE_FN SunQuadratic solar_nodes_site(const SolarNodes& n, double sl0, double cl0, float x_m, float y_m, float u, float v, int substeps) {

@@ -90,6 +90,7 @@ BLE_FN int action_apply_any(uint32_t map_alt, uint32_t map_pow_env, int action) 
 // environments (fetched once per launch) and the ten harmonic values of a step, each evaluated by one of the waves
 template <bool kNoise> struct SplitNoiseShared {};
 template <> struct SplitNoiseShared<true> {
+  alignas(16) float grad_lut[kGradLutFloats];      // the noise primitive's gradient weights (ble_noise.h)
   uint32_t draws[50][kSplitLanes];
   float nz[10][kSplitLanes];
 };
@@ -149,6 +150,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
   }
   for (int t = (int)threadIdx.x; t < kAcsPolyDoubles; t += kWaves * kSplitLanes) sh.acs_poly[t] = kAcsPoly.c[t];
   if constexpr (kNoise) {            // the harmonics' seeds and offsets of the workgroup's environments, once per launch
+    grad_lut_fill(shn.grad_lut, (int)threadIdx.x, kWaves * kSplitLanes);
     if (wave == 0 && in_range)
       noise_draws_fetch(a.gen.seed, (uint64_t)i, a.gen.episode ? a.gen.episode[i] : 0u, a.gen.harmonic_cache, n, &shn.draws[0][lane], kSplitLanes);
   }
@@ -220,7 +222,8 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
         noise_coords(s.x, s.y, s.t_elapsed, &x_km, &y_km, &t_h);
 #pragma unroll 1
         for (int k = wave; k < 10; k += kWaves)
-          shn.nz[k][lane] = noise_harmonic_value(k / 5, k % 5, harmonic_draw_from_rows(&shn.draws[0][lane], kSplitLanes, k), x_km, y_km, s.p, t_h);
+          shn.nz[k][lane] = noise_harmonic_value(k / 5, k % 5, harmonic_draw_from_rows(&shn.draws[0][lane], kSplitLanes, k), x_km, y_km, s.p, t_h,
+                                                 shn.grad_lut);
       }
       __syncthreads();                                 // ---- barrier 0 (noise only): the harmonic values are there
     }
@@ -266,7 +269,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
         node_f0 = solar_node<0>(nd, hc.sin_lat0, hc.cos_lat0, s.x, s.y, u, v, substeps);
         // the sun of stride 0 needs the first node alone: the quadratic at index 0 is its constant term (the other two
         // coefficients are finite), so it is ready at the same barrier as the nodes
-        sq.c0 = (float)node_f0; sq.c1 = 0.0f; sq.c2 = 0.0f; sq.thr = sun_thresholds(node_f0);
+        sq.c0 = (float)node_f0; sq.c1 = 0.0f; sq.c2 = 0.0f; sq.thr = sun_thresholds(node_f0, substeps);
         const SunState sun0 = sun_at_stride(0, sq, c, u, v, x_start, y_start, t_start);
         sun_sin = sun0.sin_el; sun_panel = solar_panel_factor(sun0); sun_day = sun0.day;
         sh.sin_el0[lane] = sun_sin; sh.panel0[lane] = sun_panel; sh.day0[lane] = sun_day ? 1u : 0u;

@@ -78,7 +78,9 @@ class OutputGatherer:
     # a rank's row of a slot starts 16-byte aligned whatever k and n_local are (unpack() views it as float32)
     self.row_bytes = -(-5 * k * n_local // 16) * 16
     self.packed = None          # [slots, world, row_bytes] uint8 on rank dst: the packed blocks of gather_packed
-    self.packed_gathers = 0     # gather_packed calls so far: call g went to slot g % slots
+    self.packed_gathers = 0     # gather_packed calls so far
+    self._region_gathers = 0    # ... since the last wait(): launch j of a region goes to slot j % slots
+    self._last_slot = 0
     self.gathers = 0            # exchanges issued by this rank
     self.rows_gathered = 0      # agent steps they carried
 
@@ -117,7 +119,11 @@ class OutputGatherer:
     if self.packed is None:
       rows = self.world if self.is_dst else 0
       self.packed = torch.zeros((self.slots, rows, self.row_bytes), dtype=torch.uint8, device=block.device)
-    slot = self.packed_gathers % self.slots
+    # launch j of a REGION lands in slot j: the index restarts when the region's wait() returns (it used to run on across
+    # regions, so a warm-up region of another length shifted the mapping -- ADVICE r4)
+    slot = self._region_gathers % self.slots
+    self._region_gathers += 1
+    self._last_slot = slot
     self.packed_gathers += 1
     self.gathers += 1; self.rows_gathered += int(c)
     if self.world == 1:
@@ -140,11 +146,13 @@ class OutputGatherer:
     slot of the most recent gather_packed); rank `dst` only, after wait()."""
     n = self.n_local
     if slot is None:
-      slot = (self.packed_gathers - 1) % self.slots
+      slot = self._last_slot
     row = self.packed[slot][r]
     return row[:4 * c * n].view(torch.float32).view(c, n), row[4 * c * n:5 * c * n].view(c, n)
 
   def wait(self) -> None:
+    """End of a region: the compute stream waits for the exchanges; the next gather_packed goes to slot 0 again."""
+    self._region_gathers = 0
     if self.stream is not None:
       torch.cuda.current_stream(self.reward.device).wait_stream(self.stream)
 
@@ -156,7 +164,7 @@ def packed_output_block(c: int, n_local: int, device):
   return buf, buf[:4 * c * n_local].view(torch.float32).view(c, n_local), buf[4 * c * n_local:].view(c, n_local)
 
 
-def run_region(launches, gatherer: Optional['OutputGatherer']) -> None:
+def run_region(launches, gatherer: Optional['OutputGatherer'], on_compute_enqueued=None) -> None:
   """One region of a sharded rollout: every launch (a callable that enqueues <= k agent steps of this rank's shard and
   fills its [c, n_local] reward / terminal blocks) is followed by the gather of exactly those blocks to the learner
   rank -- the last, shorter launch of a region included -- and the region ends when the exchanges have been waited for.
@@ -169,6 +177,8 @@ def run_region(launches, gatherer: Optional['OutputGatherer']) -> None:
         gatherer.gather(item[1], item[2])                 # (launch, reward rows, terminal rows): two exchanges
       else:
         gatherer.gather_packed(item[1], item[2].shape[0])  # (launch, packed buffer, reward view, terminal view): one
+  if on_compute_enqueued is not None:
+    on_compute_enqueued()        # (bench.py records an event here: what follows on the compute stream is exposed exchange time)
   if gatherer is not None:
     gatherer.wait()
 

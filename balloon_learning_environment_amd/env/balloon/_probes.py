@@ -42,10 +42,43 @@ def atmosphere(alpha, pressure):
   return float(h.item()), float(t.item())
 
 
-def solar(lat_deg, lng_deg, unix_s):
-  """solar_calculator at a site -> (refraction-corrected elevation deg, flux W/m^2)."""
+def latlng(center_lat_deg, center_lng_deg, x_m, y_m):
+  """BalloonState.latlng: (lat deg, lng deg) of the point (x, y) metres east / north of the centre."""
   dev.require_gpu('cuda')
-  la, lo, x, y = _f32(lat_deg, lng_deg, 0.0, 0.0)
+  la, lo, x, y = _f32(center_lat_deg, center_lng_deg, x_m, y_m)
+  out = torch.empty(2, dtype=torch.float64, device='cuda')
+  _lib.check(_lib.lib().ble_probe_latlng_f64(la.data_ptr(), lo.data_ptr(), x.data_ptr(), y.data_ptr(), out[0:1].data_ptr(),
+                                             out[1:2].data_ptr(), 1, _stream()), 'ble_probe_latlng_f64')
+  lat, lng = out.cpu().tolist()
+  return lat, lng
+
+
+def atmosphere_column(alpha, pressures):
+  """Atmosphere.at_pressure for a vector of pressures (no range check: out-of-range entries come back as they are) ->
+  (heights m, temperatures K) as float64 NumPy arrays of the device's float32 results."""
+  dev.require_gpu('cuda')
+  p = torch.as_tensor(np.asarray(pressures, np.float32), device='cuda')
+  a = torch.full_like(p, float(alpha))
+  h, t, flags = torch.empty_like(p), torch.empty_like(p), _flags()
+  _lib.check(_lib.lib().ble_probe_atmosphere_f32(a.data_ptr(), p.data_ptr(), h.data_ptr(), t.data_ptr(), flags.data_ptr(), p.numel(),
+                                                 _stream()), 'ble_probe_atmosphere_f32')
+  return h.cpu().numpy().astype(np.float64), t.cpu().numpy().astype(np.float64)
+
+
+def power_table(pressure_ratio, state_of_charge):
+  """power_table.lookup -> watts; raises like the reference outside [0.99, 5]."""
+  dev.require_gpu('cuda')
+  r, c = _f32(pressure_ratio, state_of_charge)
+  w, flags = _out(), _flags()
+  _lib.check(_lib.lib().ble_power_table_f32(r.data_ptr(), c.data_ptr(), w.data_ptr(), flags.data_ptr(), 1, _stream()), 'ble_power_table_f32')
+  _raise(flags)
+  return float(w.item())
+
+
+def solar(lat_deg, lng_deg, unix_s, x_m=0.0, y_m=0.0):
+  """solar_calculator at the point (x, y) metres east / north of (lat, lng) -> (refraction-corrected elevation deg, flux W/m^2)."""
+  dev.require_gpu('cuda')
+  la, lo, x, y = _f32(lat_deg, lng_deg, x_m, y_m)
   t = torch.tensor([int(unix_s)], dtype=torch.int64, device='cuda')
   el, flux = _out(), _out()
   _lib.check(_lib.lib().ble_probe_solar_f32(la.data_ptr(), lo.data_ptr(), x.data_ptr(), y.data_ptr(), t.data_ptr(), el.data_ptr(),

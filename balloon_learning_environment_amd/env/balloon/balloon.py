@@ -12,7 +12,6 @@ import math
 
 import numpy as np
 
-from balloon_learning_environment_amd import reset_host
 from balloon_learning_environment_amd.env.balloon import control
 from balloon_learning_environment_amd.utils import units
 
@@ -95,10 +94,8 @@ class BalloonState:
 
   @property
   def latlng(self) -> LatLng:  # balloon.py:217-220
-    lat, lng = reset_host.latlng_from_offset(np.array([math.radians(self.center_latlng.lat_deg)]),
-                                             np.array([math.radians(self.center_latlng.lng_deg)]),
-                                             np.array([self.x.m]), np.array([self.y.m]))
-    return LatLng(math.degrees(lat[0]), math.degrees(lng[0]))
+    from balloon_learning_environment_amd.env.balloon import _probes
+    return LatLng(*_probes.latlng(self.center_latlng.lat_deg, self.center_latlng.lng_deg, self.x.m, self.y.m))
 
   @property
   def battery_soc(self) -> float:
@@ -106,11 +103,9 @@ class BalloonState:
 
   @property
   def excess_energy(self) -> bool:  # balloon.py:231-238
-    ll = self.latlng
-    el, _ = reset_host.solar_calculator(np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)]),
-                                        np.array([int(self.date_time.timestamp())]))
-    return bool(solar_power_watts(float(el[0]), self.pressure) > self.daytime_power_load.watts and
-                self.battery_soc > 0.99)
+    from balloon_learning_environment_amd.env.balloon import _probes
+    el, _ = _probes.solar(self.center_latlng.lat_deg, self.center_latlng.lng_deg, int(self.date_time.timestamp()), self.x.m, self.y.m)
+    return bool(solar_power_watts(el, self.pressure) > self.daytime_power_load.watts and self.battery_soc > 0.99)
 
   @property
   def navigation_is_paused(self) -> bool:
@@ -123,13 +118,9 @@ class BalloonState:
 
 
 def solar_power_watts(el_deg: float, pressure: float) -> float:
-  """solar.solar_power (solar.py:515-536), host scalar (used by excess_energy / reward mirror)."""
-  att = float(reset_host.solar_atmospheric_attenuation(np.array([el_deg]), np.array([pressure]))[0])
-
-  def shadow(h):
-    return 0.4392 if el_deg >= math.degrees(math.atan2(math.sqrt(h * (10.41603 + h)), 8.69275)) else 1.0
-  return 210.0 * att * (4 * math.cos(math.radians(el_deg - 35)) * shadow(3.3) +
-                        2 * math.cos(math.radians(el_deg - 65)) * shadow(2.7))
+  """solar.solar_power (solar.py:515-536) [W], by the transition's device function (`ble_probe_solar_power_f32`)."""
+  from balloon_learning_environment_amd.env.balloon import _probes
+  return _probes.solar_power(el_deg, pressure)[1]
 
 
 # ---- row <-> BalloonState ----------------------------------------------------------------
@@ -161,10 +152,9 @@ def row_from_state(s: BalloonState, alpha: float) -> dict:
   elapsed = int(s.time_elapsed.total_seconds())
   start = now - elapsed
   if s.sunrise_with_hysteresis is None or s.sunset is None:
-    ll = s.latlng
-    sr, ss = reset_host.next_sunrise_sunset(np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)]),
-                                            np.array([now]))
-    sunrise_h, sunset = int(sr[0]) + 1800, int(ss[0])
+    from balloon_learning_environment_amd.env.balloon import solar      # (the reset kernel's search, solar.py:432-483)
+    sr, ss = solar.get_next_sunrise_sunset(s.latlng, s.date_time)
+    sunrise_h, sunset = int(sr.timestamp()) + 1800, int(ss.timestamp())
   else:
     sunrise_h, sunset = int(s.sunrise_with_hysteresis.timestamp()), int(s.sunset.timestamp())
   return dict(x=s.x.m, y=s.y.m, pressure=s.pressure, ambient_temperature=s.ambient_temperature,

@@ -1,16 +1,16 @@
 """env/balloon/standard_atmosphere.py:52-202 of the reference: `Atmosphere(key)` with `at_pressure` / `at_height`.
 
 `at_pressure` -- the lookup the transition makes every stride -- runs the kernel's own device function
-(`ble_probe_atmosphere_f32`); `at_height` is needed once per episode (the 50 000 ft pressure bound of the initial-condition
-sampler, utils/sampling.py:86-117; the reset kernel has it inline) and is served by the host tables of `reset_host`."""
+(`ble_probe_atmosphere_f32`); `at_height` (needed once per episode: the 50 000 ft pressure bound of the initial-condition
+sampler, utils/sampling.py:86-117, which the reset kernel has inline) INVERTS that same device function by bracketing --
+four launches of 4 096 pressures -- so that the package holds one implementation of the atmosphere, the device's."""
 import dataclasses
 
 import numpy as np
 
-from balloon_learning_environment_amd import reset_host
 from balloon_learning_environment_amd.utils import units
 
-DRY_AIR_SPECIFIC_GAS_CONSTANT = reset_host.DRY_AIR_SPECIFIC_GAS_CONSTANT
+DRY_AIR_SPECIFIC_GAS_CONSTANT = 8.3144621 / 0.028964922481160      # utils/constants.py: R / M_dry_air
 
 
 @dataclasses.dataclass
@@ -32,10 +32,26 @@ class AtmosphereOps:
                              float(pressure) / (DRY_AIR_SPECIFIC_GAS_CONSTANT * temperature))
 
   def at_height(self, height: units.Distance) -> AtmosphericValues:
-    tables = reset_host.AtmosphereTables(np.array([self.alpha]))
-    pressure, temperature = tables.at_height(np.array([height.meters]))   # asserts the reference's height range (:94-95)
-    return AtmosphericValues(units.Distance(meters=height.meters), float(temperature[0]), float(pressure[0]),
-                             float(pressure[0]) / (DRY_AIR_SPECIFIC_GAS_CONSTANT * float(temperature[0])))
+    from balloon_learning_environment_amd.env.balloon import _probes
+    h = float(height.meters)
+    assert -610.0 <= h < 85000.0, 'Atmosphere.at_height: height out of range (standard_atmosphere.py:94-95)'
+    # height falls monotonically with pressure: bracket h on a geometric pressure grid and refine; the device evaluates in
+    # fp64 and returns float32 (resolution 1 mm at 15 km), a float32 pressure resolves 6e-8 relative
+    lo, hi = 0.3, 120000.0                                   # Pa: 85 km .. -610 m
+    for _ in range(4):
+      ps = np.geomspace(lo, hi, 4096)
+      hs, _ = _probes.atmosphere_column(self.alpha, ps)
+      ok = np.isfinite(hs)
+      k = int(np.searchsorted(-hs[ok], -h))                   # first grid pressure whose height is <= h
+      ps_ok = ps[ok]
+      k = min(max(k, 1), ps_ok.size - 1)
+      lo, hi = float(ps_ok[k - 1]), float(ps_ok[k])
+    (h0, h1), (t0, t1) = _probes.atmosphere_column(self.alpha, [lo, hi])
+    w = 0.0 if h0 == h1 else (h0 - h) / (h0 - h1)
+    pressure = lo * (hi / lo) ** w
+    temperature = t0 + w * (t1 - t0)
+    return AtmosphericValues(units.Distance(meters=h), float(temperature), float(pressure),
+                             float(pressure) / (DRY_AIR_SPECIFIC_GAS_CONSTANT * float(temperature)))
 
 
 class Atmosphere(AtmosphereOps):

@@ -13,7 +13,6 @@ import numpy as np
 import torch
 
 from balloon_learning_environment_amd import _abi
-from balloon_learning_environment_amd import reset_host
 from balloon_learning_environment_amd import vec_state
 from balloon_learning_environment_amd.env import features
 from balloon_learning_environment_amd.env import grid_based_wind_field
@@ -67,9 +66,10 @@ class VecBalloonArena:
     self._seed0, self._reset_count = None, 0
     self.reset(seed)
 
-  def reset(self, seed: Optional[int] = None, on_device: bool = True, upwelling_ir='reference') -> None:
-    """New episodes for every env.  on_device=True: ble_reset_f32 (Philox streams on the GPU);
-    False: the NumPy host path (reset_host.py) -- same distributions, different streams.
+  def reset(self, seed: Optional[int] = None, on_device: bool = True) -> None:
+    """New episodes for every env, by ble_reset_f32 (Philox streams on the GPU).  There is no host path: on_device=False
+    (rounds 1-4: a NumPy sampler, now test tooling in tests/reset_host.py) raises; a host-made state goes in through
+    `sim.set_state(...)` followed by `sim.reset_observation_history()`.
     reset(seed) is reproducible: the same seed gives the same episodes and wind field(s), whatever
     happened before (the reference's env.seed(s); env.reset() contract, eval/eval_lib.py)."""
     if seed is not None:
@@ -81,11 +81,9 @@ class VecBalloonArena:
     seed = _mix_seed(self._seed0, self._reset_count)
     self._seed = seed
     self.sim.episode.zero_()            # Philox streams are keyed by (seed, env, episode): restart the count
-    if on_device:
-      self.sim.reset_device(seed)
-    else:
-      self.sim.set_state(reset_host.sample_initial_state(self.num_envs, seed=seed, upwelling_ir=upwelling_ir))
-      self.sim.reset_observation_history()     # (reset_device does this itself: a new episode starts a new WindGP window)
+    if not on_device:
+      raise NotImplementedError('VecBalloonArena.reset: the episode reset runs on the device only (ble_reset_f32)')
+    self.sim.reset_device(seed)
     self.wind_field.reset(np.array([seed], np.uint32), None)
     self._field_epoch = 0
     if self.per_env_fields:

@@ -1,25 +1,20 @@
 """FeatureConstructor interface (env/features.py:106-144).
 
-`PerciatelliFeatureConstructor` (env/features.py:269-581) is the single-environment host
-observation path (stage S1): 16 ambient features + a 361-level relative
-wind column from the WindGP.  The forecast column comes from the device kernel through
-`GridBasedWindField`; the GP algebra, sunrise search and pressure-range solve are host NumPy.
-`StateFeatureConstructor` is a compact raw-state observation for vectorised consumers.
+`PerciatelliFeatureConstructor` (env/features.py:269-581): 16 ambient features + a 361-level relative wind column from the
+WindGP, computed by `ble_observe_f32` (csrc/ble_observe.h) for a one-environment batch -- the WindGP history and its factor
+live on the device.  There is no host implementation in this package: a forecast without a device grid is refused.  (The
+NumPy restatement the parity tests check the kernel against is oracle/features_oracle.py; the former host constructor lives
+next to the tests, tests/features_host.py.)  `StateFeatureConstructor` is a compact raw-state observation for vectorised
+consumers.
 """
 import abc
 import dataclasses
-import datetime as dt
-import logging
 import math
 
 import numpy as np
 
-from balloon_learning_environment_amd import reset_host
 from balloon_learning_environment_amd.env import simulator_data
-from balloon_learning_environment_amd.env import wind_gp
 from balloon_learning_environment_amd.env.balloon import control
-from balloon_learning_environment_amd.env.balloon import power_table
-from balloon_learning_environment_amd.env.balloon import pressure_range_builder
 from balloon_learning_environment_amd.utils import constants
 from balloon_learning_environment_amd.utils import transforms
 from balloon_learning_environment_amd.utils import units
@@ -27,25 +22,19 @@ from balloon_learning_environment_amd.utils import units
 TOLERANCE = units.Distance(meters=1e-5)
 
 
-def _latlng_rad(balloon_state):
-  ll = balloon_state.latlng
-  return np.array([math.radians(ll.lat_deg)]), np.array([math.radians(ll.lng_deg)])
-
-
 def compute_solar_angle(balloon_state) -> float:
-  """Solar elevation [deg] at the balloon (env/features.py:56-70)."""
-  lat, lng = _latlng_rad(balloon_state)
-  el, _ = reset_host.solar_calculator(lat, lng, np.array([int(balloon_state.date_time.timestamp())]))
-  return float(el[0])
+  """Solar elevation [deg] at the balloon (env/features.py:56-70), by the transition's device function."""
+  from balloon_learning_environment_amd.env.balloon import solar
+  return solar.solar_calculator(balloon_state.latlng, balloon_state.date_time)[0]
 
 
 def compute_sunrise_time(balloon_state) -> float:
   """Normalised solar-cycle time (env/features.py:73-104): [sunrise, sunset] -> [0, pi],
-  [sunset, next sunrise] -> [pi, 2 pi]."""
+  [sunset, next sunrise] -> [pi, 2 pi]; the two events by the reset kernel's search."""
+  from balloon_learning_environment_amd.env.balloon import solar
   now = int(balloon_state.date_time.timestamp())
-  lat, lng = _latlng_rad(balloon_state)
-  sunrise, sunset = reset_host.next_sunrise_sunset(lat, lng, np.array([now], np.int64))
-  sunrise, sunset = int(sunrise[0]), int(sunset[0])
+  sunrise, sunset = solar.get_next_sunrise_sunset(balloon_state.latlng, balloon_state.date_time)
+  sunrise, sunset = int(sunrise.timestamp()), int(sunset.timestamp())
   day = constants.NUM_SECONDS_PER_DAY
   assert sunrise - day <= now <= sunrise
   assert sunset - day <= now <= sunset
@@ -170,117 +159,14 @@ _UNREACHABLE = (0.0, 1.0, 1.0)   # certain, wrong way, infinitely fast
 
 
 class PerciatelliFeatureConstructor(FeatureConstructor):
-  """env/features.py:269-581.  `forecast` needs get_forecast / get_forecast_column."""
-
-  def __init__(self, forecast, atmosphere) -> None:
-    self.num_pressure_levels = 181
-    self.min_pressure = constants.PERCIATELLI_PRESSURE_RANGE_MIN
-    self.max_pressure = constants.PERCIATELLI_PRESSURE_RANGE_MAX
-    self.pressure_levels = np.linspace(self.min_pressure, self.max_pressure, self.num_pressure_levels)
-    self.num_features = 3 * (self.num_pressure_levels * 2 - 1) + 16
-    self.windgp = wind_gp.WindGP(forecast)
-    self._atmosphere = atmosphere
-    self._last_balloon_state = None
-
-  def observe(self, observation: simulator_data.SimulatorObservation) -> None:
-    b = observation.balloon_observation
-    self._last_balloon_state = b
-    self.windgp.observe(b.x, b.y, b.pressure, b.time_elapsed, observation.wind_at_balloon)
-
-  def get_features(self) -> np.ndarray:
-    p = self._last_balloon_state.pressure
-    if not self.is_valid_pressure(p):
-      logging.warning('Balloon pressure %.2f not fully represented by feature constructor.', p)
-    out = np.zeros(self.num_features, dtype=np.float32)
-    self._add_ambient_features(out)
-    self._add_wind_features(out)
-    return out
-
-  @property
-  def observation_space(self) -> Box:
-    low = np.zeros(self.num_features, np.float32)
-    high = np.ones(self.num_features, np.float32)
-    low[[3, 4, 5, 6]] = -1.0
-    low[15], high[15] = 1.0, np.inf
-    return Box(low, high)
-
-  def is_valid_pressure(self, pressure: float) -> bool:
-    return self.min_pressure <= pressure <= self.max_pressure
-
-  def _nearest_pressure_level(self, pressure: float) -> int:
-    pressure = min(max(pressure, self.min_pressure), self.max_pressure)
-    delta = self.pressure_levels[1] - self.pressure_levels[0]
-    level = int(round((pressure - self.min_pressure) / delta))
-    assert 0 <= level < self.num_pressure_levels
-    return level
-
-  def _add_ambient_features(self, out: np.ndarray) -> None:
-    b = self._last_balloon_state
-    out[0] = transforms.linear_rescale_with_saturation(b.pressure, self.min_pressure, self.max_pressure)
-    out[1] = b.battery_soc
-    out[2] = transforms.linear_rescale_with_saturation(compute_solar_angle(b), -90.0, 90.0)
-    cycle = compute_sunrise_time(b)
-    assert 0 <= cycle <= 2 * math.pi + 1e-6
-    out[3], out[4] = math.sin(cycle), math.cos(cycle)
-    heading = math.atan2(-b.x.kilometers, -b.y.kilometers)      # from north, increasing east
-    out[5], out[6] = math.sin(heading), math.cos(heading)
-    out[7] = transforms.squash_to_unit_interval(units.relative_distance(b.x, b.y).kilometers, 250)
-    out[8] = float(b.last_command == control.AltitudeControlCommand.UP)
-    out[9] = float(b.last_command == control.AltitudeControlCommand.STAY)
-    out[10] = float(b.last_command == control.AltitudeControlCommand.DOWN)
-    out[11] = float(b.navigation_is_paused)
-    out[12] = float(not b.navigation_is_paused)
-    out[13] = float(b.excess_energy)
-    out[14] = transforms.linear_rescale_with_saturation(power_table.lookup(b.pressure_ratio, b.battery_soc), 100, 300)
-    out[15] = b.pressure_ratio
-
-  def _add_wind_features(self, out: np.ndarray) -> None:
-    b = self._last_balloon_state
-    n = self.num_pressure_levels
-    query = np.zeros((n, 4))
-    query[:, 0], query[:, 1] = b.x.meters, b.y.meters
-    query[:, 2] = self.pressure_levels
-    query[:, 3] = b.time_elapsed.total_seconds()
-    means, deviations = self.windgp.query_batch(query)
-
-    level = self._nearest_pressure_level(b.pressure)
-    pad_above = n - level - 1                 # lower-pressure side of the relative column
-    pad_below = (2 * n - 1) - pad_above - n
-    assert pad_below >= 0
-
-    distance = units.relative_distance(b.x, b.y)
-    to_station = -np.array([b.x.meters, b.y.meters]) / (distance + TOLERANCE).meters
-    reachable = pressure_range_builder.get_pressure_range(b, self._atmosphere)
-
-    winds = means[:, 0:2]
-    speed = np.linalg.norm(winds, axis=1, ord=2)
-    winds = winds / (speed + TOLERANCE.meters).reshape(-1, 1)
-    if distance < TOLERANCE:
-      angle = np.zeros(n, np.float32)
-    else:
-      angle = np.arccos(np.clip(winds @ to_station, -1.0, 1.0))
-      angle = np.where(speed < TOLERANCE.meters, np.pi, angle)
-    angle_feat = transforms.linear_rescale_with_extrapolation(angle, 0, math.pi)
-    speed_feat = transforms.squash_to_unit_interval(speed, 30)
-
-    column = np.empty((2 * n - 1, 3), np.float32)
-    column[:] = _UNREACHABLE
-    ok = (self.pressure_levels >= reachable.min_pressure) & (self.pressure_levels <= reachable.max_pressure)
-    assert np.all((deviations[ok] >= 0.0) & (deviations[ok] <= 1.00001)), 'Uncertainty not in [0, 1].'
-    body = column[pad_above:pad_above + n]
-    body[ok, 0], body[ok, 1], body[ok, 2] = deviations[ok], angle_feat[ok], speed_feat[ok]
-    out[16:] = column.reshape(-1)
-
-
-class DevicePerciatelliFeatureConstructor(FeatureConstructor):
-  """Same observation, computed by `ble_observe_f32` for a one-environment batch (the WindGP
+  """env/features.py:269-581, computed by `ble_observe_f32` for a one-environment batch (the WindGP
   history and its factor live on the device).  Needs a grid-based forecast; for N environments
   use `VecBalloonArena.observe` directly."""
 
   def __init__(self, forecast, atmosphere) -> None:
     from balloon_learning_environment_amd import vec_state       # (device module: imported on use)
     if getattr(forecast, 'grid', None) is None:
-      raise TypeError('DevicePerciatelliFeatureConstructor needs a GridBasedWindField forecast')
+      raise TypeError('PerciatelliFeatureConstructor needs a forecast with a device grid (GridBasedWindField): this package has no host observation path')
     self._forecast, self._alpha = forecast, float(atmosphere.alpha)
     self._sim = vec_state.VecSimulator(1, forecast.device)
     self._sim.set_grid(forecast.grid)
@@ -343,10 +229,10 @@ class DevicePerciatelliFeatureConstructor(FeatureConstructor):
     return Box(low, high)
 
 
+DevicePerciatelliFeatureConstructor = PerciatelliFeatureConstructor      # (the name rounds 2-4 used)
+
+
 def perciatelli_feature_constructor(forecast, atmosphere) -> FeatureConstructor:
-  """Default factory of BalloonEnv / BalloonArena: the device observation (`ble_observe_f32`)
-  whenever the forecast is a device grid; the host constructor only for forecast objects that
-  exist on the host alone (e.g. the unit-test SimpleStaticWindField)."""
-  if getattr(forecast, 'grid', None) is not None:
-    return DevicePerciatelliFeatureConstructor(forecast, atmosphere)
+  """Default factory of BalloonEnv / BalloonArena: the device observation (`ble_observe_f32`).  A forecast object that exists
+  on the host alone (no `grid` on a HIP device) raises TypeError."""
   return PerciatelliFeatureConstructor(forecast, atmosphere)

@@ -42,8 +42,10 @@ Besides `value`, the default run reports (rank 0; every leg is the same code pat
                  and [4]'s per-GPU share (32 768 envs with per-env grids), and the single-env facade
                  (configs[0]'s counterpart: BalloonEnv.step with the device observation)
   `config.ground_truth_wind`  the headline rollout flown in WindField.get_ground_truth (noise generated in-kernel, ABI 3)
-  `roofline.instruction_issue`  SQ issue counters of the headline launch shape measured IN THIS RUN (a third --pmc pass);
-                 `roofline.valu_issue_frac` is the fraction of the bound that actually applies
+  `roofline`     bound = "valu-issue": frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the headline launch shape measured IN
+                 THIS RUN (a third --pmc pass; `instruction_issue` holds the counters); `hbm_formal` (algorithmic
+                 bytes / kernel time / 8 TB/s) and `hbm_measured` (PMC traffic / kernel time) are the secondary fields
+  `per_rank`     kernel time and exposed exchange time of a timed region on every rank (HIP events)
   `observe`      the closed-loop cost: step + wind noise + the 1099-feature observation (ble_observe_f32)
                  with a full WindGP window, its own roofline and measured traffic
   `cpu_baseline` the fp64 C oracle on this box's host cores (N = 1 only)
@@ -146,17 +148,21 @@ class Rollout:
     import numpy as np
     import torch
     from balloon_learning_environment_amd import distributed as bdist
-    from balloon_learning_environment_amd import reset_host
     from balloon_learning_environment_amd import vec_state
     self.torch, self.bdist, self.np = torch, bdist, np
     self.n, self.device, self.rank, self.world = n, device, rank, world
     self.steps, self.warmup, self.substeps = steps, warmup, substeps
-    self.noise_seed = noise_seed          # None: forecast wind; else WindField.get_ground_truth, noise generated in-kernel
+    # None: forecast wind; else WindField.get_ground_truth, noise generated in-kernel.  The generator is keyed by
+    # (seed, LOCAL env index, episode): every rank gets its own seed, or all shards would fly the same noise fields
+    self.noise_seed = None if noise_seed is None else int(noise_seed) + rank
     k_total = steps + warmup
-    # synthetic inputs (host, seeded; env i of the GLOBAL batch always gets the same draw), resident in HBM
-    self.host_state = reset_host.sample_initial_state(n, seed=seed_base + rank)
+    # synthetic inputs: the product's own episode reset (ble_reset_f32, sample = 1: the reference's initial-condition
+    # distributions from a Philox stream keyed by (seed, env, episode); one seed per rank), resident in HBM.  The legs that
+    # restart the episodes copy this snapshot back.  (Rounds 1-4 drew them with a NumPy sampler that is test tooling now.)
     self.sim = vec_state.VecSimulator(n, device)
-    self.sim.set_state(self.host_state)
+    self.sim.reset_device(seed=seed_base + rank)
+    self.sim.check_errors()
+    self.initial_state = {k: t.clone() for k, t in self.sim.state.items()}
     self.decode_ms = None
     if per_env_grids:     # no broadcast at all: every rank decodes its own latents into per-env grids
       from balloon_learning_environment_amd.env import generative_wind_field
@@ -177,6 +183,15 @@ class Rollout:
     # one receive slot per launch of a region: when the region's wait() returns, rank 0 holds EVERY launch's rows
     self.gatherer = bdist.OutputGatherer(GATHER_EVERY, n, device, world, slots=self.launches_per_region) if world > 1 else None
 
+
+  def restart_episodes(self):
+    """Back to the initial states of this preset (device-to-device copies)."""
+    for k, t in self.sim.state.items():
+      t.copy_(self.initial_state[k])
+
+  def initial_host_state(self):
+    return {k: t.cpu().numpy() for k, t in self.initial_state.items()}
+
   def plan(self, k0, k1):
     """The launches of steps k0 .. k1 - 1, prepared once (VecSimulator.prepare_step_n: checks and argument marshalling
     happen here, outside any timed region): (launch, packed output buffer, reward rows, terminal rows) per launch.  A
@@ -190,9 +205,9 @@ class Rollout:
       k += c
     return out
 
-  def run(self, k0, k1, plan=None):
+  def run(self, k0, k1, plan=None, on_compute_enqueued=None):
     # every launch's rows -- the last, shorter one of a region too -- go to rank 0; the region ends when they have arrived
-    self.bdist.run_region(plan if plan is not None else self.plan(k0, k1), self.gatherer)
+    self.bdist.run_region(plan if plan is not None else self.plan(k0, k1), self.gatherer, on_compute_enqueued)
 
   def time_reps(self, reps):
     """Warm-up, snapshot, then `reps` x (restore snapshot; barrier+sync; K steps; sync+barrier).
@@ -203,8 +218,8 @@ class Rollout:
     torch.cuda.synchronize()
     snap = {k: t.clone() for k, t in self.sim.state.items()}
     live0 = float((self.sim.state['status'] == 0).sum().item())
-    wall, live, ev_ms = [], [], []
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    wall, live, ev_ms, ev_exposed_ms = [], [], [], []
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); evk = torch.cuda.Event(enable_timing=True)
     plan = self.plan(self.warmup, self.warmup + self.steps)
     g0 = (self.gatherer.gathers, self.gatherer.rows_gathered) if self.gatherer is not None else (0, 0)
     # The wall-clock repetitions carry no event records (two records cost ~10 us of host time per region: 2.4 % of a
@@ -217,13 +232,15 @@ class Rollout:
       torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
       t0 = time.perf_counter()
       if with_events: ev0.record()            # the kernels are launched on torch's current stream
-      self.run(self.warmup, self.warmup + self.steps, plan)
+      # (evk: behind the last launch, in front of the compute stream's wait for the exchanges -- ev0 .. evk is this rank's kernel
+      # time, evk .. ev1 the exchange time that no launch hides)
+      self.run(self.warmup, self.warmup + self.steps, plan, (lambda: evk.record()) if with_events else None)
       if with_events: ev1.record()
       torch.cuda.synchronize(); barrier()
       dt = time.perf_counter() - t0
       torch.cuda.synchronize()
       if with_events:
-        ev_ms.append(ev0.elapsed_time(ev1))
+        ev_ms.append(ev0.elapsed_time(evk)); ev_exposed_ms.append(evk.elapsed_time(ev1))
         continue
       wall.append(self.bdist.max_over_ranks(dt, self.device))
       # an env is stepped iff it was not terminal after the previous step; counted outside the timed region
@@ -239,10 +256,26 @@ class Rollout:
       assert self.gathers_per_region == self.launches_per_region and self.rows_gathered_per_region == self.steps
     else:
       self.gathers_per_region = self.rows_gathered_per_region = 0
+    self.ev_exposed_ms = ev_exposed_ms
     return wall, live, ev_ms
+
+  def per_rank(self, ev_ms):
+    """Per rank: kernel time and exposed (unhidden) exchange time of a timed region, HIP events on the compute stream --
+    so that a multi-GPU line decomposes itself."""
+    torch = self.torch
+    mine = torch.tensor([1e3 * statistics.fmean(ev_ms), 1e3 * statistics.fmean(self.ev_exposed_ms)], dtype=torch.float64, device=self.device)
+    if self.world > 1:
+      rows = [torch.zeros_like(mine) for _ in range(self.world)]
+      torch.distributed.all_gather(rows, mine)
+    else:
+      rows = [mine]
+    rows = [r.cpu().tolist() for r in rows]
+    return {'kernel_us_per_timed_region': [r[0] for r in rows], 'exposed_exchange_us_per_timed_region': [r[1] for r in rows],
+            'what': 'HIP events on each rank\'s compute stream: first launch .. last launch | last launch .. the exchanges waited for'}
 
   def summary(self, reps):
     wall, live, ev_ms = self.time_reps(reps)
+    per_rank = self.per_rank(ev_ms)
     rates = [l / w for l, w in zip(live, wall)]
     order = sorted(range(reps), key=lambda i: rates[i])
     med = order[reps // 2]
@@ -256,7 +289,7 @@ class Rollout:
             'live_env_steps_per_repetition': live[med], 'envs_per_gpu': self.n, 'global_envs': int(round(self.bdist.sum_over_ranks(float(self.n), self.device))),
             'live_env_fraction_end': self.live_fraction_end, 'decode_ms': self.decode_ms,
             'gathers_per_region': self.gathers_per_region, 'rows_gathered_per_region': self.rows_gathered_per_region,
-            'launches_per_region': self.launches_per_region}
+            'launches_per_region': self.launches_per_region, 'per_rank': per_rank}
 
 
 def observe_leg(roll, pairs, world, measure=False):
@@ -264,7 +297,7 @@ def observe_leg(roll, pairs, world, measure=False):
   torch, bdist = roll.torch, roll.bdist
   sim, n, device = roll.sim, roll.n, roll.device
   k_total = roll.actions.shape[0]
-  sim.set_state(roll.host_state)                         # fresh episodes
+  roll.restart_episodes()                                # fresh episodes
   obs = torch.empty(n, 1099, dtype=torch.float32, device=device)
   sim.reset_observation_history()
   obs_gatherer = bdist.ObservationGatherer(n, 1099, device, world, mode='gather') if world > 1 else None
@@ -352,7 +385,7 @@ def policy_in_the_loop_leg(roll, launches=256):
   the back-to-back rate of `launches` launches and the median HIP-event duration of a single one."""
   torch = roll.torch
   sim, n = roll.sim, roll.n
-  sim.set_state(roll.host_state)
+  roll.restart_episodes()
   k_total = roll.actions.shape[0]
   for i in range(8):
     sim.step(roll.actions[i % k_total])
@@ -608,11 +641,12 @@ def main():
     issue, issue_note = measure_issue('ble_step_kernel', child, head.launches_per_region, groups=3,
                                       agent_steps_per_launch=args.steps / head.launches_per_region)
   if issue is None:            # labelled fallback: the committed profile of an earlier build, NOT this run
-    for tag in ('r04', 'r03', 'r02', 'r01'):
+    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
       try:
         d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
         per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)
         issue = {'wave_issue_utilisation': d['active_inst_any_quad'] / d['wave_cycles_per_wave_quad'],
+                 'valu_issue_frac': d['active_inst_valu_quad'] / d['wave_cycles_per_wave_quad'],
                  'valu_insts_per_env_step': d['valu_insts_per_wave'] / per, 'salu_insts_per_env_step': d['salu_insts_per_wave'] / per,
                  'source': f'NOT measured in this run ({issue_note or "N > 1, --no-extras or --traffic off"}): profiles/{tag}_summary.json '
                            f'(rocprofv3 --pmc, per {int(per)}-step launch)'}
@@ -644,6 +678,7 @@ def main():
       del rn
     if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
       observe = observe_leg(head, args.observe, world, measure=(args.traffic == 'auto'))
+    head_initial_host_state = head.initial_host_state() if (world == 1 and not args.no_cpu_baseline) else None
     del head
     torch.cuda.empty_cache()
     for cfg in (1, 2, 3, 4):
@@ -706,19 +741,30 @@ def main():
                                  'bytes_per_rank_per_timed_region': 5 * n * hs['rows_gathered_per_region']}},
         'repetitions': {k: hs[k] for k in ('repetitions', 'steps_per_repetition', 'env_steps_per_s_min', 'env_steps_per_s_max',
                                             'env_steps_per_s_first_repetition', 'ms_per_step_min', 'ms_per_step_max')},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_detail': traffic_detail, 'traffic_note': traffic_note,
+        # What bounds ble_step_kernel is VALU issue at one wave per SIMD, so that is `bound` / `frac` (measured in this run by
+        # a nested rocprofv3 --pmc pass: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES).  The SURVEY 8(d) HBM figures stay as named
+        # secondary fields: `hbm_formal` = algorithmic bytes / kernel time, `hbm_measured` = PMC traffic / kernel time.
+        'roofline': {'bound': 'valu-issue', 'achieved': (issue or {}).get('valu_issue_frac'), 'peak': 1.0,
+                     'unit': 'VALU-issuing cycles per wave cycle (one wave per SIMD)', 'frac': (issue or {}).get('valu_issue_frac'),
+                     'frac_source': (issue or {}).get('source', 'measured in this run: nested rocprofv3 --pmc pass (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)'),
+                     'traffic': traffic, 'traffic_detail': traffic_detail, 'traffic_note': traffic_note,
+                     'hbm_formal': {'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                                    'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
+                                    'what': 'SURVEY 8(d): 280 B per env-step x live env-steps of a launch / its average duration'},
+                     'hbm_measured': ({'achieved': traffic / (hs['kernel_ms_mean'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                       'frac': traffic / (hs['kernel_ms_mean'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       'ratio_to_algorithmic': traffic / bytes_per_launch} if traffic else None),
                      'kernel': 'ble_step_kernel', 'kernel_ms': hs['kernel_ms_mean'], 'kernel_ms_median': hs['kernel_ms_median'], 'kernel_ms_min': hs['kernel_ms_min'],
                      'kernel_event_repetitions': hs['kernel_event_repetitions'],
                      'agent_steps_per_launch': args.steps / -(-args.steps // GATHER_EVERY),
                      'kernel_us_per_agent_step': 1e3 * hs['kernel_ms_mean'] * (-(-args.steps // GATHER_EVERY)) / args.steps,
-                     'algorithmic_bytes_per_env_step': ALGORITHMIC_BYTES_PER_ENV_STEP,
-                     'note': 'frac is the SURVEY 8(d) formal fraction (algorithmic bytes / time / peak); the measured HBM traffic '
-                             '(`traffic`, bytes per launch) is a few % of the algorithmic bytes because the state stays in registers for 32 '
-                             'steps and the grid gather is served by L2: the kernel is fp64/fp32 VALU-issue bound (DESIGN.md 3)',
+                     'note': 'the measured HBM traffic (`traffic`, bytes per launch) is a few % of the algorithmic bytes because the state stays '
+                             f'in registers for the {args.steps / -(-args.steps // GATHER_EVERY):g} agent steps of a launch and the grid gather is served by L2: '
+                             'nothing is re-read, HBM is not the bound (DESIGN.md 3)',
                      'valu_issue_frac': (issue or {}).get('valu_issue_frac'),
                      'wave_issue_utilisation': (issue or {}).get('wave_issue_utilisation'),
                      'instruction_issue': issue},
+        'per_rank': hs['per_rank'],
         'configs': configs,
     }
     if policy is not None:
@@ -726,9 +772,8 @@ def main():
     if observe is not None:
       out['observe'] = observe
     if world == 1 and not args.no_cpu_baseline and not args.no_extras:
-      from balloon_learning_environment_amd import reset_host
-      acts = np.random.default_rng(7).integers(0, 3, (64, 65536)).astype(np.uint8)
-      out['cpu_baseline'] = cpu_baseline(reset_host.sample_initial_state(65536, seed=1000), list(acts), field)
+      acts = np.random.default_rng(7).integers(0, 3, (64, n)).astype(np.uint8)
+      out['cpu_baseline'] = cpu_baseline(head_initial_host_state, list(acts), field)     # the SAME initial states the GPU flew
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()

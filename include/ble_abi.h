@@ -37,7 +37,7 @@ extern "C" {
 /* 2: ble_state_f32 gained the optional episode_cache; ble_wind_noise_f32 the optional harmonic_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
  *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
 /* 3: ble_step_n_f32 gained `noise` (ble_noise_gen: the wind-noise generator evaluated inside the fused rollout). */
-#define BLE_ABI_VERSION 3
+#define BLE_ABI_VERSION 4
 
 /* return codes */
 #define BLE_OK 0
@@ -119,10 +119,10 @@ typedef struct ble_state_f32 {
 } ble_state_f32;
 #define BLE_EPISODE_CACHE_ROWS 7
 #define BLE_MAX_SUBSTEPS 60
-/* Up to this many environments ble_step_f32 / ble_step_n_f32 (without a noise generator) run the four-wavefronts-per-
- * environment form of the transition (csrc/ble_step_split.h: 4 x n / 64 waves -- one per SIMD up to 16 384 environments,
- * two up to 32 768), above it the one-lane-per-environment kernel (one wave per SIMD at 65 536).  The two are
- * bit-identical; BLE_STEP_SPLIT=0 / 1 in the process environment forces one. */
+/* Up to this many environments ble_step_f32 / ble_step_n_f32 -- with or without a wind-noise generator -- run the
+ * four-wavefronts-per-environment form of the transition (csrc/ble_step_split.h: 4 x n / 64 waves -- one per SIMD up to
+ * 16 384 environments, two up to 32 768), above it the one-lane-per-environment kernel (one wave per SIMD at 65 536).
+ * The forms are bit-identical; ble_set_step_form() forces one. */
 #define BLE_SPLIT_MAX_ENVS 32768
 
 int ble_abi_version(void);
@@ -130,6 +130,13 @@ int ble_abi_version(void);
 /* hipError_t (as int) of the calling thread's most recent launch through this library; 0 = success.
  * Diagnostic companion of BLE_E_LAUNCH. */
 int ble_last_hip_error(void);
+
+/* Which form of the transition kernel ble_step_f32 / ble_step_n_f32 launch: 0 = automatic (by batch size, above), 1 = one
+ * lane per environment, 4 = four wavefronts per environment, 2 = two (an A/B form the automatic choice never takes).
+ * Process-global, thread-safe; takes effect with the next launch.  Returns the previous setting (>= 0) or
+ * BLE_E_INVALID_ARG.  The initial value is 0, or what BLE_STEP_SPLIT (0 -> one lane, 1 / 4, 2) in the process environment
+ * says when the library first looks at it -- once, not per launch.  (ABI 4; ABI 3 re-read the variable on every launch.) */
+int ble_set_step_form(int waves_per_env);
 
 /* Number of visible HIP devices (>= 0) or BLE_E_NO_DEVICE. */
 int ble_device_count(void);
@@ -315,6 +322,10 @@ int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* h
 int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg, const float* x_m,
                         const float* y_m, const int64_t* unix_s, float* el_deg, float* flux,
                         int64_t n, void* stream);
+/* BalloonState.latlng (balloon.py:217-220, spherical_geometry.py:44-76): latitude / longitude [deg, float64] of the point
+ * (x, y) metres east / north of the centre -- the function the observation and the exact solar chain evaluate (ABI 4) */
+int ble_probe_latlng_f64(const float* center_lat_deg, const float* center_lng_deg, const float* x_m, const float* y_m,
+                         double* lat_deg, double* lng_deg, int64_t n, void* stream);
 /* solar_atmospheric_attenuation + solar_power (solar.py:177-209,515-536) from el [deg] */
 int ble_probe_solar_power_f32(const float* el_deg, const float* pressure, float* attenuation,
                               float* power_w, int64_t n, void* stream);

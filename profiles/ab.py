@@ -10,7 +10,9 @@ CHILD = r'''
 import sys, os, time, json, statistics, numpy as np, torch
 SUB = int(os.environ.get('AB_SUBSTEPS', '18'))
 sys.path.insert(0, '.')
-from balloon_learning_environment_amd import vec_state, reset_host
+from balloon_learning_environment_amd import vec_state
+sys.path.insert(0, 'tests')      # (the host-side state sampler is test tooling)
+import reset_host
 n = int(sys.argv[1]); do_obs = sys.argv[2] == '1'
 sim = vec_state.VecSimulator(n)
 field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)

@@ -5,7 +5,9 @@ differences of consecutive groups.   python profiles/obs_phases.py [n_envs]"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from balloon_learning_environment_amd import vec_state, reset_host, device as dev, _lib
+from balloon_learning_environment_amd import vec_state, device as dev, _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sim = vec_state.VecSimulator(n)
 field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)

@@ -10,7 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from balloon_learning_environment_amd import reset_host, vec_state  # noqa: E402
+from balloon_learning_environment_amd import _lib, vec_state  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
@@ -29,7 +31,7 @@ for t in range(steps):
   acts = torch.randint(0, 3, (n,), dtype=torch.uint8, device='cuda', generator=gen)
   noise = None
   for mode, s in sims.items():
-    os.environ['BLE_STEP_SPLIT'] = mode
+    _lib.set_step_form(mode)
     if noise is None:
       noise = s.wind_noise(seed=11).clone()       # (the same positions in all three: the same noise)
     s.step(acts, noise)
@@ -48,6 +50,6 @@ for t in range(steps):
     for s in sims.values():
       s.check_errors()
     compared += 1
-del os.environ['BLE_STEP_SPLIT']
+_lib.set_step_form(None)
 print(f'soak: {n} environments x {steps} agent steps ({n * steps:.3g} env-steps per kernel form), {compared} full comparisons of every state array: '
       f'one lane == four waves == two waves bit for bit; {ended} episodes ended and were restarted; no error flag')

@@ -10,7 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from balloon_learning_environment_amd import reset_host, vec_state  # noqa: E402
+from balloon_learning_environment_amd import _lib, vec_state  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 
 modes = os.environ.get('SPLIT_AB_MODES', '0,4').split(',')       # BLE_STEP_SPLIT values: 0 one lane, 2 / 4 wavefronts per environment
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384, 32768]
@@ -20,7 +22,7 @@ for n in sizes:
   acts = torch.randint(0, 3, (64, n), dtype=torch.uint8, device='cuda')
   rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
   for split in modes:
-    os.environ['BLE_STEP_SPLIT'] = split
+    _lib.set_step_form(split)
     sim = vec_state.VecSimulator(n); sim.set_grid(field)
     res = {}
     for label, reps in (('fused32', 12), ('single', 200)):
@@ -45,4 +47,4 @@ for n in sizes:
     live = float((sim.state['status'] == 0).float().mean().item())
     print(f'n={n:6d} split={split}: fused {res["fused32"]:.2f} us/step = {n / res["fused32"] * 1e6:.3e} env-steps/s; '
           f'single-step launch {res["single"]:.2f} us; live at end {live:.3f}', flush=True)
-del os.environ['BLE_STEP_SPLIT']
+_lib.set_step_form(None)

@@ -8,7 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from balloon_learning_environment_amd import reset_host, vec_state  # noqa: E402
+from balloon_learning_environment_amd import _lib, vec_state  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -17,7 +19,7 @@ init = reset_host.sample_initial_state(n, seed=1000)
 acts = torch.randint(0, 3, (32, n), dtype=torch.uint8, device='cuda')
 rew = torch.zeros((32, n), device='cuda'); term = torch.zeros((32, n), dtype=torch.uint8, device='cuda')
 for split in ('1', '0'):
-  os.environ['BLE_STEP_SPLIT'] = split
+  _lib.set_step_form(split)
   sim = vec_state.VecSimulator(n); sim.set_grid(field); sim.set_state(init)
   for _ in range(launches):
     sim.step_n(acts, rew, term)

@@ -9,11 +9,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from balloon_learning_environment_amd import device as dev, reset_host, vec_state  # noqa: E402
+from balloon_learning_environment_amd import _lib, device as dev, vec_state  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 k = 32
-os.environ['BLE_STEP_SPLIT'] = '1'
+_lib.set_step_form('1')
 sim = vec_state.VecSimulator(n)
 sim.set_grid((np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).astype(np.float32))
 sim.set_state(reset_host.sample_initial_state(n, seed=1000))

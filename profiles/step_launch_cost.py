@@ -1,8 +1,10 @@
 """Per-launch fixed cost of ble_step_kernel: launches of K = 1 .. 32 agent steps (4 back to back per event pair).
    python profiles/step_launch_cost.py"""
-import sys, statistics, numpy as np, torch
+import os, sys, statistics, numpy as np, torch
 sys.path.insert(0, '.')
-from balloon_learning_environment_amd import vec_state, reset_host
+from balloon_learning_environment_amd import vec_state
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 n = 65536
 sim = vec_state.VecSimulator(n)
 field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5).astype(np.float32)

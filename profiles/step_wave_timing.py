@@ -7,7 +7,9 @@ of its phases.  Prints the launch span (first entry -> last exit), the dispatch 
 import ctypes, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from balloon_learning_environment_amd import vec_state, reset_host, device as dev
+from balloon_learning_environment_amd import vec_state, device as dev
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))      # (the host-side state sampler is test tooling)
+import reset_host  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sim = vec_state.VecSimulator(n)

@@ -115,14 +115,20 @@ extern "C" double emul_asin(double x) { return d_asin(x); }
 
 
 // ---- wind noise (csrc/ble_noise.h) and the decoder tail (csrc/ble_decode.h), host build
+static const float* host_grad_lut() {      // the kernels keep this table in LDS (grad_lut_fill)
+  alignas(16) static float lut[kGradLutFloats];
+  static bool filled = false;
+  if (!filled) { grad_lut_fill(lut, 0, 1); filled = true; }
+  return lut;
+}
 extern "C" void emul_simplex4(int64_t n, const float* x, const float* y, const float* z, const float* w, uint32_t seed,
                               float* out) {
-  for (int64_t i = 0; i < n; ++i) out[i] = simplex4(x[i], y[i], z[i], w[i], seed);
+  for (int64_t i = 0; i < n; ++i) out[i] = simplex4(x[i], y[i], z[i], w[i], seed, host_grad_lut());
 }
 extern "C" void emul_wind_noise(int64_t n, const float* x_m, const float* y_m, const float* pressure,
                                 const int32_t* elapsed_s, uint64_t seed, const uint32_t* episode, float* noise_uv) {
   for (int64_t i = 0; i < n; ++i)
-    wind_noise(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, &noise_uv[2 * i],
+    wind_noise(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, host_grad_lut(), &noise_uv[2 * i],
                &noise_uv[2 * i + 1]);
 }
 // the kernel's cached form: `cache` [kNoiseCacheRows][n] words holds the harmonics' seeds / offsets (fixture F14 writes recorded ones)
@@ -131,7 +137,7 @@ extern "C" void emul_wind_noise_cached(int64_t n, const float* x_m, const float*
                                        float* noise_uv) {
   for (int64_t i = 0; i < n; ++i)
     wind_noise_cached(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, cache, n,
-                      &noise_uv[2 * i], &noise_uv[2 * i + 1]);
+                      host_grad_lut(), &noise_uv[2 * i], &noise_uv[2 * i + 1]);
 }
 extern "C" void emul_decode_flow(int64_t n, const float* flow, float* grid) {
   int tap0[23]; float w1[23];

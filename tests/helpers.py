@@ -83,7 +83,7 @@ def wide_domain_states(n, seed):
   balloons up to 850 km from the station (beyond the wind grid), up to 110 h into the episode (the boomeranged part of the
   forecast, later table segments of everything time-based), any temperatures / infrared / battery, safety layers in any
   state.  The envelope is consistent: a superpressure drawn in 20 .. 2 300 Pa fixes volume and air content."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   rng = np.random.default_rng(seed)
   init = reset_host.sample_initial_state(n, seed=seed)
   init['pressure'][:] = np.exp(rng.uniform(np.log(1200.0), np.log(40000.0), n))

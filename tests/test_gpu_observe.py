@@ -197,7 +197,7 @@ def test_observe_edge_cases_match_oracle(vec_state):
   outside the 5-14 kPa feature range (clamped level, saturated feature 0), paused navigation,
   each last command, night / day, full and empty battery."""
   import features_oracle
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n = 12
   base = reset_host.sample_initial_state(n, seed=9)
   st = {k: np.array(v, copy=True) for k, v in base.items()}
@@ -541,7 +541,7 @@ def test_observe_high_latitude_stations_match_oracle(vec_state, lat_lo, lat_hi, 
   flown 12 steps; every observation against the oracle (which follows the reference's decisions whatever they find).
   `far`: also hundreds of kilometres off the wind grid, outside the feature's pressure band, days into the episode."""
   import features_oracle
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n, steps = 32, 12
   rng = np.random.default_rng(5)
   field = (rng.standard_normal((21, 21, 10, 9, 2)) * 6.0).astype(np.float32)

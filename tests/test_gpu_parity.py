@@ -13,6 +13,8 @@ import os
 import numpy as np
 import pytest
 
+from balloon_learning_environment_amd import _lib      # (set_step_form)
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip('torch')
@@ -403,7 +405,7 @@ def test_invalid_arguments_return_codes(ble):
   # ABI 2: the carried WindGP slab is 7 620 doubles per environment; a caller that still allocates version 1's 7 260 is
   # refused instead of being overrun
   from balloon_learning_environment_amd import _abi
-  assert lib.ble_abi_version() == 3
+  assert lib.ble_abi_version() == 4
   gp = dict(xyp=torch.zeros(4, 128, 3).cuda(), elapsed_s=torch.zeros(4, 128, dtype=torch.int32).cuda(), err_uv=torch.zeros(4, 128, 2).cuda(),
             count=torch.zeros(4, dtype=torch.int32).cuda(), chol=torch.zeros(4, 7620, dtype=torch.float64).cuda(),
             n_chol=torch.zeros(4, dtype=torch.int32).cuda())
@@ -436,7 +438,7 @@ def _sampled_batch_parity(ble, n, steps, seed, threads, init=None):
   tests/test_reference_conditioning.py), which is why the whole vertical chain including the
   thermal and ACS increments is fp64 in the kernel and the solar thresholds are re-decided in fp64.
   """
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   wide = init is not None
   init = init if wide else reset_host.sample_initial_state(n, seed=seed)
   sim = ble.VecSimulator(n)
@@ -484,7 +486,7 @@ def test_long_rollout_checkpoints_match_oracle(ble):
   axis boomerangs, through two sunsets and every safety-layer state), with auto-reset of
   terminated environments; every 125th step is checked against the oracle from the GPU's own
   pre-step state."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n = 2048
   sim = ble.VecSimulator(n)
   sim.set_state(reset_host.sample_initial_state(n, seed=77))
@@ -530,7 +532,7 @@ def test_other_step_lengths_every_env(ble, substeps):
   """Balloon.simulate_step takes any time_delta that is a multiple of the stride (balloon.py:316-319); the agent step is 18
   strides.  1, 7, 36 and BLE_MAX_SUBSTEPS = 60 strides per step (10 s .. 10 min) on 4 096 sampled environments, four steps each:
   every environment within 1e-5 of the oracle stepping with the same stride count; 61 is refused."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n = 4096
   field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
   sim = ble.VecSimulator(n); sim.set_state(reset_host.sample_initial_state(n, seed=substeps)); sim.set_grid(field)
@@ -556,6 +558,52 @@ def test_other_step_lengths_every_env(ble, substeps):
     sim.step(_dev(act, np.uint8), substeps=61)
 
 
+def test_solar_threshold_crossings_at_60_strides_every_env(ble):
+  """the band inside which a stride's solar decisions are re-made on the reference's fp64 chain must follow the step
+  length (the quadratic interpolation's error grows with its cube: csrc/ble_physics.h, sun_band).  32 768 environments at
+  BLE_MAX_SUBSTEPS = 60 strides (10 minutes = 2.5 deg of hour angle per step): half of them start 0 .. 600 s before their own
+  sunset / sunrise (the -4.242 deg day / night threshold is crossed inside the step), the other half anywhere in the day (the
+  two panel-shadow elevations and the 5 deg refraction branch are crossed by ~3 % of them per step).  Every environment's
+  charging, battery, load and temperatures within 1e-5 of the oracle; a decision taken one stride early would move the battery by
+  1.3 Wh (4e-4) and the internal temperature by 0.07 K (3e-4)."""
+  import reset_host
+  n, substeps = 32768, 60
+  field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  init = reset_host.sample_initial_state(n, seed=606)
+  rng = np.random.default_rng(606)
+  half = n // 2
+  edge = np.where(rng.random(half) < 0.5, init['sunset_rel'][:half], init['sunrise_h_rel'][:half] - 1800)
+  elapsed = np.empty(n, np.int64)
+  elapsed[:half] = np.maximum(edge - rng.integers(0, 600, half), 0)
+  elapsed[half:] = rng.integers(0, 86400, n - half)
+  init['time_elapsed_s'] = elapsed.astype(init['time_elapsed_s'].dtype)
+  sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(field)
+  for s in range(2):
+    before = sim.get_state()
+    live = before['status'] == 0
+    o2 = oracle_state_from_abi(before)
+    act = rng.integers(0, 3, n).astype(np.uint8)
+    reward, terminal = sim.step(_dev(act, np.uint8), substeps=substeps)
+    torch.cuda.synchronize(); sim.check_errors()
+    ro, to, eo, err = oracle.step(o2, act, field=field, threads=16, substeps=substeps)
+    got = sim.get_state()
+    for k in ('status', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+      np.testing.assert_array_equal(got[k][live], o2[k][live], err_msg=f'step {s}: {k}')
+    # What a solar decision moves -- charging, battery, load, the two temperatures -- and the position: every environment at 1e-5.
+    # The vertical chain (pressure, superpressure, volume, air, ACS) is the reference's ill-conditioned part
+    # (tests/test_reference_conditioning.py: the oracle's own output moves beyond 1e-5 under a 1-ulp change of its float32 inputs, and
+    # 60 strides amplify over 3.3 x the reference's step): held to 1e-5 on all but a counted handful, none of them grossly off.
+    solar_fields = ('solar_charging', 'battery_charge', 'power_load', 'internal_temperature', 'ambient_temperature', 'x', 'y')
+    for k in STATE_FLOATS:
+      e = rel_err(got[k], o2[k], FLOORS[k])[live]
+      if k in solar_fields:
+        assert e.max() <= RTOL, f'60 strides, step {s}: {k} {e.max():.3g} at env {int(np.flatnonzero(live)[e.argmax()])}'
+      else:
+        assert (e > RTOL).mean() <= 2e-3 and e.max() <= 5e-3, f'60 strides, step {s}: {k} {(e > RTOL).sum()} beyond 1e-5, worst {e.max():.3g}'
+    np.testing.assert_array_equal(terminal.cpu().numpy(), to)
+    np.testing.assert_allclose(reward.cpu().numpy()[live], ro[live], rtol=0, atol=1e-5)
+
+
 def test_wide_domain_states_every_env(ble):
   """16 385 environments drawn far outside the flight envelope (helpers.wide_domain_states): from 1 200 Pa (above the
   atmosphere window's 21 km) to 40 000 Pa, 85 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers
@@ -573,16 +621,16 @@ def test_one_lane_kernel_episodes_ending_inside_a_step_match_oracle(ble):
   rare path and takes it back after the loop (csrc/ble_step_core.h, agent_step).  Forced here (BLE_STEP_SPLIT=0: the host would pick the
   four-wave kernel at this size) on a batch in which a good part of the environments run out of power or burst inside the rollout, every
   environment against the oracle from the kernel's own pre-step state: status, strides run (time_elapsed_s), state, reward, terminal."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n = 4096
   init = reset_host.sample_initial_state(n, seed=4242)
   init['battery_charge'][: n // 4] = np.linspace(0.05, 30.0, n // 4).astype(np.float32)          # out of power within a few strides .. steps
   init['superpressure'][n // 4: n // 4 + 256] = np.linspace(2300.0, 2379.0, 256).astype(np.float32)   # close to the burst limit
-  os.environ['BLE_STEP_SPLIT'] = '0'
+  _lib.set_step_form('0')
   try:
     total, outliers, worst = _sampled_batch_parity(ble, n, 6, seed=4243, threads=8, init=init)
   finally:
-    del os.environ['BLE_STEP_SPLIT']
+    _lib.set_step_form(None)
   assert outliers == 0, (outliers, total, worst)
   assert total < 6 * n - 200                       # (episodes did end: the live count of later steps is smaller)
 
@@ -604,7 +652,7 @@ def test_config_65536_envs_full_size(ble):
 def test_full_size_properties_and_determinism(ble):
   """Size-independent properties at 65 536 envs: bitwise determinism, clocks, bounds, exact
   wind displacement, frozen terminal lanes, per-env grids == shared grid."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n = 65536
   init = reset_host.sample_initial_state(n, seed=77)
   field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
@@ -765,7 +813,7 @@ def test_fp64_primitives_on_device(ble):
 def test_fused_rollout_equals_single_steps(ble, wide):
   """ble_step_n_f32 (K steps in one launch, state in registers) == K x ble_step_f32, bit for bit -- from sampled flight
   states and from helpers.wide_domain_states (half of which end inside the rollout)."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   from helpers import wide_domain_states
   n, k = 4096, 7
   init = wide_domain_states(n, 5) if wide else reset_host.sample_initial_state(n, seed=5)
@@ -816,7 +864,8 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
   environment (the ten harmonics evaluated on different waves, summed in the reference's order)."""
   import ctypes
   import os
-  from balloon_learning_environment_amd import _abi, _lib, device as dev, reset_host
+  from balloon_learning_environment_amd import _abi, _lib, device as dev
+  import reset_host
   n, k, seed = 4096, 6, 20240917
   init = reset_host.sample_initial_state(n, seed=15)
   init['battery_charge'][:48] = 0.2                 # a few environments end inside the rollout
@@ -828,7 +877,7 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
     s = ble.VecSimulator(n); s.set_state(init); s.set_grid(field); s.episode.copy_(episodes); sims.append(s)
   a, b, c = sims
   rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
-  os.environ['BLE_STEP_SPLIT'] = waves
+  _lib.set_step_form(waves)
   try:
     if with_cache:
       a.step_n(acts, rew, term, noise_seed=seed)
@@ -837,7 +886,7 @@ def test_fused_rollout_in_ground_truth_wind_equals_noise_plus_single_steps(ble, 
       _lib.check(a.lib.ble_step_n_f32(ctypes.byref(a._struct), acts.data_ptr(), a.grid.data_ptr(), 0, ctypes.byref(gen), rew.data_ptr(),
                                       term.data_ptr(), a.err_flags.data_ptr(), None, n, 18, k, dev.stream_ptr(a.device)), 'ble_step_n_f32')
   finally:
-    del os.environ['BLE_STEP_SPLIT']
+    _lib.set_step_form(None)
   rb, tb = [], []
   for j in range(k):
     noise = b.wind_noise(seed)
@@ -867,7 +916,7 @@ def test_split_kernel_equals_one_lane_kernel(ble, wide, waves):
   and single steps with a noise term, action bytes outside 0 .. 2, environments that end inside the rollout (early in a
   step, so that their lane stops while its neighbours go on), a batch that does not fill its last workgroup."""
   import os
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   from helpers import wide_domain_states
   n, k = 4096 - 37, 9
   init = wide_domain_states(n, 8) if wide else reset_host.sample_initial_state(n, seed=8)
@@ -881,7 +930,7 @@ def test_split_kernel_equals_one_lane_kernel(ble, wide, waves):
   noise = torch.from_numpy((np.random.default_rng(4).standard_normal((n, 2)) * 1.5).astype(np.float32)).cuda()
 
   def fly(split):
-    os.environ['BLE_STEP_SPLIT'] = waves if split else '0'      # 4 / 2 wavefronts per environment (csrc/ble_step_split.h) against 1
+    _lib.set_step_form(waves if split else '0')      # 4 / 2 wavefronts per environment (csrc/ble_step_split.h) against 1
     try:
       sim = ble.VecSimulator(n); sim.set_state(init); sim.set_grid(field)
       rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
@@ -895,7 +944,7 @@ def test_split_kernel_equals_one_lane_kernel(ble, wide, waves):
       flags = int(sim.err_flags.item()); sim.err_flags.zero_()
       return sim.get_state(), rew.cpu().numpy(), term.cpu().numpy(), cnt.cpu().numpy(), singles, flags, int(sim.active_count.item())
     finally:
-      del os.environ['BLE_STEP_SPLIT']
+      _lib.set_step_form(None)
   a, b = fly(True), fly(False)
   for name in a[0]:
     np.testing.assert_array_equal(a[0][name], b[0][name], err_msg=name)
@@ -912,7 +961,7 @@ def test_split_kernel_equals_one_lane_kernel(ble, wide, waves):
 # ---------------------------------------------------------------- device reset
 def test_device_reset_derivation_matches_oracle(ble):
   """sample=0: cold start + sunrise search on given inputs (golden F10 + sampled) vs the oracle."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   d = golden('f10_reset')
   init = reset_host.sample_initial_state(4096, seed=31)
   cases = [dict(alpha=d['alpha'], x=d['x'], y=d['y'], pressure=d['pressure'], center_lat_deg=d['center_lat_deg'],
@@ -1001,7 +1050,7 @@ def test_device_reset_sampling_distributions_and_autoreset(ble):
 @pytest.mark.parametrize('n', [1, 63, 65, 1000])
 def test_ragged_batch_sizes(ble, n):
   """Batch sizes that do not fill a wavefront (tail lanes masked), incl. the single-env case."""
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   total, outliers, worst = _sampled_batch_parity(ble, n, steps=3, seed=100 + n, threads=2)
   print(f'n={n}: {total} env-steps, worst {worst:.2g}')
   assert outliers == 0 and worst <= RTOL
@@ -1037,7 +1086,7 @@ def test_config4_share_32768_envs_per_env_grids_sampled(ble):
   step by step against the oracle, each on its own grid copied back from HBM and from the GPU's own
   pre-step state (identical inputs)."""
   from balloon_learning_environment_amd import distributed as bdist
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   from balloon_learning_environment_amd.env import generative_wind_field
   lay = bdist.preset_layout(4, 0, 8)
   n = lay['n_local']
@@ -1086,7 +1135,8 @@ def test_episode_cache_is_transparent(ble):
   bit-identical to one that derives them (cache NULL); the reset kernel fills the cache; constants edited by hand
   afterwards are noticed (the entry is keyed by their bit patterns) and never produce a stale result."""
   import ctypes
-  from balloon_learning_environment_amd import device as dev, reset_host
+  from balloon_learning_environment_amd import device as dev
+  import reset_host
   n = 4096
   field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
   acts = torch.from_numpy(np.random.default_rng(5).integers(0, 3, (6, n)).astype(np.uint8)).cuda()
@@ -1132,7 +1182,8 @@ def test_integration_md_binding_runs_as_written(ble):
   """The ctypes binding INTEGRATION.md section 2 shows a reference maintainer (`HipBalloons`), executed as written (only the
   library path is filled in): one step of 1 000 sampled environments through it equals VecSimulator.step bit for bit."""
   import os, re
-  from balloon_learning_environment_amd import _lib, reset_host
+  from balloon_learning_environment_amd import _lib
+  import reset_host
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   text = open(os.path.join(root, 'INTEGRATION.md')).read()
   block = re.search(r'```python\n(# balloon_learning_environment/env/hip_backend\.py.*?)```', text, re.S).group(1)

@@ -45,7 +45,7 @@ def test_gp_history_struct_matches_header_order():
   names = re.findall(r'(?:\*|int64_t)\s*(\w+);', body)       # the pointer members, then the int64 slab stride (ABI 2)
   assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_] and names[-1] == 'chol_stride'
   assert ctypes.sizeof(_abi.BleGpHistoryF32) == 8 * len(names)
-  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 3
+  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 4
   assert int(re.search(r'#define BLE_OBS_DIM (\d+)', header).group(1)) == _lib.OBS_DIM
   assert int(re.search(r'#define BLE_GP_CAPACITY (\d+)', header).group(1)) == _lib.GP_CAPACITY
   assert int(re.search(r'#define BLE_GP_CHOL_STRIDE (\d+)', header).group(1)) == _lib.GP_CHOL_STRIDE
@@ -76,12 +76,13 @@ def test_reference_module_mirrors_have_no_cpu_path_either():
   from balloon_learning_environment_amd.env.balloon import acs, solar, stable_init, standard_atmosphere, thermal    # noqa: F401
   a = standard_atmosphere.Atmosphere(np.array([0, 7], np.uint32))
   assert 0.0 <= a.alpha < 1.0 and standard_atmosphere.Atmosphere(np.array([0, 7], np.uint32)).alpha == a.alpha
-  assert a.at_height(units.Distance(feet=50000.0)).pressure == pytest.approx(1.17e4, rel=0.05)    # (host tables: reset sampling only)
   assert solar.balloon_shadow(45.0, 3.0) == 0.4392 and thermal.absorptivity_ir(210.0) == pytest.approx(0.04587)
   if torch.cuda.is_available():
     pytest.skip('GPU present')
   from balloon_learning_environment_amd.env.balloon import altitude_safety, envelope_safety, power_safety    # noqa: F401
-  for call in (lambda: a.at_pressure(8000.0), lambda: solar.solar_power(30.0, 8000.0), lambda: acs.get_most_efficient_power(1.1),
+  from balloon_learning_environment_amd.env.balloon import power_table
+  for call in (lambda: a.at_pressure(8000.0), lambda: a.at_height(units.Distance(feet=50000.0)), lambda: power_table.lookup(1.1, 0.5),
+               lambda: solar.solar_power(30.0, 8000.0), lambda: acs.get_most_efficient_power(1.1),
                lambda: envelope_safety.EnvelopeSafetyLayer(2380.0).get_action(control.AltitudeControlCommand.DOWN, 100.0),
                lambda: altitude_safety.AltitudeSafetyLayer().get_action(control.AltitudeControlCommand.DOWN, a, 9000.0),
                lambda: thermal.d_balloon_temperature_dt(1804.0, 68.5, 210.0, 215.0, 8000.0, 30.0, 1360.0, 250.0)):
@@ -126,12 +127,10 @@ def test_balloon_state_row_roundtrip_and_properties():
   back = balloon.row_from_state(s, 0.5)
   for k, v in row.items():
     assert back[k] == pytest.approx(v), k
-  # latlng follows the oracle's spherical offset
-  lat, lng = oracle.latlng_from_offset(np.radians(2.5), np.radians(-70.0), 1234.5, -777.0)
-  assert s.latlng.lat_deg == pytest.approx(np.degrees(lat[0]), abs=1e-12)
-  assert s.latlng.lng_deg == pytest.approx(np.degrees(lng[0]), abs=1e-12)
+  # (BalloonState.latlng is a device probe since round 5: its comparison with the oracle's spherical offset is a -m gpu test)
 
 
+@pytest.mark.gpu          # (BalloonState.excess_energy reads the sun through the device probe since round 5)
 @pytest.mark.parametrize('x,y,batt,acs_w,cmd,t', [
     (1000.0, -1000.0, 2900.0, 0.0, 1, '2013-03-25T12:00:00'),
     (60000.0, 20000.0, 2900.0, 0.0, 1, '2013-03-25T12:00:00'),
@@ -161,3 +160,17 @@ def test_gym_registration_module_without_gym():
       mod.register_env()
   else:
     mod.register_env(); mod.register_env()      # idempotent
+
+
+def test_package_holds_one_implementation():
+  """no NumPy / SciPy twin of the device paths inside the product package (the host sampler, WindGP,
+  feature constructor and pressure-range search of rounds 1-4 live next to the tests now)."""
+  pkg = os.path.join(ROOT, 'balloon_learning_environment_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith('.py'):
+        src = open(os.path.join(dirpath, f)).read()
+        assert 'scipy' not in src and 'np.linalg' not in src and 'numpy.linalg' not in src, f
+        assert 'reset_host' not in src.replace('tests/reset_host.py', '') and 'wind_gp' not in src, f
+  for gone in ('reset_host.py', 'env/wind_gp.py', 'env/balloon/pressure_range_builder.py'):
+    assert not os.path.exists(os.path.join(pkg, gone)), gone

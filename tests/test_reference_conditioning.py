@@ -34,7 +34,7 @@ def _oracle_state(init):
 
 
 def test_one_ulp_input_perturbation_moves_the_reference_beyond_1e_5():
-  from balloon_learning_environment_amd import reset_host
+  import reset_host
   n, steps = 65536, 3                        # the sample of tests/test_gpu_parity.py::test_config_65536_envs_full_size
   threads = min(16, os.cpu_count() or 1)
   field = (np.random.default_rng(0).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)

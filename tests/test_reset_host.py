@@ -4,7 +4,7 @@ import time
 import numpy as np
 
 import oracle
-from balloon_learning_environment_amd import reset_host as rh
+import reset_host as rh
 from helpers import golden, known_answers, unix
 
 

@@ -5,7 +5,7 @@ Host NumPy restatement of what the reference gets from scikit-learn's
 GaussianProcessRegressor(kernel=3.6^2 * Matern(ls, nu=0.5), alpha=0.05, optimizer=None):
   K = s^2 exp(-||(x - x') / ls||) + alpha I,  L = chol(K),  a = K^-1 y,
   mean* = K* a,  var* = s^2 - sum((L^-1 K*^T)^2),  deviation = var* / s^2.
-Host-side, single-environment form (used with forecast objects that exist on the host only); the batched device GP --
+TEST TOOLING: the host-side, single-environment form (carrier of the reference's wind_gp_test.py); the product's GP --
 N environments, fp64, factor carried in HBM and slid from step to step -- is `ble_observe_f32` (csrc/ble_observe.h).
 """
 import datetime as dt
