@@ -55,4 +55,5 @@ class BleGpHistoryF32(ctypes.Structure):
 
 class BleNoiseGen(ctypes.Structure):
   """struct ble_noise_gen: the wind-noise generator of a fused rollout (ble_step_n_f32, ABI 3)."""
-  _fields_ = [('seed', ctypes.c_uint64), ('episode', ctypes.c_void_p), ('harmonic_cache', ctypes.c_void_p)]
+  _fields_ = [('seed', ctypes.c_uint64), ('episode', ctypes.c_void_p), ('harmonic_cache', ctypes.c_void_p),
+              ('env_offset', ctypes.c_int64)]       # (ABI 4: the shard's first environment in the global batch; default 0)

@@ -30,7 +30,7 @@ OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
 NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
+EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
            'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
            'ble_probe_f64_prims')
@@ -88,9 +88,11 @@ def lib():
   l.ble_step_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]
   l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, ctypes.POINTER(_abi.BleNoiseGen), _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
   l.ble_reset_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
+  l.ble_reset_at_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _i64, _vp]
   l.ble_observe_f32.argtypes = [st, _vp, _i64, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
   l.ble_decode_flow_fields_f32.argtypes = [_vp, _vp, _i64, _vp]
   l.ble_wind_noise_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _vp, _i64, _vp]
+  l.ble_wind_noise_at_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _vp, _i64, _i64, _vp]
   l.ble_forecast_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_forecast_column_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
     }
   }
   if (kNoise && in_range)
-    noise_draws_fetch(gen.seed, (uint64_t)i, gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n, noise_draws + threadIdx.x, kStepBlock);
+    noise_draws_fetch(gen.seed, (uint64_t)i, (uint64_t)(i + gen.env_offset), gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n,
+                      noise_draws + threadIdx.x, kStepBlock);
   const StrideK K = stride_k_vreg();      // the stride loop's fp64 constants as register pairs, once per launch (see d_vreg)
   BLE_STEP_MARK(3);
 #pragma unroll 1
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
                                                              const float* __restrict__ pressure,
                                                              const int32_t* __restrict__ elapsed, unsigned long long seed,
                                                              const uint32_t* __restrict__ episode, int mode,
-                                                             uint32_t* harmonic_cache, float* __restrict__ noise_uv, int64_t n) {
+                                                             uint32_t* harmonic_cache, float* __restrict__ noise_uv, int64_t n,
+                                                             int64_t env_offset) {
   __shared__ __attribute__((aligned(16))) float grad_lut[kGradLutFloats];
   grad_lut_fill(grad_lut, (int)threadIdx.x, 256);
   __syncthreads();
@@ -480,9 +482,9 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
   if (mode == 0) {
     const uint32_t ep = episode ? episode[i] : 0u;
     if (harmonic_cache != nullptr)
-      wind_noise_cached(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, harmonic_cache, n, grad_lut, &u, &v);
+      wind_noise_cached(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, (uint64_t)(i + env_offset), ep, harmonic_cache, n, grad_lut, &u, &v);
     else
-      wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)i, ep, grad_lut, &u, &v);
+      wind_noise(x[i], y[i], pressure[i], elapsed[i], seed, (uint64_t)(i + env_offset), ep, grad_lut, &u, &v);
   } else {
     u = simplex4(x[i], y[i], pressure[i], (float)elapsed[i] * (1.0f / 3600.0f), (uint32_t)seed, grad_lut);
     v = 0.0f;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
 // sunset search of PowerSafetyLayer.__init__ and fresh clocks / FSMs / battery (balloon.py:175-215).
 __global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, const uint8_t* __restrict__ mask,
                                                            unsigned long long seed, uint32_t* episode, int sample,
-                                                           uint32_t* err_flags, int64_t n) {
+                                                           uint32_t* err_flags, int64_t n, int64_t env_offset) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   uint32_t flags = 0;
   if (i < n && (mask == nullptr || mask[i] != 0)) {
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, con
     if (sample) {
       const uint32_t ep = episode ? episode[i] : 0u;
       if (episode) episode[i] = ep + 1u;
-      Philox g = philox_init(seed, (uint64_t)i, ep);
+      Philox g = philox_init(seed, (uint64_t)(i + env_offset), ep);        // keyed by the GLOBAL environment index
       alpha = (float)philox_uniform(g);                                                  // standard_atmosphere.py:82
       start = 1293840000LL + (int64_t)(philox_uniform(g) * (double)(1419984000LL - 1293840000LL));   // sampling.py:65-83
       const double ga = philox_gamma(g, 1.2), gb = philox_gamma(g, 2.0);                // Beta(1.2, 2.0)
@@ -644,7 +646,7 @@ inline int launch_split(const ble_state_f32* st, const uint8_t* action, const fl
   a.st = *st; a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
   a.reward = reward; a.terminal = terminal; a.effective_action = effective_action; a.err_flags = err_flags;
   a.active_count = active_count; a.n = n; a.substeps = substeps; a.n_steps = n_steps;
-  a.gen = noise ? StepNoise{noise->seed, noise->episode, noise->harmonic_cache} : StepNoise{0ull, nullptr, nullptr};
+  a.gen = noise ? StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset} : StepNoise{0ull, nullptr, nullptr, 0ll};
   const dim3 grid(blocks(n, kSplitLanes));
   const bool pair = split_waves(n) == 2;
   if (noise != nullptr) {
@@ -698,7 +700,7 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
   const int lanes = env_lanes();
   BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
-                     active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr});
+                     active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr, 0ll});
   return launch_status();
 }
 
@@ -717,11 +719,11 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
   if (noise != nullptr) {
     BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
-               active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache});
+               active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset});
   } else {
     BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
-               active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr});
+               active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr, 0ll});
   }
   return launch_status();
 }
@@ -773,14 +775,20 @@ int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, v
   return launch_status();
 }
 
+int ble_wind_noise_at_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
+                          unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
+                          float* noise_uv, int64_t env_offset, int64_t n, void* stream) {
+  if (!x_m || !y_m || !pressure || !elapsed_s || !noise_uv || n < 0 || env_offset < 0 || mode < 0 || mode > 1) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(ble_wind_noise_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x_m, y_m, pressure,
+             elapsed_s, seed, episode, mode, harmonic_cache, noise_uv, n, env_offset);
+  return launch_status();
+}
+
 int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
                        unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
                        float* noise_uv, int64_t n, void* stream) {
-  if (!x_m || !y_m || !pressure || !elapsed_s || !noise_uv || n < 0 || mode < 0 || mode > 1) return BLE_E_INVALID_ARG;
-  if (n == 0) return BLE_OK;
-  BLE_LAUNCH(ble_wind_noise_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x_m, y_m, pressure,
-             elapsed_s, seed, episode, mode, harmonic_cache, noise_uv, n);
-  return launch_status();
+  return ble_wind_noise_at_f32(x_m, y_m, pressure, elapsed_s, seed, episode, mode, harmonic_cache, noise_uv, 0, n, stream);
 }
 
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts, uint32_t* err_flags,
@@ -849,13 +857,18 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
   return launch_status();
 }
 
-int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,
-                  int sample, uint32_t* err_flags, int64_t n, void* stream) {
-  if (!state_ok(st) || n < 0) return BLE_E_INVALID_ARG;
+int ble_reset_at_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,
+                     int sample, uint32_t* err_flags, int64_t env_offset, int64_t n, void* stream) {
+  if (!state_ok(st) || n < 0 || env_offset < 0) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(ble_reset_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, mask, seed,
-                     episode, sample, err_flags, n);
+                     episode, sample, err_flags, n, env_offset);
   return launch_status();
+}
+
+int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,
+                  int sample, uint32_t* err_flags, int64_t n, void* stream) {
+  return ble_reset_at_f32(st, mask, seed, episode, sample, err_flags, 0, n, stream);
 }
 
 int ble_probe_f64_prims(const double* x, double* y, int op, int64_t n, void* stream) {

@@ -229,7 +229,10 @@ BLE_FN void wind_noise_from_values(const float* nz, int64_t stride, float* u, fl
 // The draws of one environment into `dst` (50 words, `dst_stride` apart): from the HBM cache when it holds this (seed, episode)'s
 // -- redrawn and stored there otherwise -- or straight from the Philox stream when there is no cache.
 constexpr int kNoiseCacheRows = 53;
-BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint32_t episode, uint32_t* cache, int64_t n, uint32_t* dst, int64_t dst_stride) {
+// `env`: the environment's row in this call's arrays (and in `cache`); `env_key` = env + the shard's offset: the index the Philox
+// stream is keyed by, so that a sharded batch draws what the unsharded one does
+BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint64_t env_key, uint32_t episode, uint32_t* cache, int64_t n, uint32_t* dst,
+                              int64_t dst_stride) {
   if (cache != nullptr) {
     uint32_t* mine = cache + env;
     const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
@@ -239,7 +242,7 @@ BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint32_t episode, uin
       return;
     }
   }
-  Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
+  Philox g = philox_init(seed ^ 0x5EEDF00Dull, env_key, episode);
 #pragma unroll 1
   for (int k = 0; k < 10; ++k) {
     const HarmonicDraw d = harmonic_draw(g);
@@ -257,19 +260,19 @@ BLE_FN void noise_draws_fetch(uint64_t seed, uint64_t env, uint32_t episode, uin
 }
 
 // the generator of a fused rollout (struct ble_noise_gen of the ABI)
-struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* harmonic_cache; };
+struct StepNoise { unsigned long long seed; const uint32_t* episode; uint32_t* harmonic_cache; long long env_offset; };
 
 // The same with the draws kept in HBM between calls, as the reference keeps them in its NoisyWindHarmonic objects between
 // resets: `cache` is [kNoiseCacheRows][n] 32-bit words (coalesced), rows 5 k .. 5 k + 4 = (seed, ox, oy, op, ot) of harmonic k
 // = 5 comp + h, rows 50 .. 52 the key (episode + 1, seed lo, seed hi) the entry was drawn for; an entry drawn for another
 // (seed, episode) -- or an all-zero, fresh one -- is redrawn and stored.  Same values as wind_noise(), bit for bit.
-BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint32_t episode,
-                              uint32_t* cache, int64_t n, const float* lut, float* u, float* v) {
+BLE_FN void wind_noise_cached(float x_m, float y_m, float pressure, int32_t elapsed_s, uint64_t seed, uint64_t env, uint64_t env_key,
+                              uint32_t episode, uint32_t* cache, int64_t n, const float* lut, float* u, float* v) {
   BLE_NO_CONTRACT
   uint32_t* mine = cache + env;
   const uint32_t k0 = episode + 1u, k1 = (uint32_t)seed, k2 = (uint32_t)(seed >> 32);
   if (!(mine[50 * n] == k0 && mine[51 * n] == k1 && mine[52 * n] == k2)) {
-    Philox g = philox_init(seed ^ 0x5EEDF00Dull, env, episode);
+    Philox g = philox_init(seed ^ 0x5EEDF00Dull, env_key, episode);
 #pragma unroll 1
     for (int k = 0; k < 10; ++k) {
       const HarmonicDraw d = harmonic_draw(g);

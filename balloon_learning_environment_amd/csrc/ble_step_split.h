@@ -152,7 +152,8 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
   if constexpr (kNoise) {            // the harmonics' seeds and offsets of the workgroup's environments, once per launch
     grad_lut_fill(shn.grad_lut, (int)threadIdx.x, kWaves * kSplitLanes);
     if (wave == 0 && in_range)
-      noise_draws_fetch(a.gen.seed, (uint64_t)i, a.gen.episode ? a.gen.episode[i] : 0u, a.gen.harmonic_cache, n, &shn.draws[0][lane], kSplitLanes);
+      noise_draws_fetch(a.gen.seed, (uint64_t)i, (uint64_t)(i + a.gen.env_offset), a.gen.episode ? a.gen.episode[i] : 0u, a.gen.harmonic_cache, n,
+                        &shn.draws[0][lane], kSplitLanes);
   }
   __syncthreads();
   const bool was_live = live;

@@ -49,9 +49,11 @@ class VecBalloonArena:
   lane flies in its previous field)."""
 
   def __init__(self, num_envs: int, wind_field_instance: Optional[grid_based_wind_field.GridBasedWindField] = None,
-               seed: Optional[int] = None, device='cuda:0', per_env_fields: bool = False):
+               seed: Optional[int] = None, device='cuda:0', per_env_fields: bool = False, env_offset: int = 0):
+    """env_offset: this arena's environment 0 in the global batch of a sharded job (vec_state.VecSimulator): with one seed for
+    the job the shards reset and fly in the noise exactly as the unsharded batch would."""
     self.num_envs = int(num_envs)
-    self.sim = vec_state.VecSimulator(self.num_envs, device)
+    self.sim = vec_state.VecSimulator(self.num_envs, device, env_offset=env_offset)
     self.device = self.sim.device
     if wind_field_instance is None:
       from balloon_learning_environment_amd.env import generative_wind_field

@@ -50,10 +50,15 @@ _on_own_device = dev.on_own_device
 class VecSimulator:
   """N balloons on one GPU.  State tensors are exposed as attributes of `.state`."""
 
-  def __init__(self, n: int, device='cuda:0'):
+  def __init__(self, n: int, device='cuda:0', env_offset: int = 0):
+    """env_offset: index of this simulator's environment 0 in the GLOBAL batch (a rank of a sharded run passes its shard's
+    start): the device reset and the wind noise key their Philox streams by (seed, env_offset + i, episode), so the shards of
+    a batch draw exactly what the unsharded batch draws -- one seed for the whole job, whatever the sharding."""
     self.device = dev.require_gpu(device)
     self.lib = _lib.lib()
     self.n = int(n)
+    self.env_offset = int(env_offset)
+    assert self.env_offset >= 0
     with torch.cuda.device(self.device):
       self.state: Dict[str, torch.Tensor] = {
           name: torch.zeros(self.n, dtype=dev.torch_dtype(_abi.FIELD_DTYPES[name]), device=self.device)
@@ -106,10 +111,10 @@ class VecSimulator:
     draws (if `sample`), Newton cold start, sunrise/sunset search, fresh clocks and FSMs."""
     if mask is not None:
       assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == self.n
-    code = self.lib.ble_reset_f32(ctypes.byref(self._struct), dev.ptr(mask), int(seed) & (2 ** 64 - 1),
-                                  self.episode.data_ptr(), 1 if sample else 0, self.err_flags.data_ptr(), self.n,
-                                  dev.stream_ptr(self.device))
-    _lib.check(code, 'ble_reset_f32')
+    code = self.lib.ble_reset_at_f32(ctypes.byref(self._struct), dev.ptr(mask), int(seed) & (2 ** 64 - 1),
+                                     self.episode.data_ptr(), 1 if sample else 0, self.err_flags.data_ptr(), self.env_offset, self.n,
+                                     dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_reset_at_f32')
     if self._gp is not None:        # a new episode gets a new feature constructor (balloon_arena.py:171-177)
       if mask is None:
         self._obs_reset.fill_(1)
@@ -167,7 +172,7 @@ class VecSimulator:
     the wind grid(s), the WindGP history (ring, carried factor, pending resets) and the live-environment counter --
     clones, on the simulator's device.  The derived caches (per-episode constants, noise draws) are not part of it: they
     are keyed by what they were derived from and refill themselves."""
-    d = {'n': self.n, 'state': {k: t.clone() for k, t in self.state.items()}, 'episode': self.episode.clone(),
+    d = {'n': self.n, 'env_offset': self.env_offset, 'state': {k: t.clone() for k, t in self.state.items()}, 'episode': self.episode.clone(),
          'active_slots': self.active_slots.clone(), 'err_flags': self.err_flags.clone(),
          'grid': None if self.grid is None else self.grid.clone(), 'grid_env_stride': self.grid_env_stride, 'gp': None}
     if self._gp is not None:
@@ -182,6 +187,7 @@ class VecSimulator:
     has another layout (shared vs per-environment) replaces the grid tensor; launches prepared before must then be
     prepared again."""
     assert int(d['n']) == self.n, f"checkpoint of {d['n']} environments, simulator of {self.n}"
+    self.env_offset = int(d.get('env_offset', self.env_offset))
     for k, t in self.state.items():
       t.copy_(d['state'][k])
     self.episode.copy_(d['episode']); self.active_slots.copy_(d['active_slots']); self.err_flags.copy_(d['err_flags'])
@@ -213,10 +219,11 @@ class VecSimulator:
     if self._noise_cache is None:      # the harmonics' seeds and offsets, drawn once per (seed, episode) like the reference's
       self._noise_cache = torch.zeros(_lib.NOISE_CACHE_ROWS, self.n, dtype=torch.int32, device=self.device)
     s = self.state
-    code = self.lib.ble_wind_noise_f32(s['x'].data_ptr(), s['y'].data_ptr(), s['pressure'].data_ptr(),
-                                       s['time_elapsed_s'].data_ptr(), int(seed) & (2 ** 64 - 1), self.episode.data_ptr(),
-                                       0, self._noise_cache.data_ptr(), out.data_ptr(), self.n, dev.stream_ptr(self.device))
-    _lib.check(code, 'ble_wind_noise_f32')
+    code = self.lib.ble_wind_noise_at_f32(s['x'].data_ptr(), s['y'].data_ptr(), s['pressure'].data_ptr(),
+                                          s['time_elapsed_s'].data_ptr(), int(seed) & (2 ** 64 - 1), self.episode.data_ptr(),
+                                          0, self._noise_cache.data_ptr(), out.data_ptr(), self.env_offset, self.n,
+                                          dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_wind_noise_at_f32')
     return out
 
   def reset_observation_history(self, mask: Optional[torch.Tensor] = None) -> None:
@@ -255,7 +262,7 @@ class VecSimulator:
     if self._noise_cache is None:
       with torch.cuda.device(self.device):
         self._noise_cache = torch.zeros(_lib.NOISE_CACHE_ROWS, self.n, dtype=torch.int32, device=self.device)
-    return _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr())
+    return _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr(), self.env_offset)
 
   @_on_own_device
   def step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,

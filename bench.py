@@ -144,7 +144,7 @@ class Rollout:
   """One preset's workload on this rank: state + grid resident in HBM, `time_reps` runs the timed region."""
 
   def __init__(self, n, device, rank, world, *, per_env_grids=False, shared_field=None, seed_base=1000,
-               steps=192, warmup=32, substeps=18, noise_seed=None):
+               steps=192, warmup=32, substeps=18, noise_seed=None, env_offset=None):
     import numpy as np
     import torch
     from balloon_learning_environment_amd import distributed as bdist
@@ -152,15 +152,17 @@ class Rollout:
     self.torch, self.bdist, self.np = torch, bdist, np
     self.n, self.device, self.rank, self.world = n, device, rank, world
     self.steps, self.warmup, self.substeps = steps, warmup, substeps
-    # None: forecast wind; else WindField.get_ground_truth, noise generated in-kernel.  The generator is keyed by
-    # (seed, LOCAL env index, episode): every rank gets its own seed, or all shards would fly the same noise fields
-    self.noise_seed = None if noise_seed is None else int(noise_seed) + rank
+    # None: forecast wind; else WindField.get_ground_truth, noise generated in-kernel.  ONE seed for the whole job:
+    # reset and noise streams are keyed by (seed, GLOBAL env index, episode) -- this rank's environments are env_offset .. + n of
+    # the global batch (ABI 4; with local indices all shards flew identical fields: ADVICE r4)
+    self.noise_seed = noise_seed
+    self.env_offset = rank * n if env_offset is None else int(env_offset)
     k_total = steps + warmup
-    # synthetic inputs: the product's own episode reset (ble_reset_f32, sample = 1: the reference's initial-condition
-    # distributions from a Philox stream keyed by (seed, env, episode); one seed per rank), resident in HBM.  The legs that
+    # synthetic inputs: the product's own episode reset (ble_reset_at_f32, sample = 1: the reference's initial-condition
+    # distributions from a Philox stream keyed by (seed, global env index, episode)), resident in HBM.  The legs that
     # restart the episodes copy this snapshot back.  (Rounds 1-4 drew them with a NumPy sampler that is test tooling now.)
-    self.sim = vec_state.VecSimulator(n, device)
-    self.sim.reset_device(seed=seed_base + rank)
+    self.sim = vec_state.VecSimulator(n, device, env_offset=self.env_offset)
+    self.sim.reset_device(seed=seed_base)
     self.sim.check_errors()
     self.initial_state = {k: t.clone() for k, t in self.sim.state.items()}
     self.decode_ms = None

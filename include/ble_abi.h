@@ -187,6 +187,9 @@ typedef struct ble_noise_gen {
   unsigned long long seed;
   const uint32_t* episode;  /* optional device uint32[n]: the per-environment episode counters ble_reset_f32 maintains (NULL = 0) */
   uint32_t* harmonic_cache; /* optional, as for ble_wind_noise_f32: [BLE_NOISE_CACHE_ROWS][n] words */
+  int64_t env_offset;       /* ABI 4: index of this call's environment 0 in the GLOBAL batch (0 on one GPU; the shard's first
+                               environment on a rank of a sharded run).  The noise field of environment i is keyed by
+                               (seed, env_offset + i, episode[i]): a sharded batch flies the fields the unsharded one does */
 } ble_noise_gen;
 
 /*
@@ -222,6 +225,11 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
  */
 int ble_reset_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed,
                   uint32_t* episode, int sample, uint32_t* err_flags, int64_t n, void* stream);
+/* The same for a SHARD of a larger batch (ABI 4): environment i of this call is environment env_offset + i of the global
+ * batch and draws from the Philox stream (seed, env_offset + i, episode[i]) -- the union of the shards' resets is the reset
+ * of the unsharded batch, whatever the sharding.  ble_reset_f32 is this with env_offset = 0. */
+int ble_reset_at_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed,
+                     uint32_t* episode, int sample, uint32_t* err_flags, int64_t env_offset, int64_t n, void* stream);
 
 /*
  * GridBasedWindField.get_forecast (grid_based_wind_field.py:70-94,145-187) for n query
@@ -305,6 +313,10 @@ int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, v
 int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
                        unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
                        float* noise_uv, int64_t n, void* stream);
+/* ... for a shard whose environment 0 is environment env_offset of the global batch (ABI 4; see ble_reset_at_f32). */
+int ble_wind_noise_at_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
+                          unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
+                          float* noise_uv, int64_t env_offset, int64_t n, void* stream);
 
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,

@@ -136,7 +136,7 @@ extern "C" void emul_wind_noise_cached(int64_t n, const float* x_m, const float*
                                        const int32_t* elapsed_s, uint64_t seed, const uint32_t* episode, uint32_t* cache,
                                        float* noise_uv) {
   for (int64_t i = 0; i < n; ++i)
-    wind_noise_cached(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, episode ? episode[i] : 0u, cache, n,
+    wind_noise_cached(x_m[i], y_m[i], pressure[i], elapsed_s[i], seed, (uint64_t)i, (uint64_t)i, episode ? episode[i] : 0u, cache, n,
                       host_grad_lut(), &noise_uv[2 * i], &noise_uv[2 * i + 1]);
 }
 extern "C" void emul_decode_flow(int64_t n, const float* flow, float* grid) {

@@ -604,6 +604,48 @@ def test_solar_threshold_crossings_at_60_strides_every_env(ble):
     np.testing.assert_allclose(reward.cpu().numpy()[live], ro[live], rtol=0, atol=1e-5)
 
 
+def test_shards_reset_and_fly_what_the_unsharded_batch_does(ble):
+  """ABI 4 (`ble_reset_at_f32`, `ble_wind_noise_at_f32`, `ble_noise_gen.env_offset`): the Philox streams of the device reset and
+  of the wind noise are keyed by the GLOBAL environment index, so the shards of a batch -- here 1 500 + 2 596 of 4 096, as two
+  simulators with env_offset 0 and 1 500 -- reset to, draw the noise of and fly through exactly the states of the unsharded
+  batch with the same seeds: initial states, a noise evaluation, an 8-step fused rollout in the ground-truth wind (noise
+  generated in-kernel), and a second, masked reset.  Bit for bit on every array."""
+  n, cut, k = 4096, 1500, 8
+  field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(4).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  whole = ble.VecSimulator(n)
+  parts = [(ble.VecSimulator(cut, env_offset=0), slice(0, cut)), (ble.VecSimulator(n - cut, env_offset=cut), slice(cut, n))]
+
+  def same(what):
+    got = whole.get_state()
+    for sim, sl in parts:
+      st = sim.get_state()
+      for name in got:
+        np.testing.assert_array_equal(st[name], got[name][sl], err_msg=f'{what}: {name}, shard at {sim.env_offset}')
+
+  for sim in [whole] + [p for p, _ in parts]:
+    sim.set_grid(field); sim.reset_device(seed=99); sim.check_errors()
+  same('reset')
+  assert len(np.unique(whole.get_state()['x'])) > n - 8                      # (distinct draws: not one stream n times)
+  noise = whole.wind_noise(seed=5).cpu().numpy()
+  for sim, sl in parts:
+    np.testing.assert_array_equal(sim.wind_noise(seed=5).cpu().numpy(), noise[sl])
+  rew = torch.zeros((k, n), dtype=torch.float32).cuda(); term = torch.zeros((k, n), dtype=torch.uint8).cuda()
+  whole.step_n(acts, rew, term, noise_seed=5)
+  for sim, sl in parts:
+    r = torch.zeros((k, sim.n), dtype=torch.float32).cuda(); t = torch.zeros((k, sim.n), dtype=torch.uint8).cuda()
+    sim.step_n(acts[:, sl].contiguous(), r, t, noise_seed=5)
+    np.testing.assert_array_equal(r.cpu().numpy(), rew.cpu().numpy()[:, sl])
+    np.testing.assert_array_equal(t.cpu().numpy(), term.cpu().numpy()[:, sl])
+  same('fused rollout in the ground-truth wind')
+  mask = torch.from_numpy((np.random.default_rng(6).random(n) < 0.3).astype(np.uint8)).cuda()
+  whole.reset_device(seed=99, mask=mask)
+  for sim, sl in parts:
+    sim.reset_device(seed=99, mask=mask[sl].contiguous())
+  same('second, masked reset')
+  np.testing.assert_array_equal(np.concatenate([p.episode.cpu().numpy() for p, _ in parts]), whole.episode.cpu().numpy())
+
+
 def test_wide_domain_states_every_env(ble):
   """16 385 environments drawn far outside the flight envelope (helpers.wide_domain_states): from 1 200 Pa (above the
   atmosphere window's 21 km) to 40 000 Pa, 85 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers
