@@ -153,7 +153,10 @@ BLE_FN Philox philox_init(uint64_t seed, uint64_t env, uint32_t episode) {
 }
 BLE_FN uint32_t philox_u32(Philox& g) {
   if (g.have == 0) philox_refill(g);
-  return g.out[--g.have];
+  // (selects, not g.out[--g.have]: a run-time index into the buffer put the whole generator in scratch memory -- 48 B per lane in
+  // every kernel that draws inside a rolled loop: the noise kernel, the four-wave kernel with the noise generator)
+  const int h = --g.have;
+  return h == 3 ? g.out[3] : (h == 2 ? g.out[2] : (h == 1 ? g.out[1] : g.out[0]));
 }
 BLE_FN double philox_uniform(Philox& g) {   // [0, 1), 53 bits
   const uint64_t hi = philox_u32(g), lo = philox_u32(g);
