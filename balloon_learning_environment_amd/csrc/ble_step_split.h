@@ -53,6 +53,11 @@
 namespace ble {
 
 constexpr int kSplitWaves = 4;
+// Which role evaluates the sun of the NEXT stride (it depends on the stride index alone): 2 = the envelope wave (rounds 4-5),
+// 1 = the thermal wave, 3 = the ACS + power wave.  A/B knob (profiles/r05_raw/split_sun_role_ab.txt).
+#ifndef BLE_SPLIT_SUN_ROLE
+#define BLE_SPLIT_SUN_ROLE 2
+#endif
 constexpr int kSplitLanes = 64;
 
 // LDS of one workgroup (12.6 KB)
@@ -70,7 +75,8 @@ struct SplitShared {
   uint32_t code_batt[2][kSplitLanes];                                        // wave 3: kOutOfPower after the stride, or 0
   // ---- step exchange (written in the per-step part, read after its barriers; rewritten a step later, many barriers on)
   double eot_min[kSplitLanes]; float eph[3][kSplitLanes];                    // wave 1 -> waves 2, 3: the ephemeris fields the hour-angle nodes need
-  double node_f[2][kSplitLanes];                                             // waves 1, 3 -> wave 2: the middle and end nodes of the step
+  double node_f[2][kSplitLanes];                                             // waves 1, 3 -> the sun role: the middle and end nodes of the step
+  double node_f0[kSplitLanes];                                               // wave 2 -> the sun role (when that is another wave): the first node
   float u[kSplitLanes], v[kSplitLanes];                                      // wave 2 -> all: the wind of the step
   float sin_el0[kSplitLanes], panel0[kSplitLanes]; uint32_t day0[kSplitLanes];   // wave 2 -> waves 1, 3: the sun of stride 0
   uint32_t map_alt[kSplitLanes];                                             // wave 0 -> wave 3: the altitude layer's action map
@@ -120,6 +126,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
   // the roles this wave plays: 0 vertical, 1 thermal, 2 sun + envelope, 3 ACS + power (kWaves == 2: {0, 1} and {2, 3})
   constexpr bool r0 = kWaves == 4 ? wave == 0 : wave == 0, r1 = kWaves == 4 ? wave == 1 : wave == 0;
   constexpr bool r2 = kWaves == 4 ? wave == 2 : wave == 1, r3 = kWaves == 4 ? wave == 3 : wave == 1;
+  constexpr bool rs = BLE_SPLIT_SUN_ROLE == 1 ? r1 : (BLE_SPLIT_SUN_ROLE == 3 ? r3 : r2);      // the role that evaluates the strides' sun
   const int lane = (int)threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * kSplitLanes + lane;
   const int64_t n = a.n;
@@ -274,12 +281,13 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
         const SunState sun0 = sun_at_stride(0, sq, c, u, v, x_start, y_start, t_start);
         sun_sin = sun0.sin_el; sun_panel = solar_panel_factor(sun0); sun_day = sun0.day;
         sh.sin_el0[lane] = sun_sin; sh.panel0[lane] = sun_panel; sh.day0[lane] = sun_day ? 1u : 0u;
+        if (!rs) sh.node_f0[lane] = node_f0;
       }
     }
     BLE_SPLIT_T(0);
     __syncthreads();                                   // ---- barrier 2: the nodes, the sun of stride 0, the altitude layer's map
     BLE_SPLIT_T(1);
-    if (r2) sq = solar_node_coefs(node_f0, sh.node_f[0][lane], sh.node_f[1][lane], substeps);
+    if (rs) sq = solar_node_coefs(r2 ? node_f0 : sh.node_f0[lane], sh.node_f[0][lane], sh.node_f[1][lane], substeps);
     if ((r1 || r3) && !r2) { sun_sin = sh.sin_el0[lane]; sun_panel = sh.panel0[lane]; sun_day = sh.day0[lane] != 0u; }
     if (r3) eff = action_apply_any(sh.map_alt[lane], map_pow_env, act);
     if (live) flags |= step_flags;
@@ -314,16 +322,16 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
         t_int_n = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, hc.q_earth, K);
         if (publish) sh.t_int[wr][lane] = t_int_n;
       }
-      if (r2) {
+      if (rs) {
         const SunState sn = sun_at_stride(k + 1, sq, c, u, v, x_start, y_start, t_start);
         sun_sin_n = sn.sin_el; sun_panel_n = solar_panel_factor(sn); sun_day_n = sn.day;
+        if (publish) { sh.sin_el[wr][lane] = sun_sin_n; sh.panel[wr][lane] = sun_panel_n; sh.day[wr][lane] = sun_day_n ? 1u : 0u; }
+      }
+      if (r2) {
         // step 4: superpressure and volume (balloon.py:470-482): burst above 2 380 Pa, zero pressure at <= 0 (the later check overrides)
         superpressure_volume_f64(n_air, t_int, p, rp, &vol_n, &sp_n, K);
         const uint32_t code = sp_n <= 0.0 ? (uint32_t)kZeroPressure : (!(sp_n <= 2380.0) ? (uint32_t)kBurst : 0u);
-        if (publish) {
-          sh.sin_el[wr][lane] = sun_sin_n; sh.panel[wr][lane] = sun_panel_n; sh.day[wr][lane] = sun_day_n ? 1u : 0u;
-          sh.vol[wr][lane] = vol_n; sh.sp[wr][lane] = sp_n; sh.code_sp[wr][lane] = code;
-        }
+        if (publish) { sh.vol[wr][lane] = vol_n; sh.sp[wr][lane] = sp_n; sh.code_sp[wr][lane] = code; }
       }
       if (r3) {
         const float att = solar_attenuation(sun_sin, (float)p, sun_day);
@@ -349,7 +357,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
       if (r1) t_int = t_int_n; else if (r2 || r3) t_int = sh.t_int[rd][lane];
       if (r2) { vol = vol_n; sp = sp_n; } else { if (r0 || r1) vol = sh.vol[rd][lane]; if (r3) sp = sh.sp[rd][lane]; }
       if (r3) { n_air = n_air_n; batt = batt_n; } else if (r0 || r2) n_air = sh.n_air[rd][lane];
-      if (r2) { sun_sin = sun_sin_n; sun_panel = sun_panel_n; sun_day = sun_day_n; }
+      if (rs) { sun_sin = sun_sin_n; sun_panel = sun_panel_n; sun_day = sun_day_n; }
       else if (r1 || r3) { sun_sin = sh.sin_el[rd][lane]; sun_day = sh.day[rd][lane] != 0u; if (r3) sun_panel = sh.panel[rd][lane]; }
       // later checks override earlier ones (balloon.py:479-482, 541-542): burst, zero pressure, out of power
       const uint32_t cb = sh.code_batt[rd][lane], cs = sh.code_sp[rd][lane];
