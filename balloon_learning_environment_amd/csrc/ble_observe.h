@@ -106,6 +106,8 @@ struct alignas(16) ObsShared {
   int lo_idx, hi_idx;                    // first / last reachable level of the 181
   int n_obs;
   int range_ok;
+  int table_done;                        // waves that have finished their share of the elevation table (the rendezvous of phase 0)
+  int pad_i;
   double pad[64];                        // sink of the masked stores of the drop recurrences (a select, not a branch)
   alignas(16) double pb[kGpMax][2];      // phase 1: (p_k, beta_k) of the rank-1 update that drops the oldest observation
   alignas(16) union {
@@ -509,50 +511,23 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     unix_day_fraction(now, &jc, &frac);
     sh.flux_now = solar_flux_f64(jc);
   }
+  // The carried factor, its drop vector, the copy of row 64 and zeta / d land in LDS HERE (round 5: they did after the elevation
+  // table, in front of B2): requested at kernel entry, they have arrived under the roles above, the 60 registers of the prefetch
+  // are free for the table, and -- what this buys -- after B1 the second slide wave has everything it reads and starts sliding
+  // while the other three fill the table.  Unconditional: a refit overwrites what it does not use.
+#pragma unroll
+  for (int i = 0; i < kCholPrefetch; ++i) {
+    const int e2 = tid + kObsBlock * i;
+    if (e2 < chol_pairs) reinterpret_cast<double2*>(sh.L)[e2] = chol_pre[i];
+  }
+  if (tid < kGpMax) { sh.pb[tid][0] = p_pre; sh.loc[tid][0] = zu_pre; sh.loc[tid][1] = zv_pre; }      // (loc's x, y slots: unused with a carried factor)
+  if (tid >= 128 && tid < 192) sh.brow[tid - 128] = brow_pre;
+  if (tid == 0) sh.table_done = 0;
   BLE_ROLE_ENTRY_DONE();
-  __syncthreads();
+  __syncthreads();   // B1
   BLE_SUB(1);        // ephemeris nodes + site ready
   site.sin_lat = sh.site[0]; site.cos_lat = sh.site[1]; site.lng_deg = sh.site[2];
-  {
-    double dd[3][6];
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) dd[f][j] = sh.eph[j][f];
-#pragma unroll
-      for (int lvl = 1; lvl < 6; ++lvl)
-#pragma unroll
-        for (int j = 5; j >= lvl; --j) dd[f][j] -= dd[f][j - 1];          // forward differences, in place
-    }
-    int64_t days0 = now / 86400;
-    int32_t sod_now = (int32_t)(now - days0 * 86400);
-    if (sod_now < 0) sod_now += 86400;
-    for (int k = tid; k < kElevTable; k += kObsBlock) {
-      const double u = (double)k * (1.0 / 144.0);                          // (t_k - t_0) / 25 920 s
-      const double w2 = (u - 1.0) * 0.5, w3 = (u - 2.0) * (1.0 / 3.0), w4 = (u - 3.0) * 0.25, w5 = (u - 4.0) * 0.2;
-      double val[3];
-#pragma unroll
-      for (int f = 0; f < 3; ++f)
-        val[f] = d_fma(u, d_fma(w2, d_fma(w3, d_fma(w4, d_fma(w5, dd[f][5], dd[f][4]), dd[f][3]), dd[f][2]), dd[f][1]), dd[f][0]);
-      int32_t sod = sod_now + 180 * (k - 240);
-      sod = sod < 0 ? sod + 86400 : sod;                                   // |offset| <= 86 400 s
-      sod = sod >= 86400 ? sod - 86400 : sod;
-      el_table[k] = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod * (1.0 / 86400.0), val[0], val[1], val[2]);
-    }
-    if (tid == kObsBlock - 1) {        // elevation one second from now (is_solar_afternoon, solar.py:239-256), same interpolant
-      const double u = (43200.0 + 1.0) * (1.0 / 25920.0);
-      const double w2 = (u - 1.0) * 0.5, w3 = (u - 2.0) * (1.0 / 3.0), w4 = (u - 3.0) * 0.25, w5 = (u - 4.0) * 0.2;
-      double val[3];
-#pragma unroll
-      for (int f = 0; f < 3; ++f)
-        val[f] = d_fma(u, d_fma(w2, d_fma(w3, d_fma(w4, d_fma(w5, dd[f][5], dd[f][4]), dd[f][3]), dd[f][2]), dd[f][1]), dd[f][0]);
-      int32_t sod = sod_now + 1;
-      sod = sod >= 86400 ? sod - 86400 : sod;
-      sh.el_next = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod / 86400.0, val[0], val[1], val[2]);
-    }
-  }
-  BLE_SUB(2);        // elevation table filled
-  BLE_SUB(3);        // search levels / pressure column done
+  // ---- the window's shape (every wave forms the ballots itself), and whether the stored factor can be slid
   unsigned long long b0, b1;
   {
     const int32_t age_a = ta > elapsed ? ta - elapsed : elapsed - ta, age_b = tb > elapsed ? tb - elapsed : elapsed - tb;
@@ -563,10 +538,6 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   valid = wave < 2 && ((b_mine >> lane) & 1ull) != 0;
   const int pos = __popcll(b_mine & ((1ull << lane) - 1ull));
   const int count_w0 = __popcll(b0);
-  BLE_MARK();
-  BLE_STOP(1);
-
-  // ---- phase 0c: compact the window into LDS (chronological)
   int n_obs = count_w0 + __popcll(b1);
   int drop = 0;
   if (n_obs > kGpMax) { drop = n_obs - kGpMax; n_obs = kGpMax; flags |= kFlagGpWindow; }
@@ -587,6 +558,50 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
     incremental = hist.chol != nullptr && drop == 0 && last_invalid < first_valid && n_dropped >= 0 &&
                   n_dropped <= 1 && n_dropped <= n_chol0 && n_chol0 <= kGpMax;
   }
+  // With a factor to slide there is no workgroup barrier between the table and the roles of phase 1 (everything a slide wave
+  // reads landed before B1): every wave fills ITS SHARE of the table, announces it in LDS and goes on to its role; only the
+  // searches (wave 0) and the cold starts (wave 1) wait for the whole table.  The shares are sized by what follows them
+  // (cycles with two workgroups per CU: searches 9.8 k, cold starts 11.0 k, slide rows 0-63 7.7 k, rows 64+ 13.0 k; one pass of
+  // 64 entries 1.9 k): wave 2 four passes, waves 0 and 1 three, wave 3 two (the last one 17 entries + the elevation one second
+  // from now as entry 721).  Refit: the same shares, then B2 as before.
+  const bool early_slide = __builtin_amdgcn_readfirstlane((int)incremental) != 0;      // (workgroup-uniform)
+  const int k_first = wave == 2 ? 0 : (wave == 0 ? 256 : (wave == 1 ? 448 : 640));
+  const int k_end = wave == 2 ? 256 : (wave == 0 ? 448 : (wave == 1 ? 640 : kElevTable + 1));
+  {
+    double dd[3][6];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) dd[f][j] = sh.eph[j][f];
+#pragma unroll
+      for (int lvl = 1; lvl < 6; ++lvl)
+#pragma unroll
+        for (int j = 5; j >= lvl; --j) dd[f][j] -= dd[f][j - 1];          // forward differences, in place
+    }
+    int64_t days0 = now / 86400;
+    int32_t sod_now = (int32_t)(now - days0 * 86400);
+    if (sod_now < 0) sod_now += 86400;
+    for (int k = k_first + lane; k < k_end; k += 64) {
+      const bool in_table = k < kElevTable;                                 // (entry 721: one second from now, is_solar_afternoon, solar.py:239-256)
+      const double u = in_table ? (double)k * (1.0 / 144.0) : (43200.0 + 1.0) * (1.0 / 25920.0);      // (t_k - t_0) / 25 920 s
+      const double w2 = (u - 1.0) * 0.5, w3 = (u - 2.0) * (1.0 / 3.0), w4 = (u - 3.0) * 0.25, w5 = (u - 4.0) * 0.2;
+      double val[3];
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+        val[f] = d_fma(u, d_fma(w2, d_fma(w3, d_fma(w4, d_fma(w5, dd[f][5], dd[f][4]), dd[f][3]), dd[f][2]), dd[f][1]), dd[f][0]);
+      int32_t sod = sod_now + (in_table ? 180 * (k - 240) : 1);
+      sod = sod < 0 ? sod + 86400 : sod;                                   // |offset| <= 86 400 s
+      sod = sod >= 86400 ? sod - 86400 : sod;
+      const double el = solar_elevation_site_f64(site.sin_lat, site.cos_lat, site.lng_deg, (double)sod * (1.0 / 86400.0), val[0], val[1], val[2]);
+      *(in_table ? &el_table[k] : &sh.el_next) = el;
+    }
+  }
+  BLE_SUB(2);        // elevation table filled
+  BLE_SUB(3);        // search levels / pressure column done
+  BLE_MARK();
+  BLE_STOP(1);
+
+  // ---- phase 0c: compact the window into LDS (chronological)
   if (wave < 2 && valid) {
     const int at = pos + (wave == 1 ? count_w0 : 0) - drop;
     if (at >= 0) {
@@ -602,22 +617,24 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32
   }
   const int n_pad = (n_obs + 15) & ~15;          // identity-padded to the 16-row MFMA tile
   const int n_fac = n_pad < kGpMax ? n_pad : kGpMax;   // rows that exist in LDS (120 is a multiple of the 8-column panel)
-  if (incremental) {
-#pragma unroll
-    for (int i = 0; i < kCholPrefetch; ++i) {
-      const int e2 = tid + kObsBlock * i;
-      if (e2 < chol_pairs) reinterpret_cast<double2*>(sh.L)[e2] = chol_pre[i];
-    }
-    if (tid < kGpMax) sh.pb[tid][0] = p_pre;
-    if (tid >= 128 && tid < 192) sh.brow[tid - 128] = brow_pre;
-    if (tid < kGpMax) { sh.loc[tid][0] = zu_pre; sh.loc[tid][1] = zv_pre; }      // (x, y slots: unused with a carried factor)
-  }
   // Rows of the factor the MFMA sweep works on.  Incremental: the window WITHOUT its newest observation
   // (that one becomes a bordering row, folded in after the sweep); refit: the whole window.
   const bool appended = count != count0;
   const bool has_last = incremental && appended;
   const int nr = has_last ? n_obs - 1 : n_obs;
-  __syncthreads();   // B2: the elevation table, the compacted window and the landed factor are in LDS
+  if (early_slide) {
+    // the rendezvous: each wave announces its share of the table (waves 0 and 1 also their part of the compacted window,
+    // which is read after B3 only); the searches (wave 0) and the cold starts (wave 1) wait for the whole table, the slide
+    // waves need none of it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&sh.table_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wave < 2) {
+      while (__hip_atomic_load(&sh.table_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  } else {
+    __syncthreads();   // B2 (refit): the elevation table and the compacted window are in LDS
+  }
   const double el_now = sh.el_table[240], flux_now = sh.flux_now;      // entry 240 is `now`
 
   // ---- phase 1: four roles
