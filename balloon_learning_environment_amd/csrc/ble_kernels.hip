@@ -65,6 +65,15 @@ __device__ __forceinline__ void report_flags(uint32_t flags, uint32_t* err_flags
 // (wind_field.py:125-145) is evaluated IN the kernel at every step's pre-step position -- the same lane function as
 // ble_wind_noise_f32 (wind_noise_cached), hence the same bits as ble_wind_noise_f32 + ble_step_f32 step by step.  A
 // separate instantiation: the noise-free rollout keeps its register allocation.
+// ble_step_kernel<noise>'s LDS as ONE object in this order: the gradient table (read five times per harmonic at a per-lane index) and the
+// arrays the stride loop reads stay within ds_read's 16-bit offset; the 50 KB of harmonic draws, walked by a pointer, come last.  As
+// separate objects the compiler put the draws first and the table at the end of 66 KB: every read of it paid an addition of its base.
+struct StepNoiseShared {
+  __attribute__((aligned(16))) float grad_lut[kGradLutFloats];      // the noise primitive's gradient weights
+  double acs_poly[kAcsPolyDoubles];
+  float term_save[kTermSaveRows * kStepBlock];
+  uint32_t draws[50 * kStepBlock];      // the harmonics' seeds and offsets of the workgroup's environments, fetched once per launch
+};
 template <bool kNoise>
 __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
@@ -77,11 +86,17 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
                                                           int64_t n, int substeps, int lanes, int n_steps, StepNoise gen) {
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
-  __shared__ double acs_poly[kAcsPolyDoubles];
-  // kNoise: the harmonics' seeds and offsets of this wave's environments, fetched once per launch ([50][64] words)
-  __shared__ uint32_t noise_draws[kNoise ? 50 * kStepBlock : 1];
-  __shared__ __attribute__((aligned(16))) float grad_lut[kNoise ? kGradLutFloats : 4];      // the noise primitive's gradient weights
-  __shared__ float term_save[kTermSaveRows * kStepBlock];       // where a lane parks the state its episode ended with (agent_step): one block per wave
+  // acs_poly: the ACS table's piecewise cubics; term_save: where a lane parks the state its episode ended with (agent_step), one block
+  // per wave
+  double* acs_poly; float* term_save; float* grad_lut = nullptr; uint32_t* noise_draws = nullptr;
+  if constexpr (kNoise) {
+    __shared__ StepNoiseShared shm;
+    acs_poly = shm.acs_poly; term_save = shm.term_save; grad_lut = shm.grad_lut; noise_draws = shm.draws;
+  } else {
+    __shared__ double acs_poly_lds[kAcsPolyDoubles];
+    __shared__ float term_save_lds[kTermSaveRows * kStepBlock];
+    acs_poly = acs_poly_lds; term_save = term_save_lds;
+  }
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int64_t i = ((int64_t)blockIdx.x * (kStepBlock / 64) + wave) * lanes + lane;
   const bool in_range = i < n && lane < lanes;

@@ -11,7 +11,8 @@
 // 10 generators x 256 B per environment would not fit LDS at one lane per environment), its
 // empirical variance measured on the device (tests/test_gpu_noise.py).
 //
-// Every function below evaluates with `fp contract(off)`: the generator runs in two kernels -- ble_wind_noise_kernel and,
+// Every function below evaluates with `fp contract(off)` (a fused multiply-add only where f_fma is written): the generator runs in two
+// kernels -- ble_wind_noise_kernel and,
 // inlined, ble_step_kernel<noise> (ABI 3) -- and the two must produce the same bits whatever the surrounding code lets the
 // compiler fuse (tests/test_gpu_parity.py: fused rollout in the ground-truth wind == noise kernel + single steps).
 #pragma once
@@ -59,21 +60,26 @@ constexpr float kNoiseVariance = 1.02f;          // simplex_wind_noise.py:73
 BLE_FN uint32_t float_bits_u32(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); return b; }
 BLE_FN float u32_bits_float(uint32_t b) { float v; __builtin_memcpy(&v, &b, 4); return v; }
 
-BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) {
-  uint32_t h = seed;
-  h = (h ^ (uint32_t)i) * 0x9E3779B1u; h ^= h >> 15;
+// The lattice point's hash, one multiply-xorshift round per coordinate.  The first round is a function of (seed, i) alone and the five
+// corners of a simplex have i or i + 1 there: simplex4 evaluates the two once and picks (lattice_hash_first / lattice_hash_rest).
+BLE_FN uint32_t lattice_hash_first(int i, uint32_t seed) {
+  uint32_t h = (seed ^ (uint32_t)i) * 0x9E3779B1u;
+  return h ^ (h >> 15);
+}
+BLE_FN uint32_t lattice_hash_rest(uint32_t h, int j, int k, int l) {
   h = (h ^ (uint32_t)j) * 0x85EBCA77u; h ^= h >> 13;
   h = (h ^ (uint32_t)k) * 0xC2B2AE3Du; h ^= h >> 16;
   h = (h ^ (uint32_t)l) * 0x27D4EB2Fu; h ^= h >> 15;
   return h;
 }
+BLE_FN uint32_t lattice_hash(int i, int j, int k, int l, uint32_t seed) { return lattice_hash_rest(lattice_hash_first(i, seed), j, k, l); }
 // The 32 gradients -- the midpoints of the edges of the 4-cube: one zero component (g >> 3 says which), the other three +-1
 // (bits 0, 1, 2 of g are the signs of the first, second, third non-zero component in x, y, z, w order) -- as a table of
 // (wx, wy, wz, ww) weights: 512 B that every kernel which evaluates the noise keeps in LDS (grad_lut_fill).  Round 5: the dot
-// product through the table is one 16-byte LDS read + 4 multiplies + 3 adds; picking the three components and their signs with
-// compares, selects and sign-bit arithmetic was 16 vector instructions per corner, 80 per harmonic (of 333).  Same bits: a weight
-// of +-1 is an exact product, the zero weight adds a zero, and the additions keep the order ((x' + y') + z') + w' that
-// (a + b) + c had.
+// product through the table is one 16-byte LDS read + a multiplication and three fused multiply-adds; picking the three components
+// and their signs with compares, selects and sign-bit arithmetic was 16 vector instructions per corner, 80 per harmonic (of 333).
+// A weight of +-1 is an exact product and the zero weight adds a zero: the value is the sum of the three signed components in
+// x, y, z, w order.
 constexpr int kGradLutFloats = 32 * 4;
 BLE_FN void grad_lut_entry(int g, float* w4) {
   const int zero = g >> 3;
@@ -87,15 +93,17 @@ BLE_FN void grad_lut_entry(int g, float* w4) {
 BLE_FN void grad_lut_fill(float* lut, int tid, int n_threads) {      // followed by a barrier of the filling threads
   for (int g = tid; g < 32; g += n_threads) grad_lut_entry(g, lut + 4 * g);
 }
-// One corner: (0.6 - |d|^2)^4 * (gradient . d).  `lut`: the table above, 16-byte aligned.
+// One corner: (0.6 - |d|^2)^4 * (gradient . d).  `lut`: the table above, 16-byte aligned.  The two sums are chains of EXPLICIT fused
+// multiply-adds (4 + 4 instructions; as products and sums they were 8 + 7): written out, so that both kernels that inline this -- and
+// the host build the tests compare with -- round alike.
 BLE_FN float simplex_corner(float x, float y, float z, float w, uint32_t h, const float* lut) {
   BLE_NO_CONTRACT
-  float t = 0.6f - x * x - y * y - z * z - w * w;
+  float t = f_fma(-w, w, f_fma(-z, z, f_fma(-y, y, f_fma(-x, x, 0.6f))));
   // a corner farther than sqrt(0.6) contributes nothing: t clamped to 0 makes its term (+-)0, which leaves the sum's bits alone -- no
   // branch (with 64 environments in a wave some lane always takes the other side)
   t = t < 0.0f ? 0.0f : t;
   const float* gw = static_cast<const float*>(__builtin_assume_aligned(lut + ((h >> 27) << 2), 16));
-  const float dot = ((gw[0] * x + gw[1] * y) + gw[2] * z) + gw[3] * w;
+  const float dot = f_fma(gw[3], w, f_fma(gw[2], z, f_fma(gw[1], y, gw[0] * x)));
   t *= t;
   return t * t * dot;
 }
@@ -113,17 +121,19 @@ BLE_FN float simplex4(float x, float y, float z, float w, uint32_t seed, const f
   if (y0 > z0) ry++; else rz++;
   if (y0 > w0) ry++; else rw++;
   if (z0 > w0) rz++; else rw++;
-  float n = simplex_corner(x0, y0, z0, w0, lattice_hash(i, j, k, l, seed), lut);
+  const uint32_t h_i0 = lattice_hash_first(i, seed), h_i1 = lattice_hash_first(i + 1, seed);
+  float n = simplex_corner(x0, y0, z0, w0, lattice_hash_rest(h_i0, j, k, l), lut);
 #pragma unroll
   for (int c = 1; c <= 3; ++c) {
     const int th = 4 - c;                          // corner c adds 1 to the axes of rank >= 4 - c
-    const int di = rx >= th, dj = ry >= th, dk = rz >= th, dl = rw >= th;
-    const float off = (float)c * G4;
-    n += simplex_corner(x0 - (float)di + off, y0 - (float)dj + off, z0 - (float)dk + off, w0 - (float)dl + off,
-                        lattice_hash(i + di, j + dj, k + dk, l + dl, seed), lut);
+    const bool di = rx >= th, dj = ry >= th, dk = rz >= th, dl = rw >= th;
+    // the corner's offset from the cell's origin is c G4 - d per axis: one of two constants, picked (one select + one addition per axis)
+    const float stay = (float)c * G4, move = (float)c * G4 - 1.0f;
+    n += simplex_corner(x0 + (di ? move : stay), y0 + (dj ? move : stay), z0 + (dk ? move : stay), w0 + (dl ? move : stay),
+                        lattice_hash_rest(di ? h_i1 : h_i0, j + (int)dj, k + (int)dk, l + (int)dl), lut);
   }
-  n += simplex_corner(x0 - 1.0f + 4.0f * G4, y0 - 1.0f + 4.0f * G4, z0 - 1.0f + 4.0f * G4, w0 - 1.0f + 4.0f * G4,
-                      lattice_hash(i + 1, j + 1, k + 1, l + 1, seed), lut);
+  const float last = 4.0f * G4 - 1.0f;
+  n += simplex_corner(x0 + last, y0 + last, z0 + last, w0 + last, lattice_hash_rest(h_i1, j + 1, k + 1, l + 1), lut);
   return 27.0f * n;
 }
 

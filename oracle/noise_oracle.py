@@ -52,7 +52,7 @@ def lattice_hash(i, j, k, l, seed):
 
 
 def _corner(x, y, z, w, h, dt):
-  t = dt(0.6) - x * x - y * y - z * z - w * w
+  t = dt(0.6) - x * x - y * y - z * z - w * w            # (the kernel: four fused multiply-adds in this order)
   g = (h >> np.uint32(27)).astype(np.int64)
   zero = g >> 3
   a = np.where(zero == 0, y, x); b = np.where(zero <= 1, z, y); c = np.where(zero <= 2, w, z)
@@ -79,11 +79,11 @@ def simplex4(x, y, z, w, seed, dtype=np.float64):
   for c in (1, 2, 3):
     th = 4 - c
     di, dj, dk, dl = (r >= th for r in (rx, ry, rz, rw))
-    off = dt(c) * g4
-    n = n + _corner(x0 - di.astype(dtype) + off, y0 - dj.astype(dtype) + off, z0 - dk.astype(dtype) + off,
-                    w0 - dl.astype(dtype) + off, lattice_hash(i + di, j + dj, k + dk, l + dl, seed), dt)
-  one = dt(1.0) - dt(4.0) * g4
-  n = n + _corner(x0 - one, y0 - one, z0 - one, w0 - one, lattice_hash(i + 1, j + 1, k + 1, l + 1, seed), dt)
+    stay = dt(c) * g4; move = dt(c) * g4 - dt(1.0)      # the corner's offset per axis: one of two constants (ble_noise.h)
+    n = n + _corner(x0 + np.where(di, move, stay), y0 + np.where(dj, move, stay), z0 + np.where(dk, move, stay),
+                    w0 + np.where(dl, move, stay), lattice_hash(i + di, j + dj, k + dk, l + dl, seed), dt)
+  last = dt(4.0) * g4 - dt(1.0)
+  n = n + _corner(x0 + last, y0 + last, z0 + last, w0 + last, lattice_hash(i + 1, j + 1, k + 1, l + 1, seed), dt)
   return dt(27.0) * n
 
 
