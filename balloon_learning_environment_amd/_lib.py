@@ -22,7 +22,8 @@ _SOURCES = [os.path.join(_PKG_DIR, 'csrc', f) for f in ('ble_kernels.hip', 'ble_
                                                           'ble_observe.h', 'ble_noise.h', 'ble_decode.h', 'ble_step_split.h')]
 _HEADER = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'ble_abi.h')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+NOISE_PRIMITIVE_VERSION = 2     # BLE_NOISE_PRIMITIVE_VERSION this mirror, oracle/noise_oracle.py and tests/golden/f14 were made with
 BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH, FLAG_DAY_CYCLE = 64, 128, 256
@@ -30,7 +31,7 @@ OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
 NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
+EXPORTS = ('ble_abi_version', 'ble_noise_primitive_version', 'ble_vehicle_default', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
            'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
            'ble_probe_f64_prims')
@@ -84,6 +85,9 @@ def lib():
       raise BleLibraryError(f'{LIB_PATH} does not export {name}')
   if l.ble_abi_version() != ABI_VERSION:
     raise BleLibraryError('ABI version mismatch between libble_hip.so and the Python mirror')
+  if l.ble_noise_primitive_version() != NOISE_PRIMITIVE_VERSION:
+    raise BleLibraryError(f'libble_hip.so evaluates wind-noise primitive version {l.ble_noise_primitive_version()}, this package (its oracle and '
+                          f'fixtures) was made with {NOISE_PRIMITIVE_VERSION}: recorded noise seeds would fly another wind')
   st = ctypes.POINTER(_abi.BleStateF32)
   l.ble_step_f32.argtypes = [st, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]
   l.ble_step_n_f32.argtypes = [st, _vp, _vp, _i64, ctypes.POINTER(_abi.BleNoiseGen), _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]
@@ -106,6 +110,7 @@ def lib():
   l.ble_probe_safety_f32.argtypes = [_int, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_f64_prims.argtypes = [_vp, _vp, _int, _i64, _vp]
   l.ble_set_step_form.argtypes = [_int]
+  l.ble_vehicle_default.argtypes = [ctypes.POINTER(_abi.BleVehicle)]
   for name in EXPORTS:
     getattr(l, name).restype = _int
   _lib = l
@@ -121,7 +126,8 @@ def check(code: int, what: str) -> None:
 class step_form:
   """`with _lib.step_form(waves): ...` forces the transition kernel's form (0 automatic, 1 one lane per environment,
   4 / 2 wavefronts per environment: `ble_set_step_form`) for the launches inside the block and restores the previous
-  setting.  A/B runs and the bit-identity tests; the automatic choice is by batch size (BLE_SPLIT_MAX_ENVS)."""
+  setting.  A/B runs and the bit-identity tests; the automatic choice is by batch size (BLE_SPLIT_MAX_ENVS).  (2 exists in
+  experiment builds only: the product library refuses it since ABI 5.)"""
 
   def __init__(self, waves_per_env: int):
     self.waves = int(waves_per_env)
@@ -129,7 +135,7 @@ class step_form:
   def __enter__(self):
     self.before = lib().ble_set_step_form(self.waves)
     if self.before < 0:
-      raise ValueError(f'step form must be 0, 1, 2 or 4, not {self.waves}')
+      raise ValueError(f'step form must be 0, 1 or 4, not {self.waves}')
     return self
 
   def __exit__(self, *exc):
@@ -139,6 +145,10 @@ class step_form:
 
 def set_step_form(mode) -> int:
   """`ble_set_step_form` with the spelling of the former BLE_STEP_SPLIT switch: None / 'auto' -> automatic, '0' -> one lane per
-  environment, '1' / '4' -> four wavefronts, '2' -> two.  Returns the previous setting."""
+  environment, '1' / '4' -> four wavefronts ('2' -> two: experiment builds only, BLE_E_INVALID_ARG from the product library).  Returns
+  the previous setting; raises ValueError when the library refuses the form."""
   waves = {None: 0, 'auto': 0, '0': 1, '1': 4, '4': 4, '2': 2}[mode if mode is None else str(mode)]
-  return lib().ble_set_step_form(waves)
+  before = lib().ble_set_step_form(waves)
+  if before < 0:
+    raise ValueError(f'this library has no step form {mode!r}')
+  return before

@@ -74,8 +74,10 @@ struct StepNoiseShared {
   float term_save[kTermSaveRows * kStepBlock];
   uint32_t draws[50 * kStepBlock];      // the harmonics' seeds and offsets of the workgroup's environments, fetched once per launch
 };
-template <bool kNoise>
-__global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, const uint8_t* __restrict__ action,
+// V: the flight vehicle's constants -- VehicleDefault (compile-time: ble_state_f32.vehicle == NULL) or VehicleRt (a kernel argument, i.e.
+// scalar registers: ABI 5) -- as the LAST argument, so that the default instantiation's argument layout is what it was.
+template <bool kNoise, class V = VehicleDefault>
+__global__ __launch_bounds__(kStepBlock) void ble_step_kernel(StateDev st, const uint8_t* __restrict__ action,
                                                           const float* __restrict__ wind_grid,
                                                           int64_t grid_env_stride,
                                                           const float* __restrict__ noise_uv,
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
                                                           uint8_t* __restrict__ terminal,
                                                           uint8_t* __restrict__ effective_action,
                                                           uint32_t* err_flags, unsigned long long* active_count,
-                                                          int64_t n, int substeps, int lanes, int n_steps, StepNoise gen) {
+                                                          int64_t n, int substeps, int lanes, int n_steps, StepNoise gen, V veh) {
   // `lanes` (64 or 32) = environments per wavefront.  32 leaves the upper half of the wave
   // idle and doubles the number of waves: an occupancy/latency experiment knob.
   // acs_poly: the ACS table's piecewise cubics; term_save: where a lane parks the state its episode ended with (agent_step), one block
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
   if (kNoise && in_range)
     noise_draws_fetch(gen.seed, (uint64_t)i, (uint64_t)(i + gen.env_offset), gen.episode ? gen.episode[i] : 0u, gen.harmonic_cache, n,
                       noise_draws + threadIdx.x, kStepBlock);
-  const StrideK K = stride_k_vreg();      // the stride loop's fp64 constants as register pairs, once per launch (see d_vreg)
+  const StrideK K = stride_k_vreg(veh.dry_mass, veh.lift, veh.v0);      // the stride loop's fp64 constants as register pairs, once per launch (see d_vreg)
   BLE_STEP_MARK(3);
 #pragma unroll 1
   for (int k = 0; k < n_steps; ++k) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kStepBlock) void ble_step_kernel(ble_state_f32 st, 
         asm volatile("" : "+v"(nu), "+v"(nv));
       } else if (noise_uv) { nu = noise_uv[2 * i]; nv = noise_uv[2 * i + 1]; }
       float r;
-      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, K, term_save + wave * (kTermSaveRows * kTermSaveStride) + lane, &r, &flags);
+      const int eff = agent_step(s, c, hc, act, corners, wq, nu, nv, substeps, acs_poly, K, term_save + wave * (kTermSaveRows * kTermSaveStride) + lane, &r, &flags, veh);
       if (!(isfinite(s.p) && isfinite(s.t_int) && isfinite(s.x) && isfinite(s.y) && isfinite(s.batt)))
         flags |= kFlagNonFinite;
       reward[o] = r;
@@ -215,7 +217,10 @@ __global__ __launch_bounds__(kSplitWaves * kSplitLanes, BLE_SPLIT_WAVES_PER_EU) 
   }
   report_flags(flags, a.err_flags);
 }
-// ... and on two: {vertical, thermal} | {sun + envelope, ACS + power}, 128-thread workgroups (two waves per SIMD at 65 536 environments)
+// ... and on two: {vertical, thermal} | {sun + envelope, ACS + power}, 128-thread workgroups (two waves per SIMD at 65 536 environments).
+// An A/B form that the automatic choice never took and that measured slower at every batch size (profiles/HISTORY.md): since round 6 it is
+// NOT part of the product library -- profiles/build_variant.sh -DBLE_WITH_PAIR_FORM builds it for experiments (ble_set_step_form(2)).
+#ifdef BLE_WITH_PAIR_FORM
 template <bool kNoise>
 __global__ __launch_bounds__(2 * kSplitLanes) void ble_step_pair_kernel(SplitArgs a) {
   __shared__ SplitShared sh;
@@ -225,6 +230,10 @@ __global__ __launch_bounds__(2 * kSplitLanes) void ble_step_pair_kernel(SplitArg
   else flags = split_agent_steps<2, 1, kNoise>(a, sh, shn);
   report_flags(flags, a.err_flags);
 }
+constexpr bool kHavePairForm = true;
+#else
+constexpr bool kHavePairForm = false;
+#endif
 
 __global__ __launch_bounds__(256) void ble_forecast_kernel(const float* __restrict__ wind_grid,
                                                            int64_t grid_env_stride, const float* __restrict__ x,
@@ -512,9 +521,10 @@ __global__ __launch_bounds__(256) void ble_wind_noise_kernel(const float* __rest
 // Philox(seed, env, episode[i]); sample == 0: keep x, y, pressure, centre lat/lng, IR, alpha,
 // start_unix as they are.  Then the Newton cold start (stable_init.py:132-157), the sunrise /
 // sunset search of PowerSafetyLayer.__init__ and fresh clocks / FSMs / battery (balloon.py:175-215).
-__global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, const uint8_t* __restrict__ mask,
+template <class V = VehicleDefault>
+__global__ __launch_bounds__(kBlock) void ble_reset_kernel(StateDev st, const uint8_t* __restrict__ mask,
                                                            unsigned long long seed, uint32_t* episode, int sample,
-                                                           uint32_t* err_flags, int64_t n, int64_t env_offset) {
+                                                           uint32_t* err_flags, int64_t n, int64_t env_offset, V veh) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   uint32_t flags = 0;
   if (i < n && (mask == nullptr || mask[i] != 0)) {
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void ble_reset_kernel(ble_state_f32 st, con
     latlng_f64((double)lat0, (double)lng0, (double)x, (double)y, &site.sin_lat, &site.cos_lat, &site.lng_deg);
     double flux;
     const double el = solar_elevation_f64(site.sin_lat, site.cos_lat, site.lng_deg, start, &flux);
-    const StableParams sp = stable_params((double)alpha, (double)p, el, flux, (double)ir, &flags);
+    const StableParams sp = stable_params((double)alpha, (double)p, el, flux, (double)ir, &flags, veh);
     int64_t sunrise, sunset;
     next_sunrise_sunset(site, start, &sunrise, &sunset);
     st.ambient_temperature[i] = (float)sp.t_amb; st.internal_temperature[i] = (float)sp.t_int;
@@ -600,6 +610,15 @@ __global__ __launch_bounds__(256) void probe_f64_kernel(const double* x, double*
   y[i] = r;
 }
 namespace {
+// what a kernel gets of the caller's ble_state_f32: its device pointers (the struct's prefix)
+static_assert(sizeof(StateDev) == offsetof(ble_state_f32, vehicle) && offsetof(StateDev, episode_cache) == offsetof(ble_state_f32, episode_cache) &&
+              offsetof(StateDev, start_unix) == offsetof(ble_state_f32, start_unix) && offsetof(StateDev, status) == offsetof(ble_state_f32, status),
+              "StateDev is ble_state_f32 without its last member");
+inline StateDev state_dev(const ble_state_f32* st) {
+  StateDev d;
+  __builtin_memcpy(&d, st, sizeof d);
+  return d;
+}
 inline int env_lanes() { return kBlock; }   // one environment per lane, all 64 lanes (32 was measured: slower)
 // Below BLE_SPLIT_MAX_ENVS environments the one-lane kernel leaves most SIMDs idle (n / 64 waves on 1 024 SIMDs) and the
 // four-wave kernel still fits one wave per SIMD: it is the faster one (bit-identical results).  ble_set_step_form() forces a
@@ -613,7 +632,7 @@ inline int step_form_from_environment() {
   if (e != nullptr && e[0] != 0 && e[1] == 0) {
     if (e[0] == '0') return 1;
     if (e[0] == '1' || e[0] == '4') return 4;
-    if (e[0] == '2') return 2;
+    if (kHavePairForm && e[0] == '2') return 2;
   }
   return 0;
 }
@@ -627,15 +646,14 @@ inline int step_form() {
   }
   return f;
 }
-// returns the number of waves per environment: 1 (ble_step_kernel), 2 (ble_step_pair_kernel) or 4 (ble_step_split_kernel)
+// returns the number of waves per environment: 1 (ble_step_kernel) or 4 (ble_step_split_kernel); 2 (ble_step_pair_kernel) in -DBLE_WITH_PAIR_FORM builds only
 inline int split_waves(int64_t n) {
   const int f = step_form();
   return f != 0 ? f : (n <= BLE_SPLIT_MAX_ENVS ? 4 : 1);
 }
-inline bool use_split(int64_t n) { return split_waves(n) != 1; }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                         const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
-                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream,
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream, int waves,
                         const ble_noise_gen* noise = nullptr);
 // hipGetLastError is per-thread and sticky: an error left behind by an unrelated runtime call
 // of the host application (torch probes pointers / peers at start-up) must not be reported as
@@ -655,22 +673,24 @@ inline int launch_status() {
 inline unsigned blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 inline int launch_split(const ble_state_f32* st, const uint8_t* action, const float* wind_grid, int64_t grid_env_stride,
                         const float* noise_uv, float* reward, uint8_t* terminal, uint8_t* effective_action, uint32_t* err_flags,
-                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream,
+                        unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream, int waves,
                         const ble_noise_gen* noise) {
   SplitArgs a;
-  a.st = *st; a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
+  a.st = state_dev(st); a.action = action; a.wind_grid = wind_grid; a.grid_env_stride = grid_env_stride; a.noise_uv = noise_uv;
   a.reward = reward; a.terminal = terminal; a.effective_action = effective_action; a.err_flags = err_flags;
   a.active_count = active_count; a.n = n; a.substeps = substeps; a.n_steps = n_steps;
   a.gen = noise ? StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset} : StepNoise{0ull, nullptr, nullptr, 0ll};
   const dim3 grid(blocks(n, kSplitLanes));
-  const bool pair = split_waves(n) == 2;
-  if (noise != nullptr) {
-    if (pair) BLE_LAUNCH(ble_step_pair_kernel<true>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
-    else BLE_LAUNCH(ble_step_split_kernel<true>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
-  } else {
-    if (pair) BLE_LAUNCH(ble_step_pair_kernel<false>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
-    else BLE_LAUNCH(ble_step_split_kernel<false>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+#ifdef BLE_WITH_PAIR_FORM
+  if (waves == 2) {
+    if (noise != nullptr) BLE_LAUNCH(ble_step_pair_kernel<true>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
+    else BLE_LAUNCH(ble_step_pair_kernel<false>, grid, dim3(2 * kSplitLanes), 0, (hipStream_t)stream, a);
+    return launch_status();
   }
+#endif
+  (void)waves;
+  if (noise != nullptr) BLE_LAUNCH(ble_step_split_kernel<true>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
+  else BLE_LAUNCH(ble_step_split_kernel<false>, grid, dim3(kSplitWaves * kSplitLanes), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 inline bool state_ok(const ble_state_f32* st) {
@@ -681,16 +701,59 @@ inline bool state_ok(const ble_state_f32* st) {
   return true;
 }
 
+// ble_vehicle (the reference's dataclass fields) -> the derived constants the lane functions evaluate, in double on the host: the same
+// expressions VehicleDefault folds at compile time (a vehicle equal to the defaults yields VehicleDefault's numbers bit for bit:
+// tests/test_gpu_vehicle.py flies both instantiations side by side).
+inline bool vehicle_ok(const ble_vehicle* v) {
+  const double fields[] = {v->envelope_volume_base, v->envelope_volume_dv_pressure, v->envelope_mass, v->envelope_max_superpressure, v->envelope_cod,
+                           v->payload_mass, v->nighttime_power_load_w, v->daytime_power_load_w, v->acs_valve_hole_diameter_m, v->battery_capacity_wh,
+                           v->mols_lift_gas};
+  for (double f : fields)
+    if (!(f == f) || f - f != 0.0) return false;                                  // NaN / Inf
+  return v->envelope_volume_base > 0.0 && v->envelope_volume_dv_pressure > 0.0 && v->envelope_mass > 0.0 && v->envelope_cod > 0.0 &&
+         v->envelope_max_superpressure > 300.0 && v->battery_capacity_wh > 0.0 && v->payload_mass >= 0.0 && v->mols_lift_gas >= 0.0 &&
+         v->acs_valve_hole_diameter_m >= 0.0 && v->nighttime_power_load_w >= 0.0 && v->daytime_power_load_w >= 0.0;
+}
+inline VehicleRt make_vehicle_rt(const ble_vehicle* v) {
+  VehicleRt r;
+  r.v0 = v->envelope_volume_base; r.dvdp = v->envelope_volume_dv_pressure;
+  r.four_dvdp = 4.0 * r.dvdp; r.inv_dvdp = 1.0 / r.dvdp;
+  r.inv_cbrt_v0 = 1.0 / cbrt(r.v0);
+  r.lift = v->mols_lift_gas;
+  r.envelope_mass = v->envelope_mass; r.payload_mass = v->payload_mass; r.he_mass = kHeMolarMassD * r.lift;
+  r.dry_mass = r.he_mass + r.envelope_mass + r.payload_mass;                     // balloon.py:417-420 without the air term (kDryMassD's order)
+  r.max_sp = v->envelope_max_superpressure;
+  r.drag_arg = (2.0 * 9.80665 / v->envelope_cod) * (kGasConstantD / kAirMolarMassD);
+  r.thermal_scale = 10.0 * 4.0 * kPiD * 0.38483473658887897 / (1500.0 * r.envelope_mass);
+  const double d = v->acs_valve_hole_diameter_m;
+  r.valve_k = -0.62 * (kPiD * d * d / 4.0);
+  r.night_load_d = v->nighttime_power_load_w; r.capacity_d = v->battery_capacity_wh; r.day_load_d = v->daytime_power_load_w;
+  r.day_load = (float)r.day_load_d; r.night_load = (float)r.night_load_d; r.capacity = (float)r.capacity_d;
+  r.power_layer = v->power_safety_layer_enabled != 0;
+  return r;
+}
+
 }  // namespace
 
 extern "C" {
 
 int ble_abi_version(void) { return BLE_ABI_VERSION; }
 
+int ble_noise_primitive_version(void) { return BLE_NOISE_PRIMITIVE_VERSION; }
+
+int ble_vehicle_default(ble_vehicle* v) {
+  if (v == nullptr) return BLE_E_INVALID_ARG;
+  v->envelope_volume_base = 1804.0; v->envelope_volume_dv_pressure = 0.0199; v->envelope_mass = 68.5; v->envelope_max_superpressure = 2380.0;
+  v->envelope_cod = 0.25; v->payload_mass = 92.5; v->nighttime_power_load_w = 183.7; v->daytime_power_load_w = 120.4;
+  v->acs_valve_hole_diameter_m = 0.04; v->battery_capacity_wh = 3058.56; v->mols_lift_gas = 6830.0; v->power_safety_layer_enabled = 1;
+  v->reserved_ = 0;
+  return BLE_OK;
+}
+
 int ble_last_hip_error(void) { return g_last_hip_error; }
 
 int ble_set_step_form(int waves_per_env) {
-  if (waves_per_env != 0 && waves_per_env != 1 && waves_per_env != 2 && waves_per_env != 4) return BLE_E_INVALID_ARG;
+  if (waves_per_env != 0 && waves_per_env != 1 && waves_per_env != 4 && !(kHavePairForm && waves_per_env == 2)) return BLE_E_INVALID_ARG;
   const int before = step_form();
   g_step_form.store(waves_per_env, std::memory_order_relaxed);
   return before;
@@ -708,14 +771,22 @@ int ble_step_f32(const ble_state_f32* st, const uint8_t* action, const float* wi
   if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || substeps > BLE_MAX_SUBSTEPS ||
       grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
+  if (st->vehicle != nullptr && !vehicle_ok(st->vehicle)) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  if (use_split(n))
-    return launch_split(st, action, wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags, active_count, n,
-                        substeps, 1, stream);
   const int lanes = env_lanes();
-  BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
+  if (st->vehicle != nullptr) {              // a run-time vehicle (ABI 5): the one-lane form's second instantiation, whatever the batch size
+    BLE_LAUNCH((ble_step_kernel<false, VehicleRt>), dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
+               wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
+               active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr, 0ll}, make_vehicle_rt(st->vehicle));
+    return launch_status();
+  }
+  const int waves = split_waves(n);          // (read once per launch: a concurrent ble_set_step_form cannot split the decision)
+  if (waves != 1)
+    return launch_split(st, action, wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags, active_count, n,
+                        substeps, 1, stream, waves);
+  BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
                      wind_grid, grid_env_stride, noise_uv, reward, terminal, effective_action, err_flags,
-                     active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr, 0ll});
+                     active_count, n, substeps, lanes, 1, StepNoise{0ull, nullptr, nullptr, 0ll}, VehicleDefault{});
   return launch_status();
 }
 
@@ -723,22 +794,37 @@ int ble_step_n_f32(const ble_state_f32* st, const uint8_t* action, const float* 
                    const ble_noise_gen* noise, float* reward, uint8_t* terminal, uint32_t* err_flags,
                    unsigned long long* active_count, int64_t n, int substeps, int n_steps, void* stream) {
   if (!state_ok(st) || !action || !wind_grid || !reward || !terminal || n < 0 || substeps < 1 || substeps > BLE_MAX_SUBSTEPS || n_steps < 0 ||
-      grid_env_stride < 0)
+      grid_env_stride < 0 || (noise != nullptr && noise->env_offset < 0))      // (a negative offset would key other streams than the reset did)
     return BLE_E_INVALID_ARG;
+  if (st->vehicle != nullptr && !vehicle_ok(st->vehicle)) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   if (n_steps == 0) return BLE_OK;
   const int lanes = env_lanes();
-  if (use_split(n))          // (with or without the in-kernel noise generator)
+  if (st->vehicle != nullptr) {
+    const VehicleRt veh = make_vehicle_rt(st->vehicle);
+    if (noise != nullptr)
+      BLE_LAUNCH((ble_step_kernel<true, VehicleRt>), dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
+                 wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
+                 active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset}, veh);
+    else
+      BLE_LAUNCH((ble_step_kernel<false, VehicleRt>), dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
+                 wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
+                 active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr, 0ll}, veh);
+    return launch_status();
+  }
+  const int waves = split_waves(n);
+  if (waves != 1)          // (with or without the in-kernel noise generator)
     return launch_split(st, action, wind_grid, grid_env_stride, nullptr, reward, terminal, nullptr, err_flags, active_count, n, substeps,
-                        n_steps, stream, noise);
+                        n_steps, stream, waves, noise);
   if (noise != nullptr) {
-    BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
+    BLE_LAUNCH(ble_step_kernel<true>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
-               active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset});
+               active_count, n, substeps, lanes, n_steps, StepNoise{noise->seed, noise->episode, noise->harmonic_cache, (long long)noise->env_offset},
+               VehicleDefault{});
   } else {
-    BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, *st, action,
+    BLE_LAUNCH(ble_step_kernel<false>, dim3(blocks(n, lanes * (kStepBlock / 64))), dim3(kStepBlock), 0, (hipStream_t)stream, state_dev(st), action,
                wind_grid, grid_env_stride, (const float*)nullptr, reward, terminal, (uint8_t*)nullptr, err_flags,
-               active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr, 0ll});
+               active_count, n, substeps, lanes, n_steps, StepNoise{0ull, nullptr, nullptr, 0ll}, VehicleDefault{});
   }
   return launch_status();
 }
@@ -778,7 +864,7 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
   // a slab shorter than the kernel's layout would be overrun (and overlap the next environment's)
   if (h.chol != nullptr && (h.n_chol == nullptr || h.chol_stride < (int64_t)kCholStride || (h.chol_stride & 1) != 0))
     return BLE_E_INVALID_ARG;
-  BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, *st, wind_grid,
+  BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, state_dev(st), wind_grid,
              grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
   return launch_status();
 }
@@ -875,9 +961,14 @@ int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const flo
 int ble_reset_at_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,
                      int sample, uint32_t* err_flags, int64_t env_offset, int64_t n, void* stream) {
   if (!state_ok(st) || n < 0 || env_offset < 0) return BLE_E_INVALID_ARG;
+  if (st->vehicle != nullptr && !vehicle_ok(st->vehicle)) return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
-  BLE_LAUNCH(ble_reset_kernel, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, mask, seed,
-                     episode, sample, err_flags, n, env_offset);
+  if (st->vehicle != nullptr)
+    BLE_LAUNCH(ble_reset_kernel<VehicleRt>, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, state_dev(st), mask, seed,
+               episode, sample, err_flags, n, env_offset, make_vehicle_rt(st->vehicle));
+  else
+    BLE_LAUNCH(ble_reset_kernel<VehicleDefault>, dim3(blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, state_dev(st), mask, seed,
+               episode, sample, err_flags, n, env_offset, VehicleDefault{});
   return launch_status();
 }
 

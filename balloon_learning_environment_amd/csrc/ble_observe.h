@@ -337,7 +337,7 @@ __device__ inline double safe_pressure_search_wave(double lev_l, double sp_l, in
   return fabs((target - s1) / (s2 - s1)) * (p2 - p1) + p1;
 }
 
-__global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(ble_state_f32 st, const float* __restrict__ wind_grid,
+__global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, const float* __restrict__ wind_grid,
                                                                 int64_t grid_env_stride,
                                                                 const float* __restrict__ noise_uv,
                                                                 const uint8_t* __restrict__ reset_mask, GpHistory hist,

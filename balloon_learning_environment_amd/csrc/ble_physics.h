@@ -58,6 +58,32 @@ constexpr float kDayLoad = 120.4f;
 constexpr float kBatteryCapacity = 3058.56f;
 constexpr float kStride = 10.0f;  // balloon.py:269 inner stride [s]
 
+// BalloonState's flight-vehicle constants (balloon.py:156-173,183,200; include/ble_abi.h::ble_vehicle) in the DERIVED forms the lane
+// functions evaluate.  Two carriers with the same member names: VehicleDefault -- the reference's defaults as compile-time constants, what
+// every kernel flew before ABI 5 and what ble_state_f32.vehicle == NULL still selects: the same literals, the same folded arithmetic, the
+// same bits --, and VehicleRt -- the same quantities derived on the HOST in double (make_vehicle_rt, ble_kernels.hip) and handed to a second
+// instantiation of the kernels as an argument, i.e. in scalar registers.  The lane functions take the quantities as trailing parameters
+// whose defaults are VehicleDefault's.
+struct VehicleDefault {
+  static constexpr double v0 = 1804.0, dvdp = 0.0199, four_dvdp = 4.0 * 0.0199, inv_dvdp = 1.0 / 0.0199;   // superpressure_volume_f64
+  static constexpr double inv_cbrt_v0 = 0.08214626507693945;                                                  // 1804^(-1/3): the cold start
+  static constexpr double lift = 6830.0, dry_mass = kDryMassD;                                                // mols of helium; He + envelope + payload [kg]
+  static constexpr double envelope_mass = 68.5, payload_mass = 92.5, he_mass = kHeMolarMassD * 6830.0;       // the cold start subtracts them one by one
+  static constexpr double max_sp = 2380.0;                                                                     // burst threshold, EnvelopeSafetyLayer
+  static constexpr double drag_arg = 8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD);                        // 2 g (R / M) / cod, cod = 0.25
+  static constexpr double thermal_scale = 10.0 * 4.0 * kPiD * 0.38483473658887897 / (1500.0 * 68.5);          // 10 s x 4 pi (3 / (4 pi))^(2/3) / (c_p m_envelope)
+  static constexpr double valve_k = -0.62 * (kPiD * 0.04 * 0.04 / 4.0);                                        // -C_d x the valve's area
+  static constexpr double night_load_d = 183.7, capacity_d = 3058.56, day_load_d = 120.4;
+  static constexpr float day_load = 120.4f, night_load = 183.7f, capacity = 3058.56f;
+  static constexpr bool power_layer = true;                                                                    // power_safety_layer_enabled
+};
+struct VehicleRt {
+  double v0, dvdp, four_dvdp, inv_dvdp, inv_cbrt_v0, lift, dry_mass, envelope_mass, payload_mass, he_mass, max_sp, drag_arg, thermal_scale, valve_k;
+  double night_load_d, capacity_d, day_load_d;
+  float day_load, night_load, capacity;
+  bool power_layer;
+};
+
 // control.py / balloon.py enums
 enum : int { kDown = 0, kStay = 1, kUp = 2 };
 enum : int { kOk = 0, kOutOfPower = 1, kBurst = 2, kZeroPressure = 3 };
@@ -123,20 +149,20 @@ struct StrideK {
   double lg6, ex5;                                     // atm_temperature_advance
   double lift, v0;                                     // superpressure_volume_f64
 };
-BLE_FN StrideK stride_k_literal() {
+BLE_FN StrideK stride_k_literal(double dry_mass = VehicleDefault::dry_mass, double lift = VehicleDefault::lift, double v0 = VehicleDefault::v0) {
   StrideK k;
   k.ra_t0 = kRayleighT0; k.five = 5.0; k.eleven = 11.0; k.emit_b = kEmitB; k.emit_c = kEmitC;
-  k.dry_mass = kDryMassD;
+  k.dry_mass = dry_mass;
   k.lg5 = 0.2; k.lg4 = -0.25; k.lg3 = 1.0 / 3.0; k.ex4 = 1.0 / 24.0; k.ex3 = 1.0 / 6.0;
   k.acs_x0 = 0.05; k.forty = 40.0;
   k.t110 = 110.4; k.cond_tenth = kCondTenth;
   k.m_over_r = kAirMolarMassD / kGasConstantD; k.ten = 10.0;
   k.lg6 = -1.0 / 6.0; k.ex5 = 1.0 / 120.0;
-  k.lift = 6830.0; k.v0 = 1804.0;
+  k.lift = lift; k.v0 = v0;
   return k;
 }
-BLE_FN StrideK stride_k_vreg() {
-  StrideK k = stride_k_literal();
+BLE_FN StrideK stride_k_vreg(double dry_mass = VehicleDefault::dry_mass, double lift = VehicleDefault::lift, double v0 = VehicleDefault::v0) {
+  StrideK k = stride_k_literal(dry_mass, lift, v0);
   k.ra_t0 = d_vreg(k.ra_t0); k.five = d_vreg(k.five); k.eleven = d_vreg(k.eleven); k.emit_b = d_vreg(k.emit_b); k.emit_c = d_vreg(k.emit_c);
   k.dry_mass = d_vreg(k.dry_mass);
   k.lg5 = d_vreg(k.lg5); k.lg4 = d_vreg(k.lg4); k.lg3 = d_vreg(k.lg3); k.ex4 = d_vreg(k.ex4); k.ex3 = d_vreg(k.ex3);
@@ -552,8 +578,8 @@ BLE_FN int altitude_safety(int action, double altitude_m, uint8_t* fsm) {
 }
 // envelope_safety.py:40-157. fsm: 0 NOMINAL 1 LOW_CRITICAL 2 LOW 3 HIGH 4 HIGH_CRITICAL.
 // Thresholds are evaluated in fp64 on the (fp32) superpressure exactly as the reference.
-BLE_FN int envelope_safety(int action, float superpressure, uint8_t* fsm) {
-  const double sp = superpressure, mx = 2380.0;
+BLE_FN int envelope_safety(int action, float superpressure, uint8_t* fsm, double mx = VehicleDefault::max_sp) {
+  const double sp = superpressure;
   int s = *fsm;
   if (sp < 150.0) s = 1;
   else if (sp < 250.0) s = 2;
@@ -1141,7 +1167,7 @@ BLE_FN double earth_heat_per_area_f64(double upwelling_ir, uint32_t* flags) {   
 }
 template <bool kExactTwelfthRoot = false>
 BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double t_amb, double p, double q_solar_area,
-                                    double q_earth_area, const StrideK& K = stride_k_literal()) {
+                                    double q_earth_area, const StrideK& K = stride_k_literal(), double thermal_scale = VehicleDefault::thermal_scale) {
   constexpr double kR2 = 0.38483473658887897;          // (3 / (4 pi))^(2/3)
   constexpr double kR1 = 0.62035049089940009;          // (3 / (4 pi))^(1/3)
   const double v23 = vol * yc;
@@ -1171,7 +1197,7 @@ BLE_FN double thermal_increment_f64(double vol, double yc, double t_int, double 
   // k(T) / (2 r) = 0.0241 (T / 273.15)^0.9 V^(-1/3) / (2 (3 / (4 pi))^(1/3)): the constants ride on the tenth root's Newton factor
   const double q_conv = ((nusselt * (t_amb * d_inv_root10(t_amb, K.eleven, K.cond_tenth))) * yc) * dt;
   const double q = (q_solar_area + q_earth_area) + (q_conv - q_emit);
-  return (q * v23) * (10.0 * 4.0 * kPiD * kR2 / (1500.0 * 68.5));
+  return (q * v23) * thermal_scale;                   // 10 s x 4 pi r^2 / (c_p m_envelope), r^2 = (3 / (4 pi))^(2/3) V^(2/3)  (thermal.py:221-230)
 }
 
 // ---------------------------------------------------------------- envelope
@@ -1189,18 +1215,19 @@ BLE_FN void superpressure_volume(float mols_air, float t_int, float p, float* vo
 // fp64 variant for the vertical-dynamics chain (see ble_step_core.h): the buoyancy
 // difference rho V - m is an unstable map near float equilibrium, so V must be good to ~1e-9.
 BLE_FN void superpressure_volume_f64(double mols_air, double t_int, double p, double rp, double* volume, double* sp,
-                                     const StrideK& K = stride_k_literal()) {
+                                     const StrideK& K = stride_k_literal(), double dvdp = VehicleDefault::dvdp,
+                                     double four_dvdp = VehicleDefault::four_dvdp, double inv_dvdp = VehicleDefault::inv_dvdp) {
   // rp = 1/p.  Fully inflated branch: V from the quadratic (balloon.py:596-604); the
   // superpressure then follows from the envelope model V = V0 + dV/dp * sp, which is the
   // same root written without the division p Vu / V (relative difference ~1e-14).
   const double w = ((K.lift + mols_air) * kGasConstantD) * t_int;       // p Vu = n R T
   double vu = w * rp;
-  double b = -(K.v0 - 0.0199 * p);
-  double c4 = (4.0 * 0.0199) * w;                                       // 4 dV/dp (p Vu)
+  double b = -(K.v0 - dvdp * p);
+  double c4 = four_dvdp * w;                                            // 4 dV/dp (p Vu)
   double v = 0.5 * (d_sqrt_rs(d_fma(b, b, c4)) - b);
   bool slack = vu <= K.v0;
   *volume = slack ? vu : v;
-  *sp = slack ? 0.0 : (v - K.v0) * (1.0 / 0.0199);
+  *sp = slack ? 0.0 : (v - K.v0) * inv_dvdp;
 }
 
 // ---------------------------------------------------------------- ACS

@@ -90,36 +90,39 @@ BLE_FN double solar_attenuation_f64(double el_deg, double p) {   // solar.py:177
 // d_balloon_temperature_dt for the cold start: the transition's pow-free fp64 model (ble_physics.h), with the
 // twelfth root in fp64 as well.  yc = V^(-1/3).
 BLE_FN double thermal_dtdt_f64(double volume, double yc, double t_int, double t_amb, double p, double att, double flux,
-                               double q_earth_area) {
+                               double q_earth_area, double thermal_scale = VehicleDefault::thermal_scale) {
   constexpr double kSolarAbs = 0.01435 * (1.0 + (1.0 - 0.01435 - 0.0291) / (1.0 - 0.0291));
-  return 0.1 * thermal_increment_f64<true>(volume, yc, t_int, t_amb, p, flux * att * (0.25 * kSolarAbs), q_earth_area);
+  return 0.1 * thermal_increment_f64<true>(volume, yc, t_int, t_amb, p, flux * att * (0.25 * kSolarAbs), q_earth_area, stride_k_literal(),
+                                           thermal_scale);
 }
 struct StableParams { double t_amb, t_int, mols_air, volume, sp; };
-BLE_FN StableParams stable_params(double alpha, double p, double el_deg, double flux, double ir, uint32_t* flags) {
+// calculate_stable_params_for_pressure (stable_init.py:40-129) for the vehicle `veh` (ble_physics.h::VehicleDefault / VehicleRt)
+template <class V = VehicleDefault>
+BLE_FN StableParams stable_params(double alpha, double p, double el_deg, double flux, double ir, uint32_t* flags, const V& veh = V()) {
   StableParams o;
   const AtmWindow w = atm_window(alpha, p, flags);
   double h;
   atm_at_pressure_f64(w, alpha, p, &h, &o.t_amb);
-  double ma = ((p * kAirMolarMassD * 1804.0 / (kGasConstantD * o.t_amb) - 68.5 - 92.5 - kHeMolarMassD * 6830.0) /
+  double ma = ((p * kAirMolarMassD * veh.v0 / (kGasConstantD * o.t_amb) - veh.envelope_mass - veh.payload_mass - veh.he_mass) /
                kAirMolarMassD);
   o.mols_air = ma > 0.0 ? ma : 0.0;
   const double att = solar_attenuation_f64(el_deg, p);
   double ti = 206.0;
   const double delta = 0.01;
-  constexpr double kInvCbrt1804 = 0.08214626507693945;     // 1804^(-1/3)
   uint32_t ignored = 0;                                     // total_absorptivity of the Earth term: checked by the transition
   const double q_earth = earth_heat_per_area_f64(ir, &ignored);
 #pragma unroll 1
   for (int k = 0; k < 10; ++k) {
-    const double d1 = thermal_dtdt_f64(1804.0, kInvCbrt1804, ti - delta / 2, o.t_amb, p, att, flux, q_earth);
-    const double d2 = thermal_dtdt_f64(1804.0, kInvCbrt1804, ti + delta / 2, o.t_amb, p, att, flux, q_earth);
+    const double d1 = thermal_dtdt_f64(veh.v0, veh.inv_cbrt_v0, ti - delta / 2, o.t_amb, p, att, flux, q_earth, veh.thermal_scale);
+    const double d2 = thermal_dtdt_f64(veh.v0, veh.inv_cbrt_v0, ti + delta / 2, o.t_amb, p, att, flux, q_earth, veh.thermal_scale);
     const double d2t = (d2 - d1) / delta;
     const double mean = (d1 + d2) / 2.0;
     if (fabs(d2t) > 0.0) ti -= mean / d2t;
     if (fabs(mean) < 1e-5) break;
   }
   o.t_int = ti;
-  superpressure_volume_f64(o.mols_air, ti, p, 1.0 / p, &o.volume, &o.sp);
+  superpressure_volume_f64(o.mols_air, ti, p, 1.0 / p, &o.volume, &o.sp, stride_k_literal(veh.dry_mass, veh.lift, veh.v0), veh.dvdp, veh.four_dvdp,
+                           veh.inv_dvdp);
   return o;
 }
 

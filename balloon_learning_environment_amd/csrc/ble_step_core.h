@@ -20,6 +20,17 @@
 
 namespace ble {
 
+// The DEVICE pointers of ble_state_f32 (include/ble_abi.h: every member but the host-only `vehicle`), in its order: what the kernels take
+// as an argument.  (ble_kernels.hip asserts the layout and copies the prefix.)
+struct StateDev {
+  float *x, *y, *pressure, *ambient_temperature, *internal_temperature, *envelope_volume, *superpressure, *mols_air, *battery_charge;
+  float *acs_power, *acs_mass_flow, *solar_charging, *power_load;
+  const float *center_lat_deg, *center_lng_deg, *upwelling_infrared, *alpha;
+  const int64_t* start_unix;
+  int32_t *time_elapsed_s, *sunrise_h_rel, *sunset_rel;
+  uint8_t *status, *last_command, *alt_fsm, *env_fsm, *power_paused;
+  double* episode_cache;
+};
 struct EnvRegs {
   float x, y, p, t_amb, t_int, vol, sp, n_air, batt;
   float acs_power, mdot, charge, load;
@@ -114,29 +125,28 @@ struct LayerCursor {
 // d(dp)/d(rho V - m) ~ 1/sqrt|rho V - m| is unbounded, so an fp32-sized error in the increment itself is amplified past the
 // parity bar within a few substeps.  rho V - m = (p V M/R - m T) / T ; the common 1/T cancels in (rho V - m) / rho
 BLE_FN double stride_pressure(const AtmWindow& win, const LayerCursor& lc, double p, double rp, double vol, double n_air,
-                              double t_amb, double t_at_p, double yc, const StrideK& K) {
+                              double t_amb, double t_at_p, double yc, const StrideK& K, double drag_arg = VehicleDefault::drag_arg) {
   const double mass = d_fma(kAirMolarMassD, n_air, K.dry_mass);
   const double num = d_fma(p * vol, K.m_over_r, -mass * t_amb);
   const double dir = num >= 0.0 ? 1.0 : -1.0;
-  // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) 4 V^(-2/3))
-  const double arg = (8.0 * 9.80665 * (kGasConstantD / kAirMolarMassD)) * __builtin_fabs(num) * rp * (yc * yc);
+  // dh/dt = dir sqrt(|2 (rho V - m) g / (rho drag)|) = dir sqrt(2 g |num| (R/M) (1/p) V^(-2/3) / cod); drag_arg = 2 g (R/M) / cod (cod = 0.25: 8 g R/M)
+  const double arg = drag_arg * __builtin_fabs(num) * rp * (yc * yc);
   const double dh_dt = d_sqrt_rs(d_max(arg, 1e-30));                      // arg == 0 (exact equilibrium): 1e-15 m/s, p unchanged
   const double inv_dh = atm_inv_delta_height_f64(win, lc.lay, lc.lapse_cur, lc.kl_cur, lc.cur_hi, lc.cur_lo, p, rp, dir, t_at_p, K);
   return d_fma(inv_dh * dh_dt, K.ten, p);                                 // dir * dir == 1
 }
 // step 3: internal temperature (balloon.py:451-467)
 BLE_FN double stride_internal_temperature(double vol, double yc, double t_int, double t_amb, double p, float flux, float att,
-                                          double q_earth, const StrideK& K) {
-  return t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth, K);
+                                          double q_earth, const StrideK& K, double thermal_scale = VehicleDefault::thermal_scale) {
+  return t_int + thermal_increment_f64(vol, yc, t_int, t_amb, p, (double)((flux * att) * (0.25f * kSolarAbsorptivityTotal)), q_earth, K, thermal_scale);
 }
 // step 5: ACS (balloon.py:487-519); both branches evaluated, selected per lane.  fp64: the mass flow changes rho V - m by
 // ~1e-2 kg per stride, an fp32 rounding of it (~1e-9 kg) is amplified like the thermal increment's.
 BLE_FN void stride_acs(const double* acs_poly, int eff, double sp, double p, double rp, double t_int, float* acs_w, double* mdot_d,
-                       const StrideK& K) {
-  constexpr double kValveArea = kPiD * 0.04 * 0.04 / 4.0;
+                       const StrideK& K, double valve_k = VehicleDefault::valve_k) {
   // -0.62 A sqrt(2 sp rho_gas), rho_gas = (sp + p) M / (R T_int):  sqrt(a / T) = a rsqrt(a T)
   const double a2 = d_max((2.0 * (kAirMolarMassD / kGasConstantD)) * (sp * (sp + p)), 1e-30);
-  const double mdot_up = ((-0.62 * kValveArea) * a2) * d_rsqrt(a2 * t_int);           // sp == 0: -1e-17 kg/s
+  const double mdot_up = (valve_k * a2) * d_rsqrt(a2 * t_int);                        // valve_k = -0.62 A;  sp == 0: -1e-17 kg/s
   const double prm1 = d_max(sp * rp, 0.0);                // pressure_ratio - 1 = max(sp, 0) / p (balloon.py:247-250; rp > 0)
   double w_down, mdot_down;
   acs_down_poly(acs_poly, prm1, &w_down, &mdot_down, K);
@@ -147,13 +157,17 @@ BLE_FN double stride_mols_air(double n_air, double mdot_d) {
   return d_max(d_fma(mdot_d, 10.0 / kAirMolarMassD, n_air), 0.0);
 }
 // step 6: power (balloon.py:524-542)
-BLE_FN void stride_power_from_factor(bool is_day, float panel_factor, float att, float acs_w, float* charge, float* load, float* batt) {
+BLE_FN void stride_power_from_factor(bool is_day, float panel_factor, float att, float acs_w, float* charge, float* load, float* batt,
+                                     float day_load = VehicleDefault::day_load, float night_load = VehicleDefault::night_load,
+                                     float capacity = VehicleDefault::capacity) {
   *charge = is_day ? solar_power_from_factor(panel_factor, att) : 0.0f;
-  *load = (is_day ? kDayLoad : kNightLoad) + acs_w;
-  *batt = f_clamp(f_fma(*charge - *load, kStride / 3600.0f, *batt), 0.0f, kBatteryCapacity);
+  *load = (is_day ? day_load : night_load) + acs_w;
+  *batt = f_clamp(f_fma(*charge - *load, kStride / 3600.0f, *batt), 0.0f, capacity);
 }
-BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* charge, float* load, float* batt) {
-  stride_power_from_factor(sun.day, solar_panel_factor(sun), att, acs_w, charge, load, batt);
+BLE_FN void stride_power(const SunState& sun, float att, float acs_w, float* charge, float* load, float* batt,
+                         float day_load = VehicleDefault::day_load, float night_load = VehicleDefault::night_load,
+                         float capacity = VehicleDefault::capacity) {
+  stride_power_from_factor(sun.day, solar_panel_factor(sun), att, acs_w, charge, load, batt, day_load, night_load, capacity);
 }
 // T(p_new) for the next stride: advance inside the layer; if a transition was crossed (cold branch) re-anchor at it first --
 // no transcendental either way (see AtmWindow).  Updates the cursor.
@@ -259,16 +273,20 @@ BLE_FN SunState sun_at_stride(int kk, const SunQuadratic& sq, const EnvConst& c,
 // float64, on the float32 charge the ABI carries.  A correctly rounded division is monotone in its numerator, so the predicate
 // is a threshold on the float32 itself: 3027.9746 (0x1.7a7f3p+11) is the smallest float32 b with (double)b / 3058.56 > 0.99
 // (its predecessor gives 0.98999999; tests/test_kernel_numerics_host.py) -- the same decision without the fp64 division.
-BLE_FN bool battery_above_99_percent(float batt) { return batt >= 3027.9746f; }
+// Another capacity (a run-time vehicle): the reference's division.
+BLE_FN bool battery_above_99_percent(float batt, double capacity_wh = VehicleDefault::capacity_d) {
+  return capacity_wh == 3058.56 ? batt >= 3027.9746f : (double)batt / capacity_wh > 0.99;
+}
 // perciatelli_reward_function (env/balloon_env.py:44-102) on the post-step state; `sun` = the sun at the end of the step
 // (only read when the raw action was DOWN: last_command is the RAW action, balloon.py:286)
 template <typename SunFn>
-BLE_FN float step_reward(int action, float x, float y, float p, float batt, float acs_power, SunFn sun_end) {
+BLE_FN float step_reward(int action, float x, float y, float p, float batt, float acs_power, SunFn sun_end,
+                         float day_load = VehicleDefault::day_load, double capacity_wh = VehicleDefault::capacity_d) {
   float r = reward_distance(x, y);
   if (action == kDown) {
     const SunState sun = sun_end();
     const float pw = solar_power(sun, solar_attenuation(sun.sin_el, p, sun.day));
-    const bool excess = (pw > kDayLoad) && battery_above_99_percent(batt);   // balloon.py:231-238
+    const bool excess = (pw > day_load) && battery_above_99_percent(batt, capacity_wh);   // balloon.py:231-238
     if (!excess) {
       const float scale = f_clamp((acs_power - 100.0f) * (1.0f / 200.0f), 0.0f, 1.0f);
       r *= f_fma(-0.3f, scale, 0.95f);
@@ -282,9 +300,11 @@ constexpr int kTermSaveRows = 14, kTermSaveStride = 64;   // agent_step's parkin
 // reward; `s` is advanced in place.  Precondition: s.status == kOk.
 // The wind is handed over as the 16 gathered grid corners + weights (+ additive noise): the
 // blend happens after the per-step constants so that the gather's latency is covered.
+// `veh`: the flight vehicle (VehicleDefault: compile-time constants -- the code and the bits of every round before ABI 5 --, or VehicleRt).
+template <class V = VehicleDefault>
 BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int action, const WindCorners& corners, const WindQuery& wq,
                       float noise_u, float noise_v, int substeps, const double* acs_poly, const StrideK& K, float* term_save,
-                      float* reward, uint32_t* flags) {
+                      float* reward, uint32_t* flags, const V& veh = V()) {
   BLE_STEP_TICK(0);
   // ---- atmosphere at the pre-step pressure, fp64 (altitude layer + start of T(p) chain)
   const float p0_in = s.p;
@@ -296,8 +316,10 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   lc.lay = 0; lc.lapse_cur = win.lapse_0; lc.kl_cur = (-kAirSpecificGasD / 9.80665) * win.lapse_0; lc.cur_hi = win.pb; lc.cur_lo = win.pt;
 
   // ---- safety layers, once per agent step, on the pre-step state (balloon.py:304-313)
-  int eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused);
-  eff = envelope_safety(eff, s.sp, &s.env_fsm);
+  int eff = action;
+  if (veh.power_layer)                           // BalloonState.power_safety_layer_enabled (balloon.py:305): a disabled layer's clocks do not move
+    eff = power_safety(action, s.t_elapsed, s.batt, &s.sunrise_h, &s.sunset, &s.paused, veh.night_load_d, veh.capacity_d);
+  eff = envelope_safety(eff, s.sp, &s.env_fsm, veh.max_sp);
   eff = altitude_safety(eff, altitude, &s.alt_fsm);
   BLE_STEP_TICK(1);
 
@@ -352,26 +374,26 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
 
     // ---- step 2: buoyancy -> dh/dt -> dp (balloon.py:412-445)
     const double yc = inv_cbrt_volume(vol);
-    const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc, K);
+    const double p_new = stride_pressure(win, lc, p, rp, vol, n_air, t_amb, t_at_p, yc, K, veh.drag_arg);
 
     // ---- step 3: temperatures (balloon.py:451-467)
     const float att = solar_attenuation(sun.sin_el, pf, sun.day);
-    const double t_int_new = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth, K);
+    const double t_int_new = stride_internal_temperature(vol, yc, t_int, t_amb, p, flux, att, q_earth, K, veh.thermal_scale);
 
     // ---- step 4: superpressure and volume (balloon.py:470-482)
     double vol_new, sp_new;
-    superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new, K);
-    // balloon.py:479-482: burst above 2 380 Pa, zero pressure at <= 0 (the status code is formed after the loop)
-    bool terminal = !(sp_new <= 2380.0) || sp_new <= 0.0;
+    superpressure_volume_f64(n_air, t_int, p, rp, &vol_new, &sp_new, K, veh.dvdp, veh.four_dvdp, veh.inv_dvdp);
+    // balloon.py:479-482: burst above envelope_max_superpressure (2 380 Pa), zero pressure at <= 0 (the status code is formed after the loop)
+    bool terminal = !(sp_new <= veh.max_sp) || sp_new <= 0.0;
 
     // ---- step 5: ACS (balloon.py:487-519)
     double mdot_d;
-    stride_acs(acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d, K);
+    stride_acs(acs_poly, eff, sp, p, rp, t_int, &acs_w, &mdot_d, K, veh.valve_k);
     mdot = (float)mdot_d;
     const double n_air_new = stride_mols_air(n_air, mdot_d);
 
     // ---- step 6: power (balloon.py:524-542)
-    stride_power(sun, att, acs_w, &charge, &load, &batt);
+    stride_power(sun, att, acs_w, &charge, &load, &batt, veh.day_load, veh.night_load, veh.capacity);
     terminal = terminal || batt <= 0.0f;          // balloon.py:541-542
 
     // ---- commit (balloon.py:322-325): every RHS above used the old state
@@ -382,10 +404,10 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
     p = p_new; t_int = t_int_new; vol = vol_new; sp = sp_new; n_air = n_air_new;
     if (__builtin_expect(wave_any(terminal), 0)) if (terminal && __builtin_bit_cast(int, *term_word) == 0) {          // balloon.py:327-328
       // status of the stride that ended the step (later checks override earlier ones, like the reference's assignments).  The burst
-      // test is `!(sp <= 2380)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
+      // test is `!(sp <= max)`: a non-finite superpressure ends the episode too (kBurst + kFlagNonFinite), so that the lane is
       // frozen for the remaining steps of a fused launch instead of stepping on NaN state.
       int st = kOk;
-      if (!(sp <= 2380.0)) st = kBurst;
+      if (!(sp <= veh.max_sp)) st = kBurst;
       if (sp <= 0.0) st = kZeroPressure;
       if (batt <= 0.0f) st = kOutOfPower;
       const float parked[kTermSaveRows - 1] = {x, y, (float)p, (float)t_amb, (float)t_int, (float)vol, (float)sp, (float)n_air, batt,
@@ -423,7 +445,7 @@ BLE_FN int agent_step(EnvRegs& s, const EnvConst& c, const EnvHoisted& hc, int a
   *flags |= (s.p > 101325.0f || s.p < 0.0f || p0_in > 101325.0f || p0_in < 0.0f) ? kFlagSolarRange : 0u;
 
   // ---- reward (env/balloon_env.py:44-102), on the post-step state
-  *reward = step_reward(action, s.x, s.y, s.p, s.batt, s.acs_power, [&]() { return sun_at(k); });
+  *reward = step_reward(action, s.x, s.y, s.p, s.batt, s.acs_power, [&]() { return sun_at(k); }, veh.day_load, veh.capacity_d);
   BLE_STEP_TICK(6);
   return eff;
 }

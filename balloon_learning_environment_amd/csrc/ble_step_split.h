@@ -102,7 +102,7 @@ template <> struct SplitNoiseShared<true> {
 };
 
 struct SplitArgs {
-  ble_state_f32 st;
+  StateDev st;
   const uint8_t* action;
   const float* wind_grid;
   int64_t grid_env_stride;
@@ -137,7 +137,7 @@ BLE_FN uint32_t split_agent_steps(const SplitArgs& a, SplitShared& sh, SplitNois
   EnvConst c = {};
   EpisodeCacheRow cached = {};
   bool live = false;
-  const ble_state_f32& st = a.st;
+  const StateDev& st = a.st;
   // a lane beyond the batch flies a harmless shadow (never stored): finite, inside the first layer of the atmosphere
   s.p = 9000.0f; s.t_amb = 215.0f; s.t_int = 220.0f; s.vol = 1810.0f; s.sp = 300.0f; s.n_air = 1500.0f; s.batt = 2000.0f;
   s.status = kBurst; s.sunrise_h = 43200; s.sunset = 21600;

@@ -76,7 +76,9 @@ class VecSimulator:
     with torch.cuda.device(self.device):
       self.episode_cache = torch.zeros(_abi.EPISODE_CACHE_ROWS, self.n, dtype=torch.float64, device=self.device)
     self._struct = dev.state_struct(self.state, self.episode_cache)
+    self.vehicle: Dict[str, float] = {}     # the BalloonState vehicle fields that differ from the reference's defaults (set_vehicle)
     self._noise_cache = None        # per-episode draws of the wind noise's harmonics (allocated by the first wind_noise())
+    self._noise_gens = []           # the ble_noise_gen structs handed out (prepared launches hold them): load_state_dict re-keys them
     self._gp = None                 # WindGP history ring (allocated by the first observe())
     self._obs_reset = None          # envs whose history must restart at the next observe()
 
@@ -103,6 +105,19 @@ class VecSimulator:
       assert tuple(g.shape) == GRID_SHAPE, g.shape
       self.grid_env_stride = 0
     self.grid = g
+
+  def set_vehicle(self, **fields) -> None:
+    """The flight vehicle every balloon of this simulator flies: BalloonState's vehicle constants (reference
+    env/balloon/balloon.py:156-173: envelope_volume_base, envelope_volume_dv_pressure, envelope_mass,
+    envelope_max_superpressure, envelope_cod, payload_mass, nighttime_power_load_w, daytime_power_load_w,
+    acs_valve_hole_diameter_m, battery_capacity_wh), mols_lift_gas (:183) and power_safety_layer_enabled (:200), by keyword;
+    what is not named keeps the reference's default.  No argument (or all defaults): the kernels with compile-time constants
+    (ble_state_f32.vehicle == NULL).  Takes effect with the next launch, prepared launches and captured graphs included
+    (they read the struct this updates) -- except that a captured graph holds the KERNEL it captured: re-capture after
+    switching between the default vehicle and another one."""
+    veh = _abi.vehicle_struct(**fields)
+    _abi.set_vehicle(self._struct, veh)
+    self.vehicle = {} if veh is None else {k: getattr(veh, k) for k in _abi.VEHICLE_DEFAULTS if getattr(veh, k) != _abi.VEHICLE_DEFAULTS[k]}
 
   # ------------------------------------------------------------------ reset on the device
   @_on_own_device
@@ -172,7 +187,8 @@ class VecSimulator:
     the wind grid(s), the WindGP history (ring, carried factor, pending resets) and the live-environment counter --
     clones, on the simulator's device.  The derived caches (per-episode constants, noise draws) are not part of it: they
     are keyed by what they were derived from and refill themselves."""
-    d = {'n': self.n, 'env_offset': self.env_offset, 'state': {k: t.clone() for k, t in self.state.items()}, 'episode': self.episode.clone(),
+    d = {'n': self.n, 'env_offset': self.env_offset, 'vehicle': dict(self.vehicle), 'noise_primitive_version': _lib.NOISE_PRIMITIVE_VERSION,
+         'state': {k: t.clone() for k, t in self.state.items()}, 'episode': self.episode.clone(),
          'active_slots': self.active_slots.clone(), 'err_flags': self.err_flags.clone(),
          'grid': None if self.grid is None else self.grid.clone(), 'grid_env_stride': self.grid_env_stride, 'gp': None}
     if self._gp is not None:
@@ -187,7 +203,20 @@ class VecSimulator:
     has another layout (shared vs per-environment) replaces the grid tensor; launches prepared before must then be
     prepared again."""
     assert int(d['n']) == self.n, f"checkpoint of {d['n']} environments, simulator of {self.n}"
-    self.env_offset = int(d.get('env_offset', self.env_offset))
+    made_with = int(d.get('noise_primitive_version', _lib.NOISE_PRIMITIVE_VERSION))
+    if made_with != _lib.NOISE_PRIMITIVE_VERSION:      # (include/ble_abi.h::BLE_NOISE_PRIMITIVE_VERSION)
+      raise ValueError(f'checkpoint flown with wind-noise primitive version {made_with}, this library evaluates version '
+                       f'{_lib.NOISE_PRIMITIVE_VERSION}: its noise seeds would fly another wind')
+    offset = int(d.get('env_offset', self.env_offset))
+    if offset != self.env_offset:
+      # another shard's checkpoint: the harmonic draws cached for (seed, episode) belong to the OLD global indices -- forget them
+      # -- and the generators already handed out (prepared launches hold them by reference) are re-keyed in place
+      self.env_offset = offset
+      if self._noise_cache is not None:
+        self._noise_cache.zero_()
+      for gen in self._noise_gens:
+        gen.env_offset = offset
+    self.set_vehicle(**d.get('vehicle', {}))
     for k, t in self.state.items():
       t.copy_(d['state'][k])
     self.episode.copy_(d['episode']); self.active_slots.copy_(d['active_slots']); self.err_flags.copy_(d['err_flags'])
@@ -254,7 +283,7 @@ class VecSimulator:
     _lib.check(code, 'ble_step_f32')
     return self.reward, self.terminal
 
-  def _noise_gen(self, noise_seed: Optional[int]):
+  def _noise_gen(self, noise_seed: Optional[int], prepared: bool = False):
     """The ble_noise_gen of a fused rollout that flies in the ground-truth wind (forecast + SimplexWindNoise evaluated
     inside the kernel), or None for the forecast alone.  Same generator as wind_noise(seed): same (seed, env, episode)."""
     if noise_seed is None:
@@ -262,7 +291,10 @@ class VecSimulator:
     if self._noise_cache is None:
       with torch.cuda.device(self.device):
         self._noise_cache = torch.zeros(_lib.NOISE_CACHE_ROWS, self.n, dtype=torch.int32, device=self.device)
-    return _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr(), self.env_offset)
+    gen = _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr(), self.env_offset)
+    if prepared:          # a prepared launch keeps its generator: load_state_dict re-keys it when the shard offset changes
+      self._noise_gens.append(gen)
+    return gen
 
   @_on_own_device
   def step_n(self, actions: torch.Tensor, rewards: torch.Tensor, terminals: torch.Tensor,
@@ -298,7 +330,7 @@ class VecSimulator:
       assert active_counts.is_contiguous()
     assert self.grid is not None, 'Must call set_grid (reset) before step.'
     fn, struct = self.lib.ble_step_n_f32, ctypes.byref(self._struct)
-    gen = self._noise_gen(noise_seed)            # (kept alive by the closure)
+    gen = self._noise_gen(noise_seed, prepared=True)            # (kept alive by the closure)
     grid = self.grid                             # the closure reads THIS tensor: load_state_dict restores it in place
     args = (struct, actions.data_ptr(), grid.data_ptr(), self.grid_env_stride, None if gen is None else ctypes.byref(gen),
             rewards.data_ptr(), terminals.data_ptr(), self.err_flags.data_ptr(), dev.ptr(active_counts), self.n, substeps, k)

@@ -37,7 +37,19 @@ extern "C" {
 /* 2: ble_state_f32 gained the optional episode_cache; ble_wind_noise_f32 the optional harmonic_cache; ble_gp_history_f32 gained chol_stride and the carried slab grew to 7620 doubles (packed Cholesky L -> Lt D Lt^T +
  *    drop vector + zeta / d): a caller built against version 1 allocates 7260 doubles per environment. */
 /* 3: ble_step_n_f32 gained `noise` (ble_noise_gen: the wind-noise generator evaluated inside the fused rollout). */
-#define BLE_ABI_VERSION 4
+/* 4: ble_set_step_form, ble_probe_latlng_f64, the shard forms ble_reset_at_f32 / ble_wind_noise_at_f32 / ble_noise_gen.env_offset. */
+/* 5: ble_state_f32 gained the optional `vehicle` (ble_vehicle: BalloonState's flight-vehicle constants and
+ *    power_safety_layer_enabled as run-time inputs); ble_noise_primitive_version(); ble_set_step_form(2) is refused by the product
+ *    library (the two-wavefront form is an experiment build); ble_step_n_f32 rejects a negative ble_noise_gen.env_offset. */
+#define BLE_ABI_VERSION 5
+
+/* Version of the wind-noise PRIMITIVE's bit pattern (csrc/ble_noise.h::simplex4 and the hash / draw streams under it).  The primitive
+ * is this library's own (the reference's opensimplex==0.3 noise4d is absent and unpinned), so its values are defined by this
+ * repository -- and whenever they change, for whatever reason, this number is bumped: a noise seed recorded against version k flies
+ * the same wind only on a library that reports k.  The host mirror refuses a library whose version differs from the one its oracle
+ * (oracle/noise_oracle.py::PRIMITIVE_VERSION) and the committed fixture (tests/golden/f14_wind_noise.npz::noise_primitive_version)
+ * were made with; checkpoints carry it.  1: rounds 2-4.  2: round 5 (explicit FMAs in a corner's sums, offsets by select). */
+#define BLE_NOISE_PRIMITIVE_VERSION 2
 
 /* return codes */
 #define BLE_OK 0
@@ -65,16 +77,37 @@ extern "C" {
 #define BLE_COUNT_SLOTS 64 /* width of the live-environment counter, see ble_step_f32 */
 
 /*
+ * BalloonState's flight-vehicle constants (balloon.py:156-172: dataclass FIELDS with defaults), mols_lift_gas (:183, a state
+ * field no transition changes) and power_safety_layer_enabled (:200, read by simulate_step :305).  A HOST struct of doubles --
+ * the reference's are Python floats and several defaults (0.0199, 183.7, 3058.56) are not float32 numbers.  One vehicle per
+ * call: every environment of a batch flies the same one (the reference builds one BalloonState per balloon; batches of
+ * different vehicles are different calls).  ble_vehicle_default() fills in the reference's defaults.
+ */
+typedef struct ble_vehicle {
+  double envelope_volume_base;         /* [m^3]   1804      balloon.py:157 */
+  double envelope_volume_dv_pressure;  /* [m^3/Pa] 0.0199   :158 */
+  double envelope_mass;                /* [kg]    68.5      :159 */
+  double envelope_max_superpressure;   /* [Pa]    2380      :160 (burst threshold and EnvelopeSafetyLayer's argument, :204-205) */
+  double envelope_cod;                 /* [.]     0.25      :163 */
+  double payload_mass;                 /* [kg]    92.5      :166 */
+  double nighttime_power_load_w;       /* [W]     183.7     :168 */
+  double daytime_power_load_w;         /* [W]     120.4     :169 */
+  double acs_valve_hole_diameter_m;    /* [m]     0.04      :171 */
+  double battery_capacity_wh;          /* [Wh]    3058.56   :173 */
+  double mols_lift_gas;                /* [mol]   6830      :183 */
+  int32_t power_safety_layer_enabled;  /* bool    1         :200 */
+  int32_t reserved_;                   /* 0 */
+} ble_vehicle;
+
+/*
  * Per-environment simulator state, struct of device arrays.
  * Replaces: BalloonState (env/balloon/balloon.py:73-250), the three safety-layer
  * objects it owns (altitude_safety.py:63-111, envelope_safety.py:93-157,
  * power_safety.py:26-126) and Atmosphere's per-episode alpha
  * (standard_atmosphere.py:76-87).
- * The flight-vehicle parameters, which are dataclass fields with defaults in the reference (balloon.py:156-173: envelope
- * volume base / dV/dp, envelope mass, maximum superpressure, drag coefficient, lift-gas mols, payload mass, battery
- * capacity, day / night loads), are COMPILE-TIME constants of the kernels (csrc/ble_physics.h), fixed at those defaults --
- * the values every BASELINE configuration flies.  A vehicle with other parameters needs a rebuild; the Python mirrors
- * raise NotImplementedError for non-default values instead of silently flying the default balloon.
+ * The flight-vehicle constants: `vehicle` below (ABI 5).  NULL -- every BASELINE configuration -- selects kernels in which the
+ * reference's defaults are compile-time constants (csrc/ble_physics.h::VehicleDefault); a non-NULL vehicle selects a second
+ * instantiation of the same lane functions that reads them from scalar registers (csrc/ble_physics.h::VehicleRt).
  */
 typedef struct ble_state_f32 {
   /* mutable, read+written by ble_step_f32 (balloon.py:175-195) */
@@ -114,8 +147,15 @@ typedef struct ble_state_f32 {
    * sin / cos of the centre latitude, the earth-IR heat per unit area), keyed by the bit patterns of (alpha,
    * center_lat_deg, upwelling_infrared).  ble_reset_f32 fills it; ble_step_f32 / ble_step_n_f32 read it and, where an
    * entry does not match the constants in `st` (edited by hand, or never reset on the device), recompute and store it --
-   * so it can never go stale.  NULL: recomputed by every launch (0.8 us per launch). */
+   * so it can never go stale.  NULL: recomputed by every launch (0.8 us per launch).  Entries are functions of the episode's
+   * constants alone, not of the vehicle. */
   double* episode_cache;
+  /* OPTIONAL (may be NULL), ABI 5: HOST pointer to the vehicle every environment of this call flies, read on the host when the
+   * call is made (not retained).  NULL = the reference's defaults.  Honoured by ble_step_f32 / ble_step_n_f32 (one lane per
+   * environment whatever the batch size), ble_reset_f32 / ble_reset_at_f32 (the cold start) and ble_observe_f32 (battery state of
+   * charge, excess energy, the reachable pressure range).  A vehicle with a non-positive volume base, dV/dp, capacity, drag
+   * coefficient or maximum superpressure <= 300 Pa (envelope_safety.py's bands would overlap) is rejected with BLE_E_INVALID_ARG. */
+  const ble_vehicle* vehicle;
 } ble_state_f32;
 #define BLE_EPISODE_CACHE_ROWS 7
 #define BLE_MAX_SUBSTEPS 60
@@ -127,12 +167,20 @@ typedef struct ble_state_f32 {
 
 int ble_abi_version(void);
 
+/* BLE_NOISE_PRIMITIVE_VERSION of the loaded library (above). */
+int ble_noise_primitive_version(void);
+
+/* Fills *v with the reference's defaults (balloon.py:156-173,183,200); returns BLE_OK or BLE_E_INVALID_ARG (v == NULL). */
+int ble_vehicle_default(ble_vehicle* v);
+
 /* hipError_t (as int) of the calling thread's most recent launch through this library; 0 = success.
  * Diagnostic companion of BLE_E_LAUNCH. */
 int ble_last_hip_error(void);
 
 /* Which form of the transition kernel ble_step_f32 / ble_step_n_f32 launch: 0 = automatic (by batch size, above), 1 = one
- * lane per environment, 4 = four wavefronts per environment, 2 = two (an A/B form the automatic choice never takes).
+ * lane per environment, 4 = four wavefronts per environment.  (2 = two wavefronts per environment exists in experiment builds
+ * only -- profiles/build_variant.sh -DBLE_WITH_PAIR_FORM; the product library answers BLE_E_INVALID_ARG since ABI 5: the form was
+ * never selected and measured slower at every batch size.)
  * Process-global, thread-safe; takes effect with the next launch.  Returns the previous setting (>= 0) or
  * BLE_E_INVALID_ARG.  The initial value is 0, or what BLE_STEP_SPLIT (0 -> one lane, 1 / 4, 2) in the process environment
  * says when the library first looks at it -- once, not per launch.  (ABI 4; ABI 3 re-read the variable on every launch.) */

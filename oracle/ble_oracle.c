@@ -753,18 +753,29 @@ typedef struct {
   int status;
 } sub_state;
 
+/* BalloonState's flight-vehicle constants (balloon.py:156-173: dataclass fields), mols_lift_gas (:183) and
+ * power_safety_layer_enabled (:200): the same struct as include/ble_abi.h::ble_vehicle.  NULL = the defaults. */
+typedef struct {
+  double envelope_volume_base, envelope_volume_dv_pressure, envelope_mass, envelope_max_superpressure, envelope_cod,
+      payload_mass, nighttime_power_load_w, daytime_power_load_w, acs_valve_hole_diameter_m, battery_capacity_wh,
+      mols_lift_gas;
+  int32_t power_safety_layer_enabled, reserved_;
+} orc_vehicle;
+static const orc_vehicle ORC_VEHICLE_DEFAULT = {1804, 0.0199, 68.5, 2380, 0.25, 92.5, 183.7, 120.4, 0.04, 3058.56, 6830.0, 1, 0};
+
 /* balloon.py:356-549: one stride; all right-hand sides read the OLD state `s`. */
 static int simulate_step_internal(sub_state* s, double u, double v, const orc_atm* atm, int action,
                                   double lat0_rad, double lng0_rad, int64_t start_unix, double ir,
-                                  double stride_s) {
+                                  double stride_s, const orc_vehicle* veh) {
   int err = 0;
   sub_state n = *s;
   n.x = s->x + (u * stride_s); /* :394-395 */
   n.y = s->y + (v * stride_s);
 
   double rho_air = (s->p * DRY_AIR_MOLAR_MASS) / (UNIVERSAL_GAS_CONSTANT * s->t_amb); /* :412 */
-  double drag = 0.25 * pow(s->vol, 2.0 / 3.0);                                       /* :415 */
-  double total_mass = (HE_MOLAR_MASS * 6830.0 + DRY_AIR_MOLAR_MASS * s->n_air + 68.5 + 92.5);
+  double drag = veh->envelope_cod * pow(s->vol, 2.0 / 3.0);                          /* :415 */
+  double total_mass = (HE_MOLAR_MASS * veh->mols_lift_gas + DRY_AIR_MOLAR_MASS * s->n_air + veh->envelope_mass +
+                       veh->payload_mass); /* :417-420 */
   double direction = (rho_air * s->vol >= total_mass) ? 1.0 : -1.0;
   double dh_dt =
       direction * sqrt(fabs(2 * (rho_air * s->vol - total_mass) * GRAVITY / (rho_air * drag)));
@@ -781,16 +792,17 @@ static int simulate_step_internal(sub_state* s, double u, double v, const orc_at
   err |= solar_calculator(lat, lng, start_unix + s->t_elapsed, &el, NULL, &flux);
   double h_unused;
   err |= atm_at_pressure(atm, s->p, &h_unused, &n.t_amb); /* :457 */
-  double d_t = d_balloon_temperature_dt(s->vol, 68.5, s->t_int, s->t_amb, s->p, el, flux, ir, &err);
+  double d_t = d_balloon_temperature_dt(s->vol, veh->envelope_mass, s->t_int, s->t_amb, s->p, el, flux, ir, &err);
   n.t_int = s->t_int + d_t * stride_s; /* :466-467 */
 
-  superpressure_and_volume(6830.0, s->n_air, s->t_int, s->p, 1804, 0.0199, &n.vol, &n.sp);
-  if (n.sp > 2380) n.status = ST_BURST;       /* :479-480 */
+  superpressure_and_volume(veh->mols_lift_gas, s->n_air, s->t_int, s->p, veh->envelope_volume_base,
+                           veh->envelope_volume_dv_pressure, &n.vol, &n.sp);
+  if (n.sp > veh->envelope_max_superpressure) n.status = ST_BURST; /* :479-480 */
   if (n.sp <= 0.0) n.status = ST_ZEROPRESSURE; /* :481-482 */
 
   if (action == UP) { /* :487-499 */
     n.acs_power = 0.0;
-    double valve_area = PI * pow(0.04, 2) / 4.0;
+    double valve_area = PI * pow(veh->acs_valve_hole_diameter_m, 2) / 4.0;
     double gas_density = (s->sp + s->p) * DRY_AIR_MOLAR_MASS / (UNIVERSAL_GAS_CONSTANT * s->t_int);
     n.mdot = (-1 * 0.62 * valve_area * sqrt(2.0 * s->sp * gas_density));
   } else if (action == DOWN) { /* :500-510 */
@@ -811,11 +823,11 @@ static int simulate_step_internal(sub_state* s, double u, double v, const orc_at
     err |= solar_power(el, s->p, &n.charge);
   else
     n.charge = 0.0;
-  n.load = (is_day ? 120.4 : 183.7);
+  n.load = (is_day ? veh->daytime_power_load_w : veh->nighttime_power_load_w);
   n.load += n.acs_power;
   /* Power * timedelta -> watts * (seconds / 3600.0) watt-hours (units.py:277-281,309-314) */
   n.batt = s->batt + (n.charge - n.load) * (stride_s / 3600.0);
-  n.batt = fmin(fmax(n.batt, 0.0), 3058.56);
+  n.batt = fmin(fmax(n.batt, 0.0), veh->battery_capacity_wh);
   if (n.batt <= 0.0) n.status = ST_OUT_OF_POWER; /* :541-542 */
   n.t_elapsed = s->t_elapsed + (int64_t)stride_s;
   *s = n;
@@ -824,7 +836,7 @@ static int simulate_step_internal(sub_state* s, double u, double v, const orc_at
 
 /* env/balloon_env.py:44-102 + BalloonState.excess_energy balloon.py:231-238 */
 static double perciatelli_reward(const sub_state* s, int last_command, double lat0_rad,
-                                 double lng0_rad, int64_t start_unix, int* err) {
+                                 double lng0_rad, int64_t start_unix, int* err, const orc_vehicle* veh) {
   double distance = sqrt(s->x * s->x + s->y * s->y);
   double radius = 50.0 * 1000.0;
   double reward;
@@ -837,7 +849,7 @@ static double perciatelli_reward(const sub_state* s, int last_command, double la
     latlng_from_offset(lat0_rad, lng0_rad, s->x, s->y, &lat, &lng);
     *err |= solar_calculator(lat, lng, start_unix + s->t_elapsed, &el, NULL, &flux);
     *err |= solar_power(el, s->p, &sp_w);
-    int excess = (sp_w > 120.4) && (s->batt / 3058.56 > 0.99);
+    int excess = (sp_w > veh->daytime_power_load_w) && (s->batt / veh->battery_capacity_wh > 0.99);
     if (!excess) {
       double scale = (s->acs_power - 100.0) / (300.0 - 100.0); /* transforms.py:47-66 */
       scale = fmin(fmax(scale, 0.0), 1.0);
@@ -857,11 +869,12 @@ static double perciatelli_reward(const sub_state* s, int last_command, double la
  * `noise_uv` (n x 2) may be NULL.  `field` may be NULL if `wind_uv` (n x 2) is given
  * (fixed wind per step, used by trajectory fixtures).  Returns OR of error bits.
  */
-ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* field,
-                     const double* wind_uv, const double* noise_uv, double* reward,
-                     uint8_t* terminal, uint8_t* effective_action, int64_t n, int substeps,
-                     int n_threads) {
+ORC_API int orc_step_vehicle(const orc_state* st, const uint8_t* action, const float* field,
+                             const double* wind_uv, const double* noise_uv, double* reward,
+                             uint8_t* terminal, uint8_t* effective_action, int64_t n, int substeps,
+                             int n_threads, const orc_vehicle* veh) {
   int err_all = 0;
+  if (veh == NULL) veh = &ORC_VEHICLE_DEFAULT;
   (void)n_threads;
 #pragma omp parallel for schedule(static) reduction(| : err_all) num_threads(n_threads > 0 ? n_threads : 1)
   for (int64_t i = 0; i < n; ++i) {
@@ -890,9 +903,10 @@ ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* fi
     st->last_command[i] = action[i]; /* balloon.py:286 */
     int eff = action[i];
     int64_t now = st->start_unix[i] + st->time_elapsed_s[i];
-    eff = power_safety(eff, now, 183.7, st->battery_charge[i], 3058.56, &st->sunrise_h[i],
-                       &st->sunset[i], &st->power_paused[i]);
-    eff = envelope_safety(eff, st->superpressure[i], 2380, &st->env_fsm[i]);
+    if (veh->power_safety_layer_enabled) /* balloon.py:305 */
+      eff = power_safety(eff, now, veh->nighttime_power_load_w, st->battery_charge[i], veh->battery_capacity_wh,
+                         &st->sunrise_h[i], &st->sunset[i], &st->power_paused[i]);
+    eff = envelope_safety(eff, st->superpressure[i], veh->envelope_max_superpressure, &st->env_fsm[i]);
     eff = altitude_safety(eff, &atm, st->pressure[i], &st->alt_fsm[i], &err);
     if (effective_action) effective_action[i] = (uint8_t)eff;
 
@@ -905,7 +919,7 @@ ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* fi
     s.t_elapsed = st->time_elapsed_s[i]; s.status = ST_OK;
     for (int k = 0; k < substeps; ++k) { /* balloon.py:321-328 */
       err |= simulate_step_internal(&s, u, v, &atm, eff, lat0, lng0, st->start_unix[i],
-                                    st->upwelling_infrared[i], 10.0);
+                                    st->upwelling_infrared[i], 10.0, veh);
       if (s.status != ST_OK) break;
     }
     st->x[i] = s.x; st->y[i] = s.y; st->pressure[i] = s.p; st->ambient_temperature[i] = s.t_amb;
@@ -914,22 +928,31 @@ ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* fi
     st->acs_power[i] = s.acs_power; st->acs_mass_flow[i] = s.mdot;
     st->solar_charging[i] = s.charge; st->power_load[i] = s.load;
     st->time_elapsed_s[i] = s.t_elapsed; st->status[i] = (uint8_t)s.status;
-    reward[i] = perciatelli_reward(&s, action[i], lat0, lng0, st->start_unix[i], &err);
+    reward[i] = perciatelli_reward(&s, action[i], lat0, lng0, st->start_unix[i], &err, veh);
     terminal[i] = s.status != ST_OK;
     err_all |= err;
   }
   return err_all;
 }
 
+ORC_API int orc_step(const orc_state* st, const uint8_t* action, const float* field,
+                     const double* wind_uv, const double* noise_uv, double* reward,
+                     uint8_t* terminal, uint8_t* effective_action, int64_t n, int substeps,
+                     int n_threads) {
+  return orc_step_vehicle(st, action, field, wind_uv, noise_uv, reward, terminal, effective_action, n, substeps,
+                          n_threads, NULL);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Reset path: stable_init.py:40-157                                          */
 /* ------------------------------------------------------------------------- */
-ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* center_lat_deg,
-                            const double* center_lng_deg, const double* x, const double* y,
-                            const int64_t* unix_s, const double* ir, const double* alpha,
-                            double* t_amb, double* t_int, double* mols_air, double* volume,
-                            double* sp) {
+ORC_API int orc_stable_init_vehicle(int64_t n, const double* pressure, const double* center_lat_deg,
+                                    const double* center_lng_deg, const double* x, const double* y,
+                                    const int64_t* unix_s, const double* ir, const double* alpha,
+                                    double* t_amb, double* t_int, double* mols_air, double* volume,
+                                    double* sp, const orc_vehicle* veh) {
   int err_all = 0;
+  if (veh == NULL) veh = &ORC_VEHICLE_DEFAULT;
 #pragma omp parallel for schedule(static) reduction(| : err_all)
   for (int64_t i = 0; i < n; ++i) {
     int err = 0;
@@ -937,9 +960,9 @@ ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* cen
     orc_atm_init(alpha[i], &atm);
     double h, ta;
     err |= atm_at_pressure(&atm, pressure[i], &h, &ta);
-    double ma = ((pressure[i] * DRY_AIR_MOLAR_MASS * 1804 / (UNIVERSAL_GAS_CONSTANT * ta) - 68.5 -
-                  92.5 - HE_MOLAR_MASS * 6830.0) /
-                 DRY_AIR_MOLAR_MASS);
+    double ma = ((pressure[i] * DRY_AIR_MOLAR_MASS * veh->envelope_volume_base / (UNIVERSAL_GAS_CONSTANT * ta) -
+                  veh->envelope_mass - veh->payload_mass - HE_MOLAR_MASS * veh->mols_lift_gas) /
+                 DRY_AIR_MOLAR_MASS); /* stable_init.py:88-93 */
     if (ma < 0.0) ma = 0.0;
     double ti = 206.0;
     double lat, lng, el, flux;
@@ -947,8 +970,10 @@ ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* cen
     err |= solar_calculator(lat, lng, unix_s[i], &el, NULL, &flux);
     double delta = 0.01;
     for (int k = 0; k < 10; ++k) {
-      double d1 = d_balloon_temperature_dt(1804, 68.5, ti - delta / 2, ta, pressure[i], el, flux, ir[i], &err);
-      double d2 = d_balloon_temperature_dt(1804, 68.5, ti + delta / 2, ta, pressure[i], el, flux, ir[i], &err);
+      double d1 = d_balloon_temperature_dt(veh->envelope_volume_base, veh->envelope_mass, ti - delta / 2, ta,
+                                           pressure[i], el, flux, ir[i], &err);
+      double d2 = d_balloon_temperature_dt(veh->envelope_volume_base, veh->envelope_mass, ti + delta / 2, ta,
+                                           pressure[i], el, flux, ir[i], &err);
       double d2t = (d2 - d1) / delta;
       double mean = (d1 + d2) / 2.0;
       if (fabs(d2t) > 0.0) ti -= (mean / d2t);
@@ -957,10 +982,19 @@ ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* cen
     t_amb[i] = ta;
     t_int[i] = ti;
     mols_air[i] = ma;
-    superpressure_and_volume(6830.0, ma, ti, pressure[i], 1804, 0.0199, &volume[i], &sp[i]);
+    superpressure_and_volume(veh->mols_lift_gas, ma, ti, pressure[i], veh->envelope_volume_base,
+                             veh->envelope_volume_dv_pressure, &volume[i], &sp[i]);
     err_all |= err;
   }
   return err_all;
+}
+ORC_API int orc_stable_init(int64_t n, const double* pressure, const double* center_lat_deg,
+                            const double* center_lng_deg, const double* x, const double* y,
+                            const int64_t* unix_s, const double* ir, const double* alpha,
+                            double* t_amb, double* t_int, double* mols_air, double* volume,
+                            double* sp) {
+  return orc_stable_init_vehicle(n, pressure, center_lat_deg, center_lng_deg, x, y, unix_s, ir, alpha, t_amb, t_int,
+                                 mols_air, volume, sp, NULL);
 }
 
 ORC_API double orc_reward_only(double x, double y, double p, double batt, double acs_power,
@@ -970,7 +1004,7 @@ ORC_API double orc_reward_only(double x, double y, double p, double batt, double
   memset(&s, 0, sizeof s);
   s.x = x; s.y = y; s.p = p; s.batt = batt; s.acs_power = acs_power; s.t_elapsed = elapsed;
   int err = 0;
-  return perciatelli_reward(&s, last_command, radians(lat_deg), radians(lng_deg), start_unix, &err);
+  return perciatelli_reward(&s, last_command, radians(lat_deg), radians(lng_deg), start_unix, &err, &ORC_VEHICLE_DEFAULT);
 }
 
 ORC_API int orc_abi_version(void) { return 1; }

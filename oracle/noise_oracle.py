@@ -29,6 +29,10 @@ U_HARMONICS = ((0.1445, 702.269, 2116.987, 2587.802, 245.0), (0.2766, 1483.570, 
 V_HARMONICS = ((0.2716, 1974.228, 2028.814, 713.697, 26.435), (0.2684, 699.738, 541.845, 632.116, 9.530),
                (0.2348, 217.750, 196.522, 686.825, 3.546), (0.1186, 47.500, 43.048, 66.553, 8.424),
                (0.1066, 3663.291, 232.023, 7499.741, 225.0))
+# The version of simplex4's BIT PATTERN (== include/ble_abi.h::BLE_NOISE_PRIMITIVE_VERSION): bumped with every change of the primitive's
+# values, here and in csrc/ble_noise.h together; tests/golden/f14_wind_noise.npz records the version it was generated with
+# (tests/test_host_api.py holds the four to one number, tests/test_golden_reproducible.py the fixture to its generator).
+PRIMITIVE_VERSION = 2
 SIMPLEX4_VARIANCE = 0.088392          # of simplex4 below == simplex_wind_noise.py:70 SIMPLEX_VARIANCE
 OPENSIMPLEX_VARIANCE = 0.0569         # simplex_wind_noise.py:71: of the reference's (absent) primitive
 NOISE_VARIANCE = 1.02                 # simplex_wind_noise.py:76

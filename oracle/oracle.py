@@ -30,6 +30,30 @@ class _State(ctypes.Structure):
               [(f, ctypes.POINTER(ctypes.c_uint8)) for f in U8_FIELDS])
 
 
+# BalloonState's flight-vehicle constants (reference env/balloon/balloon.py:156-173), mols_lift_gas (:183) and
+# power_safety_layer_enabled (:200): ble_oracle.c::orc_vehicle == include/ble_abi.h::ble_vehicle
+VEHICLE_DEFAULTS = dict(envelope_volume_base=1804.0, envelope_volume_dv_pressure=0.0199, envelope_mass=68.5,
+                        envelope_max_superpressure=2380.0, envelope_cod=0.25, payload_mass=92.5,
+                        nighttime_power_load_w=183.7, daytime_power_load_w=120.4, acs_valve_hole_diameter_m=0.04,
+                        battery_capacity_wh=3058.56, mols_lift_gas=6830.0, power_safety_layer_enabled=1)
+
+
+class _Vehicle(ctypes.Structure):
+  _fields_ = ([(k, ctypes.c_double) for k in list(VEHICLE_DEFAULTS)[:-1]] +
+              [('power_safety_layer_enabled', ctypes.c_int32), ('reserved_', ctypes.c_int32)])
+
+
+def _vehicle(overrides):
+  """None (the defaults) or a dict of the fields that differ -> a pointer argument for the orc_*_vehicle entry points."""
+  if not overrides:
+    return None
+  unknown = set(overrides) - set(VEHICLE_DEFAULTS)
+  assert not unknown, unknown
+  v = dict(VEHICLE_DEFAULTS); v.update(overrides)
+  v['power_safety_layer_enabled'] = int(bool(v['power_safety_layer_enabled']))
+  return ctypes.byref(_Vehicle(reserved_=0, **v))
+
+
 def build(force: bool = False) -> str:
   src = os.path.join(_HERE, 'ble_oracle.c')
   if force or not os.path.exists(_LIB_PATH) or (
@@ -199,14 +223,14 @@ def wind_forecast(field, x_m, y_m, p, elapsed_s):
   return u, v
 
 
-def stable_init(pressure, lat_deg, lng_deg, x, y, unix_s, ir, alpha):
+def stable_init(pressure, lat_deg, lng_deg, x, y, unix_s, ir, alpha, vehicle=None):
   arrs = [_d(np.atleast_1d(a)) for a in (pressure, lat_deg, lng_deg, x, y)]
   t = np.ascontiguousarray(np.atleast_1d(unix_s), np.int64)
   ir, alpha = _d(np.atleast_1d(ir)), _d(np.atleast_1d(alpha))
   n = t.size
   outs = [np.empty(n) for _ in range(5)]
-  err = lib().orc_stable_init(ctypes.c_int64(n), *[_pd(a) for a in arrs], _p(t, ctypes.c_int64),
-                              _pd(ir), _pd(alpha), *[_pd(o) for o in outs])
+  err = lib().orc_stable_init_vehicle(ctypes.c_int64(n), *[_pd(a) for a in arrs], _p(t, ctypes.c_int64),
+                                      _pd(ir), _pd(alpha), *[_pd(o) for o in outs], _vehicle(vehicle))
   return dict(zip(('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume',
                    'superpressure'), outs)), err
 
@@ -242,8 +266,9 @@ def coerce_state(state):
   return out
 
 
-def step(state, action, field=None, wind_uv=None, noise_uv=None, substeps=18, threads=1):
-  """In-place agent step on an oracle state dict. Returns (reward, terminal, effective_action, err)."""
+def step(state, action, field=None, wind_uv=None, noise_uv=None, substeps=18, threads=1, vehicle=None):
+  """In-place agent step on an oracle state dict. Returns (reward, terminal, effective_action, err).
+  vehicle: None or a dict of the BalloonState vehicle fields that differ from the reference's defaults (VEHICLE_DEFAULTS)."""
   n = state['x'].size
   cst = _State()
   for f in FLOAT_FIELDS:
@@ -272,7 +297,7 @@ def step(state, action, field=None, wind_uv=None, noise_uv=None, substeps=18, th
     noise_uv = _d(noise_uv); assert noise_uv.shape == (n, 2)
     nptr = _pd(noise_uv)
   reward = np.empty(n); terminal = np.empty(n, np.uint8); eff = np.empty(n, np.uint8)
-  err = lib().orc_step(ctypes.byref(cst), _p(action, ctypes.c_uint8), fptr, wptr, nptr, _pd(reward),
-                       _p(terminal, ctypes.c_uint8), _p(eff, ctypes.c_uint8), ctypes.c_int64(n),
-                       ctypes.c_int(substeps), ctypes.c_int(threads))
+  err = lib().orc_step_vehicle(ctypes.byref(cst), _p(action, ctypes.c_uint8), fptr, wptr, nptr, _pd(reward),
+                               _p(terminal, ctypes.c_uint8), _p(eff, ctypes.c_uint8), ctypes.c_int64(n),
+                               ctypes.c_int(substeps), ctypes.c_int(threads), _vehicle(vehicle))
   return reward, terminal, eff, err

@@ -21,7 +21,7 @@ field = (np.random.default_rng(0).standard_normal(vec_state.GRID_SHAPE) * 5.0).a
 init = reset_host.sample_initial_state(n, seed=77)
 init['battery_charge'][: n // 16] = np.linspace(1.0, 400.0, n // 16).astype(np.float32)      # a steady trickle of episodes ending
 sims = {}
-for mode in ('0', '4', '2'):
+for mode in ('0', '4') + (('2',) if os.environ.get('BLE_WITH_PAIR_FORM') else ()):      # '2': experiment builds only (-DBLE_WITH_PAIR_FORM)
   s = vec_state.VecSimulator(n); s.set_grid(field); s.set_state(init)
   sims[mode] = s
 gen = torch.Generator(device='cuda'); gen.manual_seed(3)
@@ -43,7 +43,7 @@ for t in range(steps):
   if (t + 1) % check_every == 0:
     torch.cuda.synchronize()
     ref = sims['0'].get_state()
-    for mode in ('4', '2'):
+    for mode in ('4',) + (('2',) if os.environ.get('BLE_WITH_PAIR_FORM') else ()):
       got = sims[mode].get_state()
       for name in ref:
         assert np.array_equal(ref[name], got[name]), (t, mode, name, int((ref[name] != got[name]).sum()))

@@ -47,8 +47,11 @@ UNIX_2011 = int(units.datetime(2011, 1, 1).timestamp())
 UNIX_2015 = int(units.datetime(2015, 1, 3).timestamp())
 
 
+OUT_DIR = os.environ.get('BLE_GOLDEN_OUT') or HERE   # tests/test_golden_reproducible.py regenerates into a scratch directory
+
+
 def save(name, **arrays):
-  path = os.path.join(HERE, name + '.npz')
+  path = os.path.join(OUT_DIR, name + '.npz')
   np.savez_compressed(path, **arrays)
   print(f'{name}: {os.path.getsize(path)} bytes')
 
@@ -603,6 +606,7 @@ def f14_wind_noise(n_points=192):
   reference's own reset() put into its harmonics, and get_wind_noise / get_ground_truth at seeded points.  Pins the
   harmonic tables, spacings, offsets, NOISE_MAGNITUDE and the variance adjustment; the primitive stays unpinned."""
   from balloon_learning_environment.env import simplex_wind_noise
+  import noise_oracle                    # (the stand-in primitive's home: its version goes into the fixture)
   rng = np.random.default_rng(14)
   episodes = 3
   x = rng.uniform(-4e5, 4e5, (episodes, n_points)); y = rng.uniform(-4e5, 4e5, (episodes, n_points))
@@ -628,7 +632,7 @@ def f14_wind_noise(n_points=192):
   assert seeds.max() < 1634753849 and np.abs(offsets).max() <= 1.0
   save('f14_wind_noise', x=x, y=y, pressure=p, elapsed_s=t.astype(np.int64), seeds=seeds, offsets=offsets, noise=noise,
        ground_truth=truth, forecast=forecast, field_seed=np.int64(0), field_scale=np.float64(5.0),
-       noise_magnitude=np.float64(simplex_wind_noise.NOISE_MAGNITUDE))
+       noise_magnitude=np.float64(simplex_wind_noise.NOISE_MAGNITUDE), noise_primitive_version=np.int64(noise_oracle.PRIMITIVE_VERSION))
 
 
 # ----------------------------------------------------------------------------- F15
@@ -663,6 +667,117 @@ def f15_decoder(n_samples=2):
   save('f15_decoder', param_seed=np.int64(15), latents=latents, flow=flow, fields=fields.astype(np.float32))
 
 
+# ----------------------------------------------------------------------------- F16
+# BalloonState's flight-vehicle constants are dataclass FIELDS (balloon.py:156-173,183) and power_safety_layer_enabled a
+# per-state switch (:200,305): vehicles other than the default one, flown by the reference's own Balloon.simulate_step.
+F16_VEHICLE_FIELDS = ('envelope_volume_base', 'envelope_volume_dv_pressure', 'envelope_mass', 'envelope_max_superpressure',
+                      'envelope_cod', 'payload_mass', 'nighttime_power_load_w', 'daytime_power_load_w',
+                      'acs_valve_hole_diameter_m', 'battery_capacity_wh', 'mols_lift_gas', 'power_safety_layer_enabled')
+F16_VEHICLES = (
+    # a larger envelope with more lift gas and a weaker skin
+    dict(envelope_volume_base=2100.0, envelope_volume_dv_pressure=0.025, envelope_mass=75.0, envelope_max_superpressure=2000.0,
+         payload_mass=100.0, mols_lift_gas=7800.0),
+    # a smaller, draggier one with a stronger skin
+    dict(envelope_volume_base=1500.0, envelope_volume_dv_pressure=0.015, envelope_mass=60.0, envelope_max_superpressure=2600.0,
+         envelope_cod=0.3, payload_mass=80.0, mols_lift_gas=5700.0),
+    # the default envelope with another power system and a wider valve
+    dict(nighttime_power_load_w=250.0, daytime_power_load_w=150.0, battery_capacity_wh=2000.0, acs_valve_hole_diameter_m=0.05),
+    # the default vehicle with the power safety layer switched off
+    dict(power_safety_layer_enabled=0),
+    # everything at once
+    dict(envelope_volume_base=1950.0, envelope_volume_dv_pressure=0.0215, envelope_mass=71.25, envelope_max_superpressure=2200.0,
+         envelope_cod=0.22, payload_mass=88.0, nighttime_power_load_w=160.5, daytime_power_load_w=131.0,
+         acs_valve_hole_diameter_m=0.035, battery_capacity_wh=3500.0, mols_lift_gas=7300.0, power_safety_layer_enabled=0),
+)
+
+
+def f16_vehicle_kwargs(v):
+  """A dict of F16_VEHICLE_FIELDS -> the keyword arguments of the reference's BalloonState."""
+  kw = {}
+  for k, val in v.items():
+    if k == 'nighttime_power_load_w':
+      kw['nighttime_power_load'] = units.Power(watts=val)
+    elif k == 'daytime_power_load_w':
+      kw['daytime_power_load'] = units.Power(watts=val)
+    elif k == 'acs_valve_hole_diameter_m':
+      kw['acs_valve_hole_diameter'] = units.Distance(m=val)
+    elif k == 'battery_capacity_wh':
+      kw['battery_capacity'] = units.Energy(watt_hours=val)
+    elif k == 'power_safety_layer_enabled':
+      kw[k] = bool(val)
+    else:
+      kw[k] = val
+  return kw
+
+
+def f16_vehicles(n_steps=40):
+  rng = np.random.default_rng(16)
+  defaults = balloon.BalloonState(center_latlng=s2.LatLng.from_degrees(0.0, 0.0), date_time=units.datetime(2013, 3, 25, 9))
+  default_row = [defaults.envelope_volume_base, defaults.envelope_volume_dv_pressure, defaults.envelope_mass,
+                 defaults.envelope_max_superpressure, defaults.envelope_cod, defaults.payload_mass,
+                 defaults.nighttime_power_load.watts, defaults.daytime_power_load.watts, defaults.acs_valve_hole_diameter.meters,
+                 defaults.battery_capacity.watt_hours, defaults.mols_lift_gas, float(defaults.power_safety_layer_enabled)]
+  vehicles = np.tile(np.array(default_row, np.float64), (len(F16_VEHICLES), 1))
+  for i, v in enumerate(F16_VEHICLES):
+    for k, val in v.items():
+      vehicles[i, F16_VEHICLE_FIELDS.index(k)] = val
+  day, night = units.datetime(2013, 3, 25, 9, 25, 32), units.datetime(2011, 7, 1, 22, 0, 5)
+  dusk = units.datetime(2013, 9, 21, 17, 45, 0)
+  scen = []
+  for vi in range(len(F16_VEHICLES)):
+    cap = vehicles[vi, F16_VEHICLE_FIELDS.index('battery_capacity_wh')]
+    for start, script, batt in ((day, 'down', None), (night, 'cycle', None), (dusk, 'random', None), (day, 'up', None),
+                                (night, 'down', 0.035 * cap), (night, 'down', 0.004 * cap), (day, 'down', 0.995 * cap)):
+      scen.append(dict(vehicle=vi, lat=float(rng.uniform(-10, 10)), lng=float(rng.uniform(-175, 175)), start=start,
+                       pressure=float(rng.uniform(7000, 10500)), x=float(rng.uniform(-1.5e5, 1.5e5)),
+                       y=float(rng.uniform(-1.5e5, 1.5e5)), ir=float(rng.uniform(230, 320)), alpha=float(rng.uniform(0, 1)),
+                       script=script, batt=batt))
+  ns = len(scen)
+  cols = {k: np.zeros((ns, n_steps + 1)) for k in STATE_FLOATS}
+  for k in ('time_elapsed_s', 'sunrise_h', 'sunset'):
+    cols[k] = np.zeros((ns, n_steps + 1), np.int64)
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused'):
+    cols[k] = np.zeros((ns, n_steps + 1), np.uint8)
+  actions = np.zeros((ns, n_steps), np.uint8); wind = np.zeros((ns, n_steps, 2)); reward = np.zeros((ns, n_steps))
+  valid = np.zeros((ns, n_steps), np.uint8)
+  consts = {k: np.zeros(ns) for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha')}
+  start_unix = np.zeros(ns, np.int64); vehicle_index = np.zeros(ns, np.int64)
+  cold = {k: np.zeros(ns) for k in ('ambient_temperature', 'internal_temperature', 'mols_air', 'envelope_volume', 'superpressure')}
+  for j, s in enumerate(scen):
+    atm = ref_shims.make_atmosphere(s['alpha'])
+    st = balloon.BalloonState(center_latlng=s2.LatLng.from_degrees(s['lat'], s['lng']), date_time=s['start'],
+                              x=units.Distance(m=s['x']), y=units.Distance(m=s['y']), pressure=s['pressure'],
+                              upwelling_infrared=s['ir'], **f16_vehicle_kwargs(F16_VEHICLES[s['vehicle']]))
+    stable_init.cold_start_to_stable_params(st, atm)                   # (the vehicle's own cold start: stable_init.py:132-157)
+    for k in cold:
+      cold[k][j] = getattr(st, k)
+    assert 0.0 < st.superpressure < st.envelope_max_superpressure, (j, st.superpressure)
+    if s['batt'] is not None:
+      st.battery_charge = units.Energy(watt_hours=s['batt'])
+    b = balloon.Balloon(st)
+    su = int(s['start'].timestamp()); start_unix[j] = su; vehicle_index[j] = s['vehicle']
+    consts['center_lat_deg'][j] = s['lat']; consts['center_lng_deg'][j] = s['lng']
+    consts['upwelling_infrared'][j] = s['ir']; consts['alpha'][j] = s['alpha']
+    snap = snapshot(b.state, su)
+    for k in SNAP_KEYS:
+      cols[k][j, 0] = snap[k]
+    for i in range(n_steps):
+      a = action_for(s['script'], i, rng); actions[j, i] = a
+      u, v = rng.normal(0, 8.0, 2); wind[j, i] = (u, v)
+      if b.state.status == balloon.BalloonStatus.OK:
+        valid[j, i] = 1
+        b.simulate_step(wind_field.WindVector(units.Velocity(mps=float(u)), units.Velocity(mps=float(v))), atm,
+                        control.AltitudeControlCommand(a), dt.timedelta(minutes=3))
+        reward[j, i] = balloon_env.perciatelli_reward_function(simulator_data.SimulatorState(b.state, None, atm))
+      snap = snapshot(b.state, su)
+      for k in SNAP_KEYS:
+        cols[k][j, i + 1] = snap[k]
+  print(f'f16: {ns} trajectories over {len(F16_VEHICLES)} vehicles, {int(valid.sum())} reference steps, final status counts '
+        f'{np.bincount(cols["status"][:, -1], minlength=4).tolist()}, paused at some step: {int((cols["power_paused"].max(axis=1) > 0).sum())}')
+  save('f16_vehicles', vehicles=vehicles, vehicle_fields=np.array(F16_VEHICLE_FIELDS), vehicle_index=vehicle_index, actions=actions,
+       wind_uv=wind, reward=reward, valid=valid, start_unix=start_unix, **{'cold_' + k: v for k, v in cold.items()}, **consts, **cols)
+
+
 if __name__ == '__main__':
   which = sys.argv[1:] or ['all']
   if 'all' in which:
@@ -674,3 +789,5 @@ if __name__ == '__main__':
     f14_wind_noise()
   if 'all' in which or 'f15' in which:
     f15_decoder()
+  if 'all' in which or 'f16' in which:
+    f16_vehicles()

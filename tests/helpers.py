@@ -136,3 +136,16 @@ def noise_cache_from_draws(seeds, offsets, n, seed, episode=0):
       c[5 * k + 1:5 * k + 5] = np.asarray(offsets[comp][h], np.float32).view(np.uint32)[:, None]
   c[50] = np.uint32(episode + 1); c[51] = np.uint32(seed & 0xFFFFFFFF); c[52] = np.uint32((seed >> 32) & 0xFFFFFFFF)
   return c
+
+
+def fixture_vehicle(d, vi):
+  """Vehicle `vi` of the F16 fixture as a dict of the fields that DIFFER from the reference's defaults (the keyword form of
+  oracle.step(vehicle=...) and VecSimulator.set_vehicle(...)); {} for the default vehicle."""
+  import oracle
+  names = [str(k) for k in d['vehicle_fields']]
+  out = {}
+  for k, v in zip(names, d['vehicles'][vi]):
+    v = int(v) if k == 'power_safety_layer_enabled' else float(v)
+    if v != oracle.VEHICLE_DEFAULTS[k]:
+      out[k] = v
+  return out

@@ -33,10 +33,51 @@ def test_state_struct_matches_header_order():
   header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
   body = header[header.index('typedef struct ble_state_f32 {'):header.index('} ble_state_f32;')]
   names = re.findall(r'\*\s*(\w+);', body)
-  assert tuple(names) == _abi.FIELD_NAMES + ('episode_cache',)        # the per-env arrays, then the optional cache
+  assert tuple(names) == _abi.FIELD_NAMES + ('episode_cache', 'vehicle')        # the per-env arrays, the optional cache, the optional vehicle (ABI 5)
   assert [f[0] for f in _abi.BleStateF32._fields_] == names
   assert ctypes.sizeof(_abi.BleStateF32) == 8 * len(names)
   assert int(re.search(r'#define BLE_EPISODE_CACHE_ROWS (\d+)', header).group(1)) == _abi.EPISODE_CACHE_ROWS
+
+
+def test_vehicle_struct_matches_header_and_reference_defaults():
+  """struct ble_vehicle (ABI 5) field for field; its defaults are the reference's BalloonState defaults (balloon.py:156-173,183,200 --
+  tests/golden/f16_vehicles.npz records them from the reference's own dataclass), what ble_vehicle_default() writes and what the oracle
+  uses."""
+  header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
+  body = header[header.index('typedef struct ble_vehicle {'):header.index('} ble_vehicle;')]
+  names = re.findall(r'(?:double|int32_t)\s+(\w+);', body)
+  assert names == [f[0] for f in _abi.BleVehicle._fields_]
+  assert ctypes.sizeof(_abi.BleVehicle) == 8 * 11 + 8
+  assert _abi.VEHICLE_DEFAULTS == oracle.VEHICLE_DEFAULTS and tuple(_abi.VEHICLE_DEFAULTS) == _abi.VEHICLE_FIELDS
+  lib = ctypes.CDLL(_lib.build())          # a host function: callable without a GPU
+  v = _abi.BleVehicle()
+  lib.ble_vehicle_default.argtypes = [ctypes.POINTER(_abi.BleVehicle)]
+  assert lib.ble_vehicle_default(ctypes.byref(v)) == 0
+  assert {k: getattr(v, k) for k in _abi.VEHICLE_DEFAULTS} == _abi.VEHICLE_DEFAULTS
+  import helpers
+  d = helpers.golden('f16_vehicles')
+  assert tuple(str(k) for k in d['vehicle_fields']) == _abi.VEHICLE_FIELDS
+  for vi in range(len(d['vehicles'])):          # every field F16 does not vary holds the reference's default
+    row = dict(zip(_abi.VEHICLE_FIELDS, d['vehicles'][vi]))
+    changed = helpers.fixture_vehicle(d, vi)
+    assert all(row[k] == _abi.VEHICLE_DEFAULTS[k] for k in row if k not in changed)
+  assert set().union(*(helpers.fixture_vehicle(d, vi) for vi in range(len(d['vehicles'])))) == set(_abi.VEHICLE_FIELDS)      # ... and F16 varies them all
+  assert _abi.vehicle_struct() is None and _abi.vehicle_struct(envelope_mass=68.5) is None
+  assert _abi.vehicle_struct(envelope_mass=70.0).envelope_mass == 70.0
+  with pytest.raises(TypeError):
+    _abi.vehicle_struct(mass=1.0)
+
+
+def test_noise_primitive_version_is_one_number_everywhere():
+  """The wind-noise primitive is this repository's own: the library, the header, the Python mirror, the oracle and the committed
+  fixture F14 carry ONE version of its bit pattern (include/ble_abi.h::BLE_NOISE_PRIMITIVE_VERSION)."""
+  import helpers
+  import noise_oracle
+  header = open(os.path.join(ROOT, 'include', 'ble_abi.h')).read()
+  v = int(re.search(r'#define BLE_NOISE_PRIMITIVE_VERSION (\d+)', header).group(1))
+  lib = ctypes.CDLL(_lib.build())
+  assert v == _lib.NOISE_PRIMITIVE_VERSION == noise_oracle.PRIMITIVE_VERSION == lib.ble_noise_primitive_version()
+  assert int(helpers.golden('f14_wind_noise')['noise_primitive_version']) == v
 
 
 def test_gp_history_struct_matches_header_order():
@@ -45,7 +86,7 @@ def test_gp_history_struct_matches_header_order():
   names = re.findall(r'(?:\*|int64_t)\s*(\w+);', body)       # the pointer members, then the int64 slab stride (ABI 2)
   assert names == [f[0] for f in _abi.BleGpHistoryF32._fields_] and names[-1] == 'chol_stride'
   assert ctypes.sizeof(_abi.BleGpHistoryF32) == 8 * len(names)
-  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 4
+  assert int(re.search(r'#define BLE_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == 5
   assert int(re.search(r'#define BLE_OBS_DIM (\d+)', header).group(1)) == _lib.OBS_DIM
   assert int(re.search(r'#define BLE_GP_CAPACITY (\d+)', header).group(1)) == _lib.GP_CAPACITY
   assert int(re.search(r'#define BLE_GP_CHOL_STRIDE (\d+)', header).group(1)) == _lib.GP_CHOL_STRIDE

@@ -289,6 +289,50 @@ def test_f8_free_running_trajectories():
     np.testing.assert_allclose(reward[live], d['reward'][live, s], rtol=1e-9)
 
 
+def test_f16_non_default_vehicles_teacher_forced():
+  """F16: the reference's Balloon.simulate_step on BalloonStates whose flight-vehicle constants (balloon.py:156-173,183) differ
+  from the defaults, two of them with power_safety_layer_enabled=False (:200,305), each after ITS OWN cold start
+  (stable_init.py:132-157) -- the oracle with the same vehicle struct."""
+  d = golden('f16_vehicles')
+  assert len(d['vehicles']) >= 3 and d['actions'].shape[1] >= 40
+  n, steps = d['actions'].shape
+  worst = 0.0
+  for vi in range(len(d['vehicles'])):
+    veh = helpers.fixture_vehicle(d, vi)
+    assert veh, 'every F16 vehicle differs from the default one'
+    mine = np.nonzero(d['vehicle_index'] == vi)[0]
+    # the vehicle's own cold start
+    out, err = oracle.stable_init(d['pressure'][mine, 0], d['center_lat_deg'][mine], d['center_lng_deg'][mine], d['x'][mine, 0], d['y'][mine, 0],
+                                  d['start_unix'][mine], d['upwelling_infrared'][mine], d['alpha'][mine], vehicle=veh)
+    assert err == 0
+    for k, v in out.items():
+      np.testing.assert_allclose(v, d['cold_' + k][mine], rtol=1e-9, atol=1e-9, err_msg=f'vehicle {vi} cold start {k}')
+    for s in range(steps):
+      rows = mine[d['valid'][mine, s] == 1]
+      if rows.size == 0:
+        continue
+      st = traj_state_at(d, s, rows)
+      reward, terminal, _, err = oracle.step(st, d['actions'][rows, s], wind_uv=d['wind_uv'][rows, s], vehicle=veh)
+      assert err == 0
+      for k in STATE_FLOATS:
+        ref = d[k][rows, s + 1]
+        worst = max(worst, (np.abs(st[k] - ref) / np.maximum(np.abs(ref), 1.0)).max())
+        np.testing.assert_allclose(st[k], ref, rtol=2e-9, atol=2e-9, err_msg=f'vehicle {vi} {k} step {s}')
+      for k in STATE_INTS + STATE_U8:
+        np.testing.assert_array_equal(st[k], d[k][rows, s + 1], err_msg=f'vehicle {vi} {k} step {s}')
+      np.testing.assert_allclose(reward, d['reward'][rows, s], rtol=1e-12, atol=1e-15)
+      np.testing.assert_array_equal(terminal, d['status'][rows, s + 1] != 0)
+  assert worst < 2e-9
+  # the switch matters in the fixture: with the layer off nobody is ever paused, with it on somebody is; an episode ends out of power
+  off = np.isin(d['vehicle_index'], [vi for vi in range(len(d['vehicles'])) if not helpers.fixture_vehicle(d, vi).get('power_safety_layer_enabled', 1)])
+  assert off.any() and d['power_paused'][off].max() == 0 and d['power_paused'][~off].max() == 1 and (d['status'][off, -1] == 1).any()
+  # ... and so do the constants: flown as the DEFAULT vehicle the same states go elsewhere
+  rows = np.nonzero(d['valid'][:, 0])[0]
+  st = traj_state_at(d, 0, rows)
+  oracle.step(st, d['actions'][rows, 0], wind_uv=d['wind_uv'][rows, 0])
+  assert np.abs(st['pressure'] - d['pressure'][rows, 1]).max() > 1.0
+
+
 def test_f9_arena_step_with_grid_wind_field():
   d = golden('f9_arena')
   assert _check_traj(d, use_field=True) < 2e-9
