@@ -28,12 +28,13 @@ BLE_OK = 0
 FLAG_PRESSURE_RANGE, FLAG_ABSORPTIVITY, FLAG_SOLAR_RANGE, FLAG_POWER_TABLE, FLAG_NONFINITE = 1, 2, 4, 16, 32
 FLAG_GP_WINDOW, FLAG_PRESSURE_SEARCH, FLAG_DAY_CYCLE = 64, 128, 256
 OBS_DIM, GP_CAPACITY, GP_CHOL_STRIDE = 1099, 128, 7620
+ROW_DOUBLES = 26        # BLE_ROW_DOUBLES
 NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
-EXPORTS = ('ble_abi_version', 'ble_noise_primitive_version', 'ble_vehicle_default', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
-           'ble_forecast_column_f32', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
-           'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
+EXPORTS = ('ble_abi_version', 'ble_noise_primitive_version', 'ble_vehicle_default', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_observe_forecast_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
+           'ble_forecast_column_f32', 'ble_state_rows_f64', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
+           'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_thermal_vehicle_f32', 'ble_probe_sp_volume_vehicle_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
            'ble_probe_f64_prims')
 
 
@@ -94,18 +95,22 @@ def lib():
   l.ble_reset_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _vp]
   l.ble_reset_at_f32.argtypes = [st, _vp, ctypes.c_uint64, _vp, _int, _vp, _i64, _i64, _vp]
   l.ble_observe_f32.argtypes = [st, _vp, _i64, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
+  l.ble_observe_forecast_f32.argtypes = [st, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(_abi.BleGpHistoryF32), _int, _vp, _vp, _i64, _vp]
   l.ble_decode_flow_fields_f32.argtypes = [_vp, _vp, _i64, _vp]
   l.ble_wind_noise_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _vp, _i64, _vp]
   l.ble_wind_noise_at_f32.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _int, _vp, _vp, _i64, _i64, _vp]
   l.ble_forecast_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_forecast_column_f32.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_state_rows_f64.argtypes = [st, _i64, _i64, _vp, _i64, _vp]
   l.ble_probe_atmosphere_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_latlng_f64.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_power_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_thermal_f32.argtypes = [_vp] * 9 + [_i64, _vp]
   l.ble_probe_sp_volume_f32.argtypes = [_vp] * 5 + [_i64, _vp]
+  l.ble_probe_thermal_vehicle_f32.argtypes = [ctypes.POINTER(_abi.BleVehicle)] + [_vp] * 9 + [_i64, _vp]
+  l.ble_probe_sp_volume_vehicle_f32.argtypes = [ctypes.POINTER(_abi.BleVehicle)] + [_vp] * 5 + [_i64, _vp]
   l.ble_probe_acs_f32.argtypes = [_vp] * 4 + [_i64, _vp]
   l.ble_probe_safety_f32.argtypes = [_int, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_f64_prims.argtypes = [_vp, _vp, _int, _i64, _vp]

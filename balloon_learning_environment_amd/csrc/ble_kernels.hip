@@ -291,6 +291,21 @@ __global__ __launch_bounds__(kBlock) void ble_forecast_column_kernel(
   }
 }
 
+// ble_state_rows_f64: struct of arrays -> records of BLE_ROW_DOUBLES doubles, the struct's member order
+__global__ __launch_bounds__(64) void ble_state_rows_kernel(StateDev st, int64_t first, int64_t count, double* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= count) return;
+  const int64_t i = first + r;
+  double* o = out + r * BLE_ROW_DOUBLES;
+  o[0] = st.x[i]; o[1] = st.y[i]; o[2] = st.pressure[i]; o[3] = st.ambient_temperature[i]; o[4] = st.internal_temperature[i];
+  o[5] = st.envelope_volume[i]; o[6] = st.superpressure[i]; o[7] = st.mols_air[i]; o[8] = st.battery_charge[i];
+  o[9] = st.acs_power[i]; o[10] = st.acs_mass_flow[i]; o[11] = st.solar_charging[i]; o[12] = st.power_load[i];
+  o[13] = st.center_lat_deg[i]; o[14] = st.center_lng_deg[i]; o[15] = st.upwelling_infrared[i]; o[16] = st.alpha[i];
+  o[17] = (double)st.start_unix[i]; o[18] = (double)st.time_elapsed_s[i]; o[19] = (double)st.sunrise_h_rel[i]; o[20] = (double)st.sunset_rel[i];
+  o[21] = (double)st.status[i]; o[22] = (double)st.last_command[i]; o[23] = (double)st.alt_fsm[i]; o[24] = (double)st.env_fsm[i];
+  o[25] = (double)st.power_paused[i];
+}
+
 __global__ __launch_bounds__(256) void ble_power_table_kernel(const float* __restrict__ pr,
                                                               const float* __restrict__ soc, float* __restrict__ watts,
                                                               uint32_t* err_flags, int64_t n) {
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256) void probe_solar_power_kernel(const float* el_
 __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume, const float* t_int, const float* t_amb,
                                                             const float* pressure, const float* el_deg,
                                                             const float* flux, const float* ir, float* dtdt,
-                                                            uint32_t* err_flags, int64_t n) {
+                                                            uint32_t* err_flags, int64_t n, double thermal_scale) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   uint32_t flags = 0;
   if (i < n) {
@@ -375,17 +390,18 @@ __global__ __launch_bounds__(256) void probe_thermal_kernel(const float* volume,
     flags |= (t_int[i] < 12.3f) ? kFlagAbsorptivity : 0u;
     dtdt[i] = (float)(0.1 * thermal_increment_f64(vol, yc, (double)t_int[i], (double)t_amb[i], (double)pressure[i],
                                                   (double)((flux[i] * att) * (0.25f * kSolarAbsorptivityTotal)),
-                                                  earth_heat_per_area_f64((double)ir[i], &flags)));
+                                                  earth_heat_per_area_f64((double)ir[i], &flags), stride_k_literal(), thermal_scale));
   }
   report_flags(flags, err_flags);
 }
 __global__ __launch_bounds__(256) void probe_sp_volume_kernel(const float* mols_air, const float* t_int,
                                                               const float* pressure, float* volume, float* sp,
-                                                              int64_t n) {
+                                                              int64_t n, double lift, double v0, double dvdp) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double v, s;
-  superpressure_volume_f64((double)mols_air[i], (double)t_int[i], (double)pressure[i], d_rcp((double)pressure[i]), &v, &s);
+  superpressure_volume_f64((double)mols_air[i], (double)t_int[i], (double)pressure[i], d_rcp((double)pressure[i]), &v, &s,
+                           stride_k_literal(VehicleDefault::dry_mass, lift, v0), dvdp, 4.0 * dvdp, 1.0 / dvdp);
   volume[i] = (float)v; sp[i] = (float)s;
 }
 __global__ __launch_bounds__(256) void probe_acs_kernel(const float* pr, float* power, float* eff, float* mdot,
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(256) void probe_safety_kernel(int layer, const uint
       atm_at_pressure_f64(w, (double)alpha[i], p, &h, &t);
       eff = altitude_safety(action[i], h, &state);
     } else if (layer == 1) {                        // value = superpressure
-      eff = envelope_safety(action[i], value[i], &state);
+      eff = envelope_safety(action[i], value[i], &state, alpha != nullptr ? (double)alpha[i] : VehicleDefault::max_sp);     // (ABI 5: `alpha` = the layer's maximum superpressure)
     } else {                                        // value = battery charge; clocks (now, sunrise + 1/2 h, sunset)
       int32_t sr = clocks[3 * i + 1], ss = clocks[3 * i + 2];
       eff = power_safety(action[i], clocks[3 * i], value[i], &sr, &ss, &state, night_load_w, capacity_wh);
@@ -730,6 +746,9 @@ inline VehicleRt make_vehicle_rt(const ble_vehicle* v) {
   r.night_load_d = v->nighttime_power_load_w; r.capacity_d = v->battery_capacity_wh; r.day_load_d = v->daytime_power_load_w;
   r.day_load = (float)r.day_load_d; r.night_load = (float)r.night_load_d; r.capacity = (float)r.capacity_d;
   r.power_layer = v->power_safety_layer_enabled != 0;
+  r.inv_capacity = 1.0 / r.capacity_d;
+  r.ceiling_target = (r.payload_mass + r.envelope_mass + r.lift * kHeMolarMassD) * kGasConstantD / (kAirMolarMassD * r.v0);
+  r.sp_hi = r.max_sp - 250.0;
   return r;
 }
 
@@ -851,9 +870,9 @@ int ble_forecast_column_f32(const float* wind_grid, int64_t grid_env_stride, con
   return launch_status();
 }
 
-int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride, const float* noise_uv,
-                    const uint8_t* reset_mask, const ble_gp_history_f32* hist, int append, float* obs,
-                    uint32_t* err_flags, int64_t n, void* stream) {
+int ble_observe_forecast_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride, const float* forecast_levels,
+                             const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist, int append, float* obs,
+                             uint32_t* err_flags, int64_t n, void* stream) {
   if (!state_ok(st) || !wind_grid || !hist || !hist->xyp || !hist->elapsed_s || !hist->err_uv || !hist->count || !obs ||
       n < 0 || grid_env_stride < 0)
     return BLE_E_INVALID_ARG;
@@ -864,9 +883,21 @@ int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t gri
   // a slab shorter than the kernel's layout would be overrun (and overlap the next environment's)
   if (h.chol != nullptr && (h.n_chol == nullptr || h.chol_stride < (int64_t)kCholStride || (h.chol_stride & 1) != 0))
     return BLE_E_INVALID_ARG;
-  BLE_LAUNCH(ble_observe_kernel, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, state_dev(st), wind_grid,
-             grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n);
+  if (st->vehicle != nullptr) {
+    if (!vehicle_ok(st->vehicle)) return BLE_E_INVALID_ARG;
+    BLE_LAUNCH(ble_observe_kernel<VehicleRt>, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, state_dev(st), wind_grid,
+               grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n, make_vehicle_rt(st->vehicle), forecast_levels);
+  } else {
+    BLE_LAUNCH(ble_observe_kernel<VehicleDefault>, dim3((unsigned)n), dim3(kObsBlock), 0, (hipStream_t)stream, state_dev(st), wind_grid,
+               grid_env_stride, noise_uv, reset_mask, h, append, obs, err_flags, n, VehicleDefault{}, forecast_levels);
+  }
   return launch_status();
+}
+
+int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride, const float* noise_uv,
+                    const uint8_t* reset_mask, const ble_gp_history_f32* hist, int append, float* obs,
+                    uint32_t* err_flags, int64_t n, void* stream) {
+  return ble_observe_forecast_f32(st, wind_grid, grid_env_stride, nullptr, noise_uv, reset_mask, hist, append, obs, err_flags, n, stream);
 }
 
 int ble_decode_flow_fields_f32(const float* flow, float* wind_grid, int64_t n, void* stream) {
@@ -890,6 +921,13 @@ int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure
                        unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
                        float* noise_uv, int64_t n, void* stream) {
   return ble_wind_noise_at_f32(x_m, y_m, pressure, elapsed_s, seed, episode, mode, harmonic_cache, noise_uv, 0, n, stream);
+}
+
+int ble_state_rows_f64(const ble_state_f32* st, int64_t first, int64_t count, double* out, int64_t n, void* stream) {
+  if (!state_ok(st) || !out || first < 0 || count < 0 || n < 0 || first + count > n) return BLE_E_INVALID_ARG;
+  if (count == 0) return BLE_OK;
+  BLE_LAUNCH(ble_state_rows_kernel, dim3(blocks(count, 64)), dim3(64), 0, (hipStream_t)stream, state_dev(st), first, count, out);
+  return launch_status();
 }
 
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts, uint32_t* err_flags,
@@ -938,24 +976,36 @@ int ble_probe_solar_power_f32(const float* el_deg, const float* pressure, float*
   return launch_status();
 }
 
-int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* t_amb, const float* pressure,
-                          const float* el_deg, const float* flux, const float* upwelling_ir, float* dtdt,
-                          uint32_t* err_flags, int64_t n, void* stream) {
-  if (!volume || !t_int || !t_amb || !pressure || !el_deg || !flux || !upwelling_ir || !dtdt || n < 0)
+int ble_probe_thermal_vehicle_f32(const ble_vehicle* vehicle, const float* volume, const float* t_int, const float* t_amb, const float* pressure,
+                                  const float* el_deg, const float* flux, const float* upwelling_ir, float* dtdt,
+                                  uint32_t* err_flags, int64_t n, void* stream) {
+  if (!volume || !t_int || !t_amb || !pressure || !el_deg || !flux || !upwelling_ir || !dtdt || n < 0 || (vehicle != nullptr && !vehicle_ok(vehicle)))
     return BLE_E_INVALID_ARG;
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(probe_thermal_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, volume, t_int,
-                     t_amb, pressure, el_deg, flux, upwelling_ir, dtdt, err_flags, n);
+                     t_amb, pressure, el_deg, flux, upwelling_ir, dtdt, err_flags, n,
+                     vehicle != nullptr ? make_vehicle_rt(vehicle).thermal_scale : VehicleDefault::thermal_scale);
   return launch_status();
 }
+int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* t_amb, const float* pressure,
+                          const float* el_deg, const float* flux, const float* upwelling_ir, float* dtdt,
+                          uint32_t* err_flags, int64_t n, void* stream) {
+  return ble_probe_thermal_vehicle_f32(nullptr, volume, t_int, t_amb, pressure, el_deg, flux, upwelling_ir, dtdt, err_flags, n, stream);
+}
 
+int ble_probe_sp_volume_vehicle_f32(const ble_vehicle* vehicle, const float* mols_air, const float* t_int, const float* pressure, float* volume,
+                                    float* superpressure, int64_t n, void* stream) {
+  if (!mols_air || !t_int || !pressure || !volume || !superpressure || n < 0 || (vehicle != nullptr && !vehicle_ok(vehicle))) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  const double lift = vehicle ? vehicle->mols_lift_gas : VehicleDefault::lift, v0 = vehicle ? vehicle->envelope_volume_base : VehicleDefault::v0;
+  const double dvdp = vehicle ? vehicle->envelope_volume_dv_pressure : VehicleDefault::dvdp;
+  BLE_LAUNCH(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
+                     pressure, volume, superpressure, n, lift, v0, dvdp);
+  return launch_status();
+}
 int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const float* pressure, float* volume,
                             float* superpressure, int64_t n, void* stream) {
-  if (!mols_air || !t_int || !pressure || !volume || !superpressure || n < 0) return BLE_E_INVALID_ARG;
-  if (n == 0) return BLE_OK;
-  BLE_LAUNCH(probe_sp_volume_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mols_air, t_int,
-                     pressure, volume, superpressure, n);
-  return launch_status();
+  return ble_probe_sp_volume_vehicle_f32(nullptr, mols_air, t_int, pressure, volume, superpressure, n, stream);
 }
 
 int ble_reset_at_f32(const ble_state_f32* st, const uint8_t* mask, unsigned long long seed, uint32_t* episode,

@@ -256,23 +256,23 @@ __device__ __forceinline__ void wave_sync_lds() {
 // stable_params (ble_reset.h; stable_init.py:40-129) for the superpressure alone, with the TWO evaluations of each
 // finite-difference Newton step on a PAIR of lanes (half = 0: T - delta / 2, half = 1: T + delta / 2; exchanged with one
 // DPP quad swap): the same arithmetic, half the dependent chain.  Both lanes of a pair return the same value.
+template <class V>
 __device__ inline double stable_superpressure_paired(double alpha, double p, double el_deg, double flux, double ir, int half,
-                                                     uint32_t* flags) {
+                                                     uint32_t* flags, const V& veh) {
   const AtmWindow w = atm_window(alpha, p, flags);
   double h, t_amb;
   atm_at_pressure_f64(w, alpha, p, &h, &t_amb);
-  const double ma = ((p * kAirMolarMassD * 1804.0 / (kGasConstantD * t_amb) - 68.5 - 92.5 - kHeMolarMassD * 6830.0) /
+  const double ma = ((p * kAirMolarMassD * veh.v0 / (kGasConstantD * t_amb) - veh.envelope_mass - veh.payload_mass - veh.he_mass) /
                      kAirMolarMassD);
   const double mols_air = ma > 0.0 ? ma : 0.0;
   const double att = solar_attenuation_f64(el_deg, p);
   double ti = 206.0;
   const double delta = 0.01;
-  constexpr double kInvCbrt1804 = 0.08214626507693945;     // 1804^(-1/3)
   uint32_t ignored = 0;
   const double q_earth = earth_heat_per_area_f64(ir, &ignored);
 #pragma unroll 1
   for (int k = 0; k < 10; ++k) {
-    const double mine = thermal_dtdt_f64(1804.0, kInvCbrt1804, half ? ti + delta / 2 : ti - delta / 2, t_amb, p, att, flux, q_earth);
+    const double mine = thermal_dtdt_f64(veh.v0, veh.inv_cbrt_v0, half ? ti + delta / 2 : ti - delta / 2, t_amb, p, att, flux, q_earth, veh.thermal_scale);
     const double other = quad_swap(mine, 1);
     const double d1 = half ? other : mine, d2 = half ? mine : other;
     // (reciprocals instead of the two fp64 divisions of a step, ~10 instructions each: the iteration converges on a
@@ -283,7 +283,7 @@ __device__ inline double stable_superpressure_paired(double alpha, double p, dou
     if (fabs(mean) < 1e-5) break;
   }
   double volume, sp;
-  superpressure_volume_f64(mols_air, ti, p, 1.0 / p, &volume, &sp);
+  superpressure_volume_f64(mols_air, ti, p, 1.0 / p, &volume, &sp, stride_k_literal(veh.dry_mass, veh.lift, veh.v0), veh.dvdp, veh.four_dvdp, veh.inv_dvdp);
   return sp;
 }
 
@@ -293,8 +293,7 @@ __device__ inline double stable_superpressure_paired(double alpha, double p, dou
 __device__ __forceinline__ double lane_read(double v, int idx) { return readlane_f64(v, __builtin_amdgcn_readfirstlane(idx)); }
 
 // interp1d(p/T -> p, linear, extrapolating) at the float ceiling (pressure_range_builder.py:236-247)
-__device__ inline double pressure_ceiling_wave(double lev_l, double pot_l, int lane) {
-  const double target = (92.5 + 68.5 + 6830.0 * kHeMolarMassD) * kGasConstantD / (kAirMolarMassD * 1804.0);
+__device__ inline double pressure_ceiling_wave(double lev_l, double pot_l, int lane, double target = VehicleDefault::ceiling_target) {
   const unsigned long long stop = __ballot(lane < 20 && !(pot_l < target));      // searchsorted(side='left'): first level not below
   int i = stop ? __ffsll((long long)stop) - 1 : 20;
   i = i < 1 ? 1 : (i > 19 ? 19 : i);
@@ -305,8 +304,8 @@ __device__ inline double pressure_ceiling_wave(double lev_l, double pot_l, int l
 
 // _search_for_safe_pressure (:111-182) over superpressures that are already solved (sp_l: lane k < 20 = level k).
 __device__ inline double safe_pressure_search_wave(double lev_l, double sp_l, int lane, double significant, double sp_sig,
-                                                   bool upward, int* ok) {
-  const double lo = 250.0, hi = 2380.0 - 250.0;
+                                                   bool upward, int* ok, double hi = VehicleDefault::sp_hi) {
+  const double lo = 250.0;
   if (sp_sig >= lo && sp_sig <= hi) return significant;
   // levels on the far side of `significant`, in scan order (upward: 0 -> 19, else 19 -> 0); the first one whose
   // superpressure is inside [lo, hi] ends the scan, `last` is the level scanned just before it
@@ -337,12 +336,14 @@ __device__ inline double safe_pressure_search_wave(double lev_l, double sp_l, in
   return fabs((target - s1) / (s2 - s1)) * (p2 - p1) + p1;
 }
 
+template <class Veh = VehicleDefault>
 __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, const float* __restrict__ wind_grid,
                                                                 int64_t grid_env_stride,
                                                                 const float* __restrict__ noise_uv,
                                                                 const uint8_t* __restrict__ reset_mask, GpHistory hist,
                                                                 int append, float* __restrict__ obs,
-                                                                uint32_t* err_flags, int64_t n) {
+                                                                uint32_t* err_flags, int64_t n, Veh veh,
+                                                                const float* __restrict__ forecast_levels) {
   __shared__ ObsShared sh;
   BLE_OBS_INSTR_BEGIN();        // (profiling builds only; nothing in the product build)
   BLE_MARK();
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, 
     if (lane == 63) {
       // -- the ambient features that need only the state (features.py:400-470);   Reciprocals instead of fp64 divisions: <= 1 ulp of fp64 before the
       //    rounding to float32.
-      const double soc = (double)batt_f * (1.0 / 3058.56);
+      const double soc = (double)batt_f * veh.inv_capacity;
       const double d2 = x * x + y * y;
       const double inv_d = d2 > 0.0 ? d_rsqrt(d2) : 0.0;
       const double dist_km = d2 * inv_d * 1e-3;
@@ -671,13 +672,13 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, 
       const double elc = (el_now + 90.0) * (1.0 / 180.0);
       out[2] = (float)(elc < 0.0 ? 0.0 : (elc > 1.0 ? 1.0 : elc));
       out[3] = (float)sc; out[4] = (float)cc;
-      const double soc = (double)batt_f * (1.0 / 3058.56);
-      out[13] = (soc > 0.99 && solar_power_f64(el_now, p) > 120.4) ? 1.0f : 0.0f;     // balloon.py:231-238
+      const double soc = (double)batt_f * veh.inv_capacity;
+      out[13] = (soc > 0.99 && solar_power_f64(el_now, p) > veh.day_load_d) ? 1.0f : 0.0f;     // balloon.py:231-238
     }
   } else if (wave == 1) {
     // lane k < 20: search level k; lane 20: the float ceiling; lane 21: the floor
     const double lev_l = lane < 20 ? sh.lev[lane] : 0.0, pot_l = lane < 20 ? sh.pot[lane] : 0.0;
-    const double ceiling = pressure_ceiling_wave(lev_l, pot_l, lane);
+    const double ceiling = pressure_ceiling_wave(lev_l, pot_l, lane, veh.ceiling_target);
     // cold starts: level lane / 2 on the lane pair (lane & ~1, lane | 1) -- 44 lanes; then back to one level per lane
     double sp_pair = 0.0;
     const int lvl = lane >> 1;
@@ -685,14 +686,14 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, 
     if (lane < 44) {
       const double level = lvl < 20 ? lev_p : (lvl == 20 ? ceiling : p_floor);
       uint32_t local = 0;
-      sp_pair = stable_superpressure_paired(alpha, level, el_now, flux_now, (double)ir_f, lane & 1, &local);
+      sp_pair = stable_superpressure_paired(alpha, level, el_now, flux_now, (double)ir_f, lane & 1, &local, veh);
       flags |= local;
     }
     const double sp_l = __shfl(sp_pair, lane < 22 ? 2 * lane : 0, 64);
     // ---- reachable pressure range (pressure_range_builder.py:249-275), as soon as the 22 superpressures exist
     int ok = 1;
-    const double p_lo_w = safe_pressure_search_wave(lev_l, sp_l, lane, ceiling, lane_read(sp_l, 20), true, &ok);
-    const double p_hi_w = safe_pressure_search_wave(lev_l, sp_l, lane, p_floor, lane_read(sp_l, 21), false, &ok);
+    const double p_lo_w = safe_pressure_search_wave(lev_l, sp_l, lane, ceiling, lane_read(sp_l, 20), true, &ok, veh.sp_hi);
+    const double p_hi_w = safe_pressure_search_wave(lev_l, sp_l, lane, p_floor, lane_read(sp_l, 21), false, &ok, veh.sp_hi);
     // first and last reachable level of the 181 (features.py:530-536: level >= p_lo && level <= p_hi), here and not
     // in front of the sweep where all four waves would walk these loops
     int lo_i = (int)((p_lo_w - 5000.0) * (1.0 / 50.0)), hi_i = (int)((p_hi_w - 5000.0) * (1.0 / 50.0));
@@ -1358,12 +1359,17 @@ __global__ __launch_bounds__(kObsBlock, 2) void ble_observe_kernel(StateDev st, 
         const double val_last = gp_exp_neg_scaled(__builtin_fabs(dpl), sh.exp2_frac) - cross_m;        // (s^2 is in the table)
         const double ss = d_fma(val_last * val_last, inv_dn, ssq_m);
         const double mu = d_fma(val_last, zl_u, mean_u_m), mv = d_fma(val_last, zl_v, mean_v_m);
-        // forecast at this level from the blended column
+        // forecast at this level from the blended column -- or, for a forecast that is not a grid (ble_observe_forecast_f32: any
+        // WindField.get_forecast_column of the caller's, features.py:499-503 -> wind_gp.py:218-222), as the caller evaluated it
         int ip = (int)((level_m - 5000.0) * 1e-3);
         ip = ip > 8 ? 8 : ip;
         const double wp = (level_m - (5000.0 + 1000.0 * (double)ip)) * 1e-3;
-        const double fu = d_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
-        const double fv = d_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
+        double fu = d_fma(wp, sh.column[(ip + 1) * 2] - sh.column[ip * 2], sh.column[ip * 2]);
+        double fv = d_fma(wp, sh.column[(ip + 1) * 2 + 1] - sh.column[ip * 2 + 1], sh.column[ip * 2 + 1]);
+        if (forecast_levels != nullptr) {           // (wave-uniform)
+          const float* f = forecast_levels + (env * kObsLevels + level_idx) * 2;
+          fu = (double)f[0]; fv = (double)f[1];
+        }
         const double u = mu + fu, v = mv + fv;
         double var = kGpSigma2 - ss;
         var = var < 0.0 ? 0.0 : var;

@@ -76,12 +76,18 @@ struct VehicleDefault {
   static constexpr double night_load_d = 183.7, capacity_d = 3058.56, day_load_d = 120.4;
   static constexpr float day_load = 120.4f, night_load = 183.7f, capacity = 3058.56f;
   static constexpr bool power_layer = true;                                                                    // power_safety_layer_enabled
+  // the observation (csrc/ble_observe.h): battery_soc's reciprocal capacity, get_pressure_range's float ceiling p / T (empty mass x R / (M V0),
+  // pressure_range_builder.py:236-245) and its upper superpressure bound (max - BUFFER, :224-228)
+  static constexpr double inv_capacity = 1.0 / 3058.56;
+  static constexpr double ceiling_target = (92.5 + 68.5 + 6830.0 * kHeMolarMassD) * kGasConstantD / (kAirMolarMassD * 1804.0);
+  static constexpr double sp_hi = 2380.0 - 250.0;
 };
 struct VehicleRt {
   double v0, dvdp, four_dvdp, inv_dvdp, inv_cbrt_v0, lift, dry_mass, envelope_mass, payload_mass, he_mass, max_sp, drag_arg, thermal_scale, valve_k;
   double night_load_d, capacity_d, day_load_d;
   float day_load, night_load, capacity;
   bool power_layer;
+  double inv_capacity, ceiling_target, sp_hi;
 };
 
 // control.py / balloon.py enums

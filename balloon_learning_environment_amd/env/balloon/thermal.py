@@ -29,7 +29,5 @@ def d_balloon_temperature_dt(balloon_volume: float, balloon_mass: float, balloon
                              ambient_temperature_k: float, pressure_altitude_pa: float, solar_elevation_deg: float,
                              solar_flux: float, earth_flux: float) -> float:
   """thermal.py:175-230 [K/s], by the device function the transition integrates."""
-  if balloon_mass != 68.5:
-    raise NotImplementedError('the kernel is built for the reference envelope (68.5 kg)')
   return _probes.thermal(balloon_volume, balloon_temperature_k, ambient_temperature_k, pressure_altitude_pa, solar_elevation_deg,
-                         solar_flux, earth_flux)
+                         solar_flux, earth_flux, envelope_mass=balloon_mass)

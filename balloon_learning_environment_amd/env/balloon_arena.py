@@ -99,8 +99,10 @@ class VecBalloonArena:
     if self._grids is None:
       self._grids = torch.empty((self.num_envs,) + tuple(vec_state.GRID_SHAPE), dtype=torch.float32, device=self.device)
       self._stale = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
-    count = self.num_envs if lanes is None else int(lanes.numel())
-    latents = sampler.sample_latents(count, _mix_seed(self._seed, 1 + self._field_epoch))
+    # one latent per (seed, GLOBAL environment index, that environment's episode count): a shard (env_offset) decodes exactly
+    # the fields the unsharded batch decodes for its environments, and a masked refresh what a full one would
+    index = torch.arange(self.num_envs, dtype=torch.int64, device=self.device) if lanes is None else lanes.to(torch.int64)
+    latents = sampler.sample_latents_keyed(index + self.sim.env_offset, self.sim.episode[index], self._seed)
     self._field_epoch += 1
     if lanes is None:
       sampler.decode(latents, self._grids)
@@ -171,20 +173,20 @@ class VecBalloonArena:
 
   # ---- per-env views -----------------------------------------------------------------
   def row(self, i: int) -> dict:
-    """State of env i as Python scalars: one device->host copy per dtype instead of one per field."""
-    by_dtype = {}
-    for name, t in self.sim.state.items():
-      by_dtype.setdefault(t.dtype, []).append(name)
-    out = {}
-    for dtype, names in by_dtype.items():
-      vals = torch.stack([self.sim.state[n][i] for n in names]).cpu().tolist()
-      out.update(zip(names, vals))
-    return {name: out[name] for name in self.sim.state}
+    """State of env i as Python scalars: ONE kernel (`ble_state_rows_f64`) and one device->host copy."""
+    return self.sim.row_dict(self.sim.rows(i, 1)[0].cpu().tolist())
 
   def get_balloon_state(self, i: int = 0) -> balloon.BalloonState:
-    return balloon.state_from_row(self.row(i))
+    return balloon.state_from_row(self.row(i), self.sim.vehicle)
 
   def set_balloon_state(self, new_state: balloon.BalloonState, i: int = 0) -> None:
+    # the state's flight-vehicle constants (balloon.py:156-173,183,200): one vehicle per batch (ble_state_f32.vehicle)
+    veh = _abi.vehicle_struct(**balloon.vehicle_of(new_state))
+    overrides = {} if veh is None else {k: getattr(veh, k) for k in _abi.VEHICLE_DEFAULTS if getattr(veh, k) != _abi.VEHICLE_DEFAULTS[k]}
+    if overrides != self.sim.vehicle:
+      if self.num_envs != 1:
+        raise ValueError('all environments of a batch fly one vehicle: VecSimulator.set_vehicle(...) sets it for the batch')
+      self.sim.set_vehicle(**overrides)
     alpha = float(self.sim.state['alpha'][i].item())
     row = balloon.row_from_state(new_state, alpha)
     for name, value in row.items():
@@ -229,6 +231,7 @@ class BalloonArena(BalloonArenaInterface):
     self._wind_field = self._vec.wind_field
     self.last_reward = None
     self._row = None          # host copy of the balloon's row, valid until the next device-side change
+    self._fast, self._noise_valid = None, False      # the one-transfer step (see _step_fast)
     self.reset(seed)
 
   def _bind_wind_field(self) -> None:
@@ -256,6 +259,7 @@ class BalloonArena(BalloonArenaInterface):
     seed_ = int(time.time() * 1e6) % (2 ** 31) if seed is None else int(np.asarray(seed).ravel()[-1])
     self._vec._seed = seed_
     self._row = None
+    self._fast, self._noise_valid = None, False      # a new feature constructor (new WindGP buffers): buffers and graph are rebuilt
     self._vec.sim.episode.zero_()         # reset(seed) reproduces the same episode whatever happened before
     self._vec.sim.reset_device(seed_)
     self._wind_field.reset(np.array([seed_], np.uint32), self.get_balloon_state().date_time)
@@ -272,11 +276,106 @@ class BalloonArena(BalloonArenaInterface):
     fc = self.feature_constructor
     (fc.observe_bound if getattr(fc, '_bound', False) else fc.observe)(self.get_measurements())
 
+  # ---- the one-transfer step ---------------------------------------------------------------------------------------------
+  # BalloonArena.step as the reference's loop drives it (`observation, reward, done, info = env.step(action)`,
+  # eval/eval_lib.py:158-171) is host-synchronous: what it costs is round trips, not arithmetic.  With a grid-based wind field
+  # and the device feature constructor everything a step needs is already on the device, so the step is ONE HIP graph --
+  # action in, transition (ble_step_f32) in the ground-truth wind, the wind noise at the new position (ble_wind_noise_f32: the
+  # measured-minus-forecast term of this observation AND the next transition's ground-truth term), the observation
+  # (ble_observe_f32), the balloon's row (ble_state_rows_f64) -- and ONE pinned device-to-host copy of 4.6 KB carrying the
+  # observation, the row, the reward and both error words.  Anything the path cannot express (a host-only wind field, a
+  # subclass that edits the measurements, another feature constructor) takes the general path below.
+  def _fast_path_ok(self) -> bool:
+    fc = getattr(self, 'feature_constructor', None)
+    model = getattr(self._wind_field, 'noise_model', None)
+    return (getattr(self, '_grid_based', False) and type(self._wind_field) is grid_based_wind_field.GridBasedWindField and
+            type(fc) is features.PerciatelliFeatureConstructor and getattr(fc, '_bound', False) and
+            type(self).get_measurements is BalloonArena.get_measurements and type(self)._host_wind is BalloonArena._host_wind and
+            (model is None or (type(model).__name__ == 'SimplexWindNoise' and model._seed is not None)))
+
+  def _launch_noise(self, out: torch.Tensor) -> None:
+    """SimplexWindNoise.get_wind_noise at the balloon's CURRENT position and time, device to device: the launch
+    env/simplex_wind_noise.py::SimplexWindNoise.get_wind_noise makes, on the state where it lives."""
+    from balloon_learning_environment_amd import _lib, device as dev
+    s, sim = self._vec.sim.state, self._vec.sim
+    _lib.check(sim.lib.ble_wind_noise_f32(s['x'].data_ptr(), s['y'].data_ptr(), s['pressure'].data_ptr(), s['time_elapsed_s'].data_ptr(),
+                                          int(self._wind_field.noise_model._seed), 0, 0, 0, out.data_ptr(), 1, dev.stream_ptr(sim.device)),
+               'ble_wind_noise_f32')
+
+  def _fast_setup(self) -> dict:
+    d = self._vec.device
+    stage = torch.zeros(240 + 4 * 1099, dtype=torch.uint8, device=d)          # [26 row doubles | reward, step flags, observe flags, pad | 1099 floats]
+    host = torch.zeros(240 + 4 * 1099, dtype=torch.uint8).pin_memory()
+    host_np = host.numpy()
+    f = dict(stage=stage, host=host, row=stage[:208].view(torch.float64).view(1, 26), extra=stage[208:240].view(torch.float64),
+             obs=stage[240:].view(torch.float32).view(1, 1099), host_head=host_np[:240].view(np.float64), host_obs=host_np[240:].view(np.float32),
+             action=torch.ones(1, dtype=torch.uint8, device=d), action_host=torch.ones(1, dtype=torch.uint8).pin_memory(),
+             noise=(torch.zeros(1, 2, dtype=torch.float32, device=d) if getattr(self._wind_field, 'noise_model', None) is not None else None),
+             graph=None, eager_steps=0)
+    f['action_np'] = f['action_host'].numpy()
+    return f
+
+  def _fast_body(self, f: dict) -> None:
+    sim, fsim = self._vec.sim, self.feature_constructor._sim
+    f['action'].copy_(f['action_host'], non_blocking=True)
+    sim.step(f['action'], f['noise'])                 # the ground-truth wind: forecast (in-kernel) + the noise evaluated after the previous step
+    if f['noise'] is not None:
+      self._launch_noise(f['noise'])                  # at the NEW position: this observation's error term and the next step's noise
+    fsim.observe(f['noise'], out=f['obs'])
+    sim.rows(0, 1, out=f['row'])
+    f['extra'][0:1].copy_(sim.reward); f['extra'][1:2].copy_(sim.err_flags); f['extra'][2:3].copy_(fsim.err_flags)
+    f['host'].copy_(f['stage'], non_blocking=True)
+
+  def _step_fast(self, action: control.AltitudeControlCommand) -> np.ndarray:
+    sim = self._vec.sim
+    if self._fast is None:
+      self._fast = self._fast_setup()
+    f = self._fast
+    stream = torch.cuda.current_stream(sim.device)
+    if not self._noise_valid and f['noise'] is not None:     # after reset() / set_balloon_state(): the noise at where the balloon is now
+      self._launch_noise(f['noise'])
+    self._noise_valid = True
+    if f['graph'] is None and f['eager_steps'] >= 2:
+      # buffers exist and every lazy allocation has happened: record the step once (recording does not execute it), replay from now on
+      stream.synchronize()
+      side = torch.cuda.Stream(device=sim.device)
+      side.wait_stream(stream)
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+          self._fast_body(f)
+      stream.wait_stream(side)
+      f['graph'] = graph
+    f['action_np'][0] = int(action)
+    if f['graph'] is not None:
+      f['graph'].replay()
+    else:
+      self._fast_body(f)
+      f['eager_steps'] += 1
+    stream.synchronize()
+    return self._fast_finish(f['host_head'], f['host_obs'])
+
+  def _fast_finish(self, head, obs) -> np.ndarray:
+    sim, fsim = self._vec.sim, self.feature_constructor._sim
+    step_flags, obs_flags = int(head[27]), int(head[28])
+    if step_flags or obs_flags:        # what the reference would have raised inside the transition / the feature constructor
+      sim.err_flags.zero_(); fsim.err_flags.zero_()
+      vec_state.raise_for_flags(step_flags | obs_flags)
+    self._row = sim.row_dict(head[:26])
+    self.last_reward = float(np.float32(head[26]))
+    self.feature_constructor._features = obs.copy()        # (the pinned buffer is overwritten by the next step)
+    return self.feature_constructor._features.copy()
+
   def step(self, action: control.AltitudeControlCommand) -> np.ndarray:
     # balloon.py:288-290: stepping a terminal balloon is an error in the single-env API
-    status = self.get_balloon_state().status
+    if self._row is None:
+      self._row = self._vec.row(0)
+    status = balloon.BalloonStatus(int(self._row['status']))
     assert status == balloon.BalloonStatus.OK, (
         f'Stepping balloon after a terminal event occured. ({status.name})')
+    if self._fast_path_ok():
+      return self._step_fast(control.AltitudeControlCommand(action))
+    self._noise_valid = False
     a = torch.tensor([int(action)], dtype=torch.uint8, device=self._vec.device)
     reward, _ = self._vec.step(a, self._host_wind())
     self._row = None
@@ -290,6 +389,7 @@ class BalloonArena(BalloonArenaInterface):
 
   def set_simulator_state(self, new_state: simulator_data.SimulatorState) -> None:
     self._row = None
+    self._fast, self._noise_valid = None, False       # (another wind field may come with it)
     self._vec.sim.state['alpha'][0] = float(new_state.atmosphere.alpha)
     self.set_balloon_state(new_state.balloon_state)
     self._wind_field = new_state.wind_field
@@ -301,11 +401,15 @@ class BalloonArena(BalloonArenaInterface):
     its live state object; callers that mutate the result must pass it to set_balloon_state)."""
     if self._row is None:
       self._row = self._vec.row(0)
-    return balloon.state_from_row(self._row)
+    return balloon.state_from_row(self._row, self._vec.sim.vehicle)
 
   def set_balloon_state(self, new_state: balloon.BalloonState) -> None:
     self._row = None
+    self._noise_valid = False                          # the balloon is somewhere else now
+    before = dict(self._vec.sim.vehicle)
     self._vec.set_balloon_state(new_state, 0)
+    if self._vec.sim.vehicle != before:
+      self._fast = None                                # (a captured graph holds the KERNEL it captured: default vs run-time vehicle)
 
   def get_measurements(self) -> simulator_data.SimulatorObservation:
     b = self.get_balloon_state()

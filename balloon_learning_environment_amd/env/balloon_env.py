@@ -1,4 +1,5 @@
 """BalloonEnv (env/balloon_env.py:106-300): the gym-style RL surface over the HIP arena."""
+import datetime as dt
 import math
 import time
 from typing import Any, Callable, Dict, Mapping, Optional, Tuple, Union
@@ -69,12 +70,20 @@ class BalloonEnv:
     command = control.AltitudeControlCommand(action)
     observation = self.arena.step(command)
     assert isinstance(observation, np.ndarray)
-    simulator_state = self.arena.get_simulator_state()
-    if self._renderer is not None:
-      self._renderer.step(simulator_state)
     kernel_reward = getattr(self.arena, 'last_reward', None)
-    reward = kernel_reward if (self._use_kernel_reward and kernel_reward is not None) else self._reward_fn(simulator_state)
-    info = self._get_info(simulator_state.balloon_state)
+    row = getattr(self.arena, '_row', None)
+    if row is not None and self._renderer is None and self._use_kernel_reward and kernel_reward is not None:
+      # the step brought the balloon's row back with the observation (BalloonArena._step_fast): status and clock straight from it;
+      # the BalloonState object is built when somebody asks for it (get_simulator_state)
+      reward, status = kernel_reward, int(row['status'])
+      info = {'out_of_power': status == balloon.BalloonStatus.OUT_OF_POWER.value, 'envelope_burst': status == balloon.BalloonStatus.BURST.value,
+              'zeropressure': status == balloon.BalloonStatus.ZEROPRESSURE.value, 'time_elapsed': dt.timedelta(seconds=int(row['time_elapsed_s']))}
+    else:
+      simulator_state = self.arena.get_simulator_state()
+      if self._renderer is not None:
+        self._renderer.step(simulator_state)
+      reward = kernel_reward if (self._use_kernel_reward and kernel_reward is not None) else self._reward_fn(simulator_state)
+      info = self._get_info(simulator_state.balloon_state)
     is_terminal = info['out_of_power'] or info['envelope_burst'] or info['zeropressure']
     self._global_iteration += 1
     return observation, reward, is_terminal, info

@@ -2,7 +2,8 @@
 
 `PerciatelliFeatureConstructor` (env/features.py:269-581): 16 ambient features + a 361-level relative wind column from the
 WindGP, computed by `ble_observe_f32` (csrc/ble_observe.h) for a one-environment batch -- the WindGP history and its factor
-live on the device.  There is no host implementation in this package: a forecast without a device grid is refused.  (The
+live on the device.  There is no host implementation in this package: a forecast that is not a device grid is asked for its column
+above the balloon and the kernel takes that as an input (`ble_observe_forecast_f32`).  (The
 NumPy restatement the parity tests check the kernel against is oracle/features_oracle.py; the former host constructor lives
 next to the tests, tests/features_host.py.)  `StateFeatureConstructor` is a compact raw-state observation for vectorised
 consumers.
@@ -160,16 +161,20 @@ _UNREACHABLE = (0.0, 1.0, 1.0)   # certain, wrong way, infinitely fast
 
 class PerciatelliFeatureConstructor(FeatureConstructor):
   """env/features.py:269-581, computed by `ble_observe_f32` for a one-environment batch (the WindGP
-  history and its factor live on the device).  Needs a grid-based forecast; for N environments
-  use `VecBalloonArena.observe` directly."""
+  history and its factor live on the device).  Like the reference's it takes ANY wind_field.WindField as its forecast
+  (features.py:290-299): a grid-based one is interpolated inside the kernel; any other (the reference's unit-test field,
+  SimpleStaticWindField) is asked for its column above the balloon, `get_forecast_column(x, y, 181 levels, elapsed)`
+  (features.py:499-503), which the kernel takes as an input (`ble_observe_forecast_f32`).  For N environments use
+  `VecBalloonArena.observe` directly."""
 
-  def __init__(self, forecast, atmosphere) -> None:
+  LEVELS = tuple(5000.0 + 50.0 * k for k in range(181))       # features.py:288-289: np.linspace(5000, 14000, 181)
+
+  def __init__(self, forecast, atmosphere, device=None) -> None:
     from balloon_learning_environment_amd import vec_state       # (device module: imported on use)
-    if getattr(forecast, 'grid', None) is None:
-      raise TypeError('PerciatelliFeatureConstructor needs a forecast with a device grid (GridBasedWindField): this package has no host observation path')
     self._forecast, self._alpha = forecast, float(atmosphere.alpha)
-    self._sim = vec_state.VecSimulator(1, forecast.device)
-    self._sim.set_grid(forecast.grid)
+    self._grid_based = getattr(forecast, 'grid', None) is not None
+    self._sim = vec_state.VecSimulator(1, getattr(forecast, 'device', None) or device or 'cuda:0')
+    self._sim.set_grid(forecast.grid if self._grid_based else np.zeros(vec_state.GRID_SHAPE, np.float32))
     self._features = None
     self.num_features = 1099
 
@@ -180,7 +185,7 @@ class PerciatelliFeatureConstructor(FeatureConstructor):
     from balloon_learning_environment_amd import device as dev
     assert sim.n == 1 and sim.device == self._sim.device
     self._sim.state = sim.state
-    self._sim._struct = dev.state_struct(sim.state, getattr(sim, 'episode_cache', None))
+    self._sim._struct = sim._struct          # (the arena's own struct: its device pointers AND its vehicle)
     self._bound = True
 
   def observe_bound(self, observation: simulator_data.SimulatorObservation) -> None:
@@ -195,6 +200,7 @@ class PerciatelliFeatureConstructor(FeatureConstructor):
     from balloon_learning_environment_amd import device as dev
     self._sim.state = {name: t.clone() for name, t in self._sim.state.items()}
     self._sim._struct = dev.state_struct(self._sim.state, self._sim.episode_cache)
+    self._sim.set_vehicle(**self._sim.vehicle)
     self._bound = False
 
   def observe(self, observation: simulator_data.SimulatorObservation) -> None:
@@ -212,10 +218,15 @@ class PerciatelliFeatureConstructor(FeatureConstructor):
     if copy_state:
       row = balloon_lib.row_from_state(b, self._alpha)
       self._sim.set_state({k: np.array([v]) for k, v in row.items()})
+      self._sim.set_vehicle(**balloon_lib.vehicle_of(b))        # battery_soc, excess_energy and get_pressure_range read the vehicle
     fc = self._forecast.get_forecast(b.x, b.y, b.pressure, b.time_elapsed)
     w = observation.wind_at_balloon
     noise = torch.tensor([[w.u.mps - fc.u.mps, w.v.mps - fc.v.mps]], dtype=torch.float32, device=self._sim.device)
-    self._features = self._sim.observe(noise)[0].cpu().numpy()
+    column = None
+    if not self._grid_based:      # a forecast that is not a grid: its own column above the balloon (features.py:499-503)
+      col = self._forecast.get_forecast_column(b.x, b.y, list(self.LEVELS), b.time_elapsed)
+      column = torch.tensor([[[c.u.mps, c.v.mps] for c in col]], dtype=torch.float32, device=self._sim.device)
+    self._features = self._sim.observe(noise, forecast_levels=column)[0].cpu().numpy()
     self._sim.check_errors()
 
   def get_features(self) -> np.ndarray:
@@ -233,6 +244,6 @@ DevicePerciatelliFeatureConstructor = PerciatelliFeatureConstructor      # (the 
 
 
 def perciatelli_feature_constructor(forecast, atmosphere) -> FeatureConstructor:
-  """Default factory of BalloonEnv / BalloonArena: the device observation (`ble_observe_f32`).  A forecast object that exists
-  on the host alone (no `grid` on a HIP device) raises TypeError."""
+  """Default factory of BalloonEnv / BalloonArena: the device observation (`ble_observe_f32`; `ble_observe_forecast_f32` for a
+  forecast object that is not a device grid)."""
   return PerciatelliFeatureConstructor(forecast, atmosphere)

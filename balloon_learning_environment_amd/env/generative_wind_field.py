@@ -84,6 +84,26 @@ class GenerativeWindFieldSampler(grid_wind_field_sampler.GridWindFieldSampler):
     gen = torch.Generator(device=self.device); gen.manual_seed(int(seed))
     return torch.randn((n, NUM_LATENTS), dtype=torch.float32, device=self.device, generator=gen)
 
+  @dev.on_own_device
+  def sample_latents_keyed(self, global_index: torch.Tensor, episode: torch.Tensor, seed: int) -> torch.Tensor:
+    """[n, 64] standard-normal latents, row i a function of (seed, global_index[i], episode[i]) ALONE -- a counter-based stream
+    (splitmix64 of the counter, Box-Muller) instead of one generator walked in batch order: the wind field of environment g in its
+    e-th episode is the same whatever the batch it is decoded in, so the shards of a job (VecBalloonArena(env_offset=...)) fly in
+    the fields the unsharded batch flies in, and a masked refresh draws what a full one would."""
+    g = global_index.to(self.device, torch.int64).reshape(-1, 1)
+    e = episode.to(self.device, torch.int64).reshape(-1, 1)
+
+    def mix(z):                                   # splitmix64's finaliser on int64 tensors (two's-complement wrap = mod 2^64)
+      z = (z ^ ((z >> 30) & 0x3FFFFFFFF)) * (-4658895280553007687)        # 0xBF58476D1CE4E5B9
+      z = (z ^ ((z >> 27) & 0x1FFFFFFFFF)) * (-7723592293110705685)       # 0x94D049BB133111EB
+      return z ^ ((z >> 31) & 0x1FFFFFFFF)
+    k = torch.arange(NUM_LATENTS, dtype=torch.int64, device=self.device).reshape(1, -1)
+    base = mix(mix(torch.full_like(g, int(seed) & 0x7FFFFFFFFFFFFFFF) + e * (-7046029254386353131)) + g)   # (0x9E3779B97F4A7C15)
+    h1, h2 = mix(base + (2 * k + 1) * (-7046029254386353131)), mix(base + (2 * k + 2) * (-7046029254386353131))
+    u1 = (((h1 >> 11) & ((1 << 53) - 1)).to(torch.float64) + 0.5) * (1.0 / 9007199254740992.0)           # (0, 1)
+    u2 = (((h2 >> 11) & ((1 << 53) - 1)).to(torch.float64)) * (1.0 / 9007199254740992.0)                 # [0, 1)
+    return (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)).to(torch.float32).contiguous()
+
   def sample_field(self, key, date_time: Optional[dt.datetime] = None) -> np.ndarray:
     seed = int(np.asarray(key).ravel()[-1]) if key is not None else 0
     return self.decode(self.sample_latents(1, seed))[0].cpu().numpy()

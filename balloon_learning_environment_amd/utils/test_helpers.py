@@ -11,9 +11,8 @@ from balloon_learning_environment_amd.utils import units
 START_DATE_TIME = units.datetime(2013, 3, 25, 9, 25, 32)          # :37
 
 def create_arena(feature_constructor_factory=features.PerciatelliFeatureConstructor, seed=None):      # :40-43
-  """The reference's arena in its unit-test wind field.  SimpleStaticWindField is a host-only forecast object, which this
-  package's (device) PerciatelliFeatureConstructor refuses: hand in a feature constructor that can read it -- the tests
-  pass their NumPy twin, tests/features_host.py."""
+  """The reference's arena in its unit-test wind field (SimpleStaticWindField: not a grid -- the device feature constructor asks it
+  for its column above the balloon, `ble_observe_forecast_f32`)."""
   return balloon_arena.BalloonArena(feature_constructor_factory, wind_field.SimpleStaticWindField(), seed=seed)
 
 
@@ -23,12 +22,11 @@ def create_balloon(x: units.Distance = units.Distance(m=0.0), y: units.Distance 
                    power_safety_layer_enabled: bool = True, use_stable_init: bool = True, upwelling_infrared: float = 250.0,
                    atmosphere=None) -> balloon.Balloon:                            # :96-130
   """Creates a balloon object for easy testing."""
-  if not power_safety_layer_enabled:
-    raise NotImplementedError('the transition always runs the power safety layer (balloon.py:304-306 with the default flag)')
   date_time = date_time if date_time is not None else START_DATE_TIME
   time_elapsed = time_elapsed if time_elapsed is not None else dt.timedelta()
   b = balloon.Balloon(balloon.BalloonState(center_latlng=balloon.LatLng.from_degrees(center_lat, center_lng), x=x, y=y,
                                            pressure=pressure, date_time=date_time, time_elapsed=time_elapsed,
+                                           power_safety_layer_enabled=power_safety_layer_enabled,
                                            upwelling_infrared=upwelling_infrared))
   b.state.battery_charge = b.state.battery_capacity * power_percent
   if use_stable_init:

@@ -94,6 +94,27 @@ class VecSimulator:
   def get_state(self) -> Dict[str, np.ndarray]:
     return {name: t.cpu().numpy() for name, t in self.state.items()}
 
+  @_on_own_device
+  def rows(self, first: int = 0, count: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Environments first .. first + count - 1 as records: a [count, 26] float64 DEVICE tensor, the per-environment members of
+    ble_state_f32 in the struct's order (_abi.FIELD_NAMES), every value exact (`ble_state_rows_f64`) -- one transfer for a host
+    consumer instead of one per member.  Asynchronous on the current stream."""
+    count = self.n - first if count is None else int(count)
+    if out is None:
+      out = torch.empty(count, _lib.ROW_DOUBLES, dtype=torch.float64, device=self.device)
+    assert out.dtype == torch.float64 and out.is_contiguous() and out.numel() == count * _lib.ROW_DOUBLES
+    _lib.check(self.lib.ble_state_rows_f64(ctypes.byref(self._struct), int(first), count, out.data_ptr(), self.n, dev.stream_ptr(self.device)),
+               'ble_state_rows_f64')
+    return out
+
+  @staticmethod
+  def row_dict(record) -> dict:
+    """One record of rows() (26 numbers, host) -> {field: python scalar} with the members' own types."""
+    out = {}
+    for name, v in zip(_abi.FIELD_NAMES, record):
+      out[name] = float(v) if _abi.FIELD_DTYPES[name] == np.float32 else int(v)
+    return out
+
   def set_grid(self, grid, per_env: bool = False) -> None:
     """`grid`: (21,21,10,9,2) float32 shared by all envs, or (n,21,21,10,9,2) per env."""
     g = grid if isinstance(grid, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(grid, np.float32))
@@ -139,11 +160,14 @@ class VecSimulator:
   # ------------------------------------------------------------------ observation
   @_on_own_device
   def observe(self, noise_uv: Optional[torch.Tensor] = None, append: bool = True,
-              out: Optional[torch.Tensor] = None, carry_factor: bool = True) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, carry_factor: bool = True,
+              forecast_levels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PerciatelliFeatureConstructor.observe + get_features for every env: [n, 1099] float32
     device tensor.  `noise_uv` [n, 2]: measured wind minus forecast at the balloons (None = 0).
     carry_factor (fixed by the first call): keep each env's WindGP Cholesky factor in HBM (61 KB per
-    env) and slide it from step to step instead of refactoring the whole window every call."""
+    env) and slide it from step to step instead of refactoring the whole window every call.
+    forecast_levels [n, 181, 2] float32: the forecast (u, v) at the 181 levels 5 000 .. 14 000 Pa above every balloon as the
+    CALLER's WindField gives it (a forecast that is not a grid: `ble_observe_forecast_f32`); None: from the grid."""
     assert self.grid is not None, 'Must call set_grid (reset) before observe.'
     if self._gp is None:
       self._allocate_history(carry_factor)
@@ -152,11 +176,13 @@ class VecSimulator:
     if out is None:
       out = torch.empty(self.n, _lib.OBS_DIM, dtype=torch.float32, device=self.device)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (self.n, _lib.OBS_DIM)
-    code = self.lib.ble_observe_f32(ctypes.byref(self._struct), self.grid.data_ptr(), self.grid_env_stride,
-                                    dev.ptr(noise_uv), self._obs_reset.data_ptr(), ctypes.byref(self._gp_struct),
-                                    1 if append else 0, out.data_ptr(), self.err_flags.data_ptr(), self.n,
-                                    dev.stream_ptr(self.device))
-    _lib.check(code, 'ble_observe_f32')
+    if forecast_levels is not None:
+      assert forecast_levels.dtype == torch.float32 and forecast_levels.is_contiguous() and tuple(forecast_levels.shape) == (self.n, 181, 2)
+    code = self.lib.ble_observe_forecast_f32(ctypes.byref(self._struct), self.grid.data_ptr(), self.grid_env_stride, dev.ptr(forecast_levels),
+                                             dev.ptr(noise_uv), self._obs_reset.data_ptr(), ctypes.byref(self._gp_struct),
+                                             1 if append else 0, out.data_ptr(), self.err_flags.data_ptr(), self.n,
+                                             dev.stream_ptr(self.device))
+    _lib.check(code, 'ble_observe_forecast_f32')
     self._obs_reset.zero_()         # stream-ordered after the kernel
     return out
 

@@ -48,6 +48,9 @@ Besides `value`, the default run reports (rank 0; every leg is the same code pat
   `per_rank`     kernel time and exposed exchange time of a timed region on every rank (HIP events)
   `observe`      the closed-loop cost: step + wind noise + the 1099-feature observation (ble_observe_f32)
                  with a full WindGP window, its own roofline and measured traffic
+  `observe_configs`  the same closed loop at the batch sizes of the other BASELINE configs on one GPU -- 4 096 (configs[1]), 8 192
+                 (one GPU's share of configs[3]), 32 768 with per-environment grids (configs[4]'s share): ms per observation
+                 launch, env-steps/s of step + noise + observation, fp64 fraction; N = 1 only
   `cpu_baseline` the fp64 C oracle on this box's host cores (N = 1 only)
 Prints ONE JSON line on rank 0.
 """
@@ -169,7 +172,9 @@ class Rollout:
     if per_env_grids:     # no broadcast at all: every rank decodes its own latents into per-env grids
       from balloon_learning_environment_amd.env import generative_wind_field
       sampler = generative_wind_field.GenerativeWindFieldSampler(device=device, seed=0)
-      latents = sampler.sample_latents(n, seed=100 + rank)
+      # one latent per GLOBAL environment index (with a per-rank generator stream every shard decoded the same fields unless
+      # the seed was varied by hand): the shards' fields are the unsharded batch's
+      latents = sampler.sample_latents_keyed(torch.arange(n, device=device) + self.env_offset, torch.ones(n, dtype=torch.int64, device=device), seed=100)
       grids = torch.empty((n,) + tuple(vec_state.GRID_SHAPE), dtype=torch.float32, device=device)
       sampler.decode(latents[:min(n, 256)], grids[:min(n, 256)]); torch.cuda.synchronize()
       d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
@@ -660,6 +665,7 @@ def main():
   ground_truth = None
   configs = {f'configs[{args.config}]': {k: hs[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step')}}
   observe = None
+  observe_configs = {}
   policy = None
   if not args.no_extras:
     extra_reps = max(5, min(11, args.reps))
@@ -691,6 +697,8 @@ def main():
       size = None
       if cfg == 3 and world == 1:
         size = 8192                                      # one GPU's share of configs[3] on an 8-GPU node
+      if os.environ.get('BLE_BENCH_SIDE_ENVS') and cfg in (3, 4):
+        size = int(os.environ['BLE_BENCH_SIDE_ENVS'])    # (tests: the side legs' code path at a small batch)
       # side legs time 192-step regions after 32 warm-up steps whatever --steps / --warmup say (the default run's shape: six
       # 32-step launches on one rank): a 20-step region of a 10 us-per-step shard is 0.2 ms, of which the host's launch +
       # synchronise is 12 %, and five warm-up steps leave the first repetitions on a cold clock
@@ -706,6 +714,17 @@ def main():
         pl = policy_in_the_loop_leg(r)
         configs[key]['one_launch_per_step'] = {'us_per_step_back_to_back': pl['us_per_step_back_to_back'], 'env_steps_per_s': pl['env_steps_per_s'],
                                                'us_per_launch_event_median': pl['us_per_launch_event_median']}
+      if world == 1 and args.observe > 0 and cfg in (1, 3, 4):
+        # the closed loop every drop-in agent sees -- step + wind noise + observation with a full WindGP window -- at THIS config's
+        # batch size (so that a multi-GPU run of configs[3] / [4] can be read against a one-GPU closed-loop number)
+        ol = observe_leg(r, min(args.observe, 6), world)
+        observe_configs[key] = {'envs': s['envs_per_gpu'], 'per_env_grids': cfg == 4,
+                                'ms_per_observation_launch': ol['ms_per_observation_launch'], 'ms_per_step_plus_observation': ol['ms_per_step_plus_observation'],
+                                'env_steps_per_s_with_observation': ol['env_steps_per_s_with_observation'], 'env_observations_per_s': ol['env_observations_per_s'],
+                                'fp64_frac_algorithmic': ol['roofline']['frac'], 'executed_mfma_tflops': ol['roofline']['executed_mfma_tflops'],
+                                'hbm_gbs_algorithmic': ol['roofline']['hbm_gbs_algorithmic'], 'window_observations': ol['window_observations'],
+                                'live_env_fraction': ol['live_env_fraction']}
+        configs[key]['closed_loop'] = observe_configs[key]
       del r
       torch.cuda.empty_cache()
       if cfg != 4:       # the same leg in the reference's own wind (noise generated in-kernel; the ten harmonics on the four waves)
@@ -773,6 +792,8 @@ def main():
       out['policy_in_the_loop'] = policy
     if observe is not None:
       out['observe'] = observe
+    if observe_configs:
+      out['observe_configs'] = observe_configs
     if world == 1 and not args.no_cpu_baseline and not args.no_extras:
       acts = np.random.default_rng(7).integers(0, 3, (64, n)).astype(np.uint8)
       out['cpu_baseline'] = cpu_baseline(head_initial_host_state, list(acts), field)     # the SAME initial states the GPU flew

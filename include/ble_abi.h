@@ -335,6 +335,16 @@ typedef struct ble_gp_history_f32 {
 int ble_observe_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride,
                     const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,
                     int append, float* obs, uint32_t* err_flags, int64_t n, void* stream);
+/* ... for a forecast that is NOT a grid (ABI 5).  The reference's feature constructor takes any wind_field.WindField
+ * (features.py:290-299) and asks it for the column above the balloon, forecast.get_forecast_column(x, y, 181 levels, elapsed)
+ * (features.py:499-503 -> wind_gp.py:218-222) -- e.g. the SimpleStaticWindField of its unit tests (wind_field.py:149-184), a step
+ * function of pressure that no (21, 21, 10, 9) grid reproduces.
+ *   forecast_levels  optional [n][181][2] float32: the caller's forecast (u, v) [m/s] at the levels 5 000 + 50 k Pa, k = 0 .. 180, at each
+ *                    environment's position and time.  NULL: the column comes from wind_grid, as in ble_observe_f32 (which is this
+ *                    call with NULL).  wind_grid must be a valid grid either way (its column is then computed and not used). */
+int ble_observe_forecast_f32(const ble_state_f32* st, const float* wind_grid, int64_t grid_env_stride, const float* forecast_levels,
+                             const float* noise_uv, const uint8_t* reset_mask, const ble_gp_history_f32* hist,
+                             int append, float* obs, uint32_t* err_flags, int64_t n, void* stream);
 
 /*
  * Tail of the wind-field VAE decoder (generative/vae.py:149-186, Decoder.__call__ after the
@@ -365,6 +375,16 @@ int ble_wind_noise_f32(const float* x_m, const float* y_m, const float* pressure
 int ble_wind_noise_at_f32(const float* x_m, const float* y_m, const float* pressure, const int32_t* elapsed_s,
                           unsigned long long seed, const uint32_t* episode, int mode, uint32_t* harmonic_cache,
                           float* noise_uv, int64_t env_offset, int64_t n, void* stream);
+
+/*
+ * Rows of the struct-of-arrays state as records (ABI 5): out[count][BLE_ROW_DOUBLES] doubles, row r = environment first + r, the 26
+ * per-environment members of ble_state_f32 in the struct's order (x ... power_paused), every value converted exactly (float32, int32,
+ * int64 seconds < 2^53 and bytes are all doubles).  What a host consumer that wants ONE balloon as an object -- BalloonArena.
+ * get_balloon_state / get_simulator_state (env/balloon_arena.py:204-226), the evaluation loop's per-step read (eval/eval_lib.py:163) --
+ * copies back in one transfer instead of 26.
+ */
+#define BLE_ROW_DOUBLES 26
+int ble_state_rows_f64(const ble_state_f32* st, int64_t first, int64_t count, double* out, int64_t n, void* stream);
 
 /* power_table.lookup (env/balloon/power_table.py:21-38). watts out as float. */
 int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charge, float* watts,
@@ -397,6 +417,15 @@ int ble_probe_thermal_f32(const float* volume, const float* t_int, const float* 
 /* calculate_superpressure_and_volume (balloon.py:552-609) */
 int ble_probe_sp_volume_f32(const float* mols_air, const float* t_int, const float* pressure,
                             float* volume, float* superpressure, int64_t n, void* stream);
+/* ... with the function's own vehicle arguments (mols_lift_gas, envelope_volume_base, envelope_volume_dv_pressure: balloon.py:552-558)
+ * taken from `vehicle` (ABI 5; NULL = the defaults), and d_balloon_temperature_dt with its balloon_mass argument (thermal.py:175-181) =
+ * vehicle->envelope_mass */
+int ble_probe_sp_volume_vehicle_f32(const ble_vehicle* vehicle, const float* mols_air, const float* t_int, const float* pressure,
+                                    float* volume, float* superpressure, int64_t n, void* stream);
+int ble_probe_thermal_vehicle_f32(const ble_vehicle* vehicle, const float* volume, const float* t_int, const float* t_amb,
+                                  const float* pressure, const float* el_deg, const float* flux,
+                                  const float* upwelling_ir, float* dtdt, uint32_t* err_flags, int64_t n,
+                                  void* stream);
 /* acs.get_most_efficient_power / get_fan_efficiency / get_mass_flow (acs.py:44-68) */
 int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* efficiency,
                       float* mass_flow, int64_t n, void* stream);
@@ -415,6 +444,8 @@ int ble_probe_acs_f32(const float* pressure_ratio, float* power_w, float* effici
 int ble_probe_safety_f32(int layer, const uint8_t* action, const float* value, const float* alpha,
                          int32_t* clocks, double night_load_w, double capacity_wh, uint8_t* fsm,
                          uint8_t* effective_action, uint32_t* err_flags, int64_t n, void* stream);
+/* ABI 5: for layer 1 `alpha`, if not NULL, holds each element's maximum superpressure [Pa] (EnvelopeSafetyLayer.__init__'s argument,
+ * envelope_safety.py:100-107); NULL = the reference vehicle's 2 380 Pa. */
 
 /* The kernel's own fp64 primitives (reciprocal / rsqrt seeds and refinements, log, exp,
  * sincos), element-wise on device doubles.  op: 0 rcp seed, 1 rcp, 2 rsq seed, 3 rsqrt,

@@ -27,6 +27,14 @@ HE_MOLAR_MASS, AIR_MOLAR_MASS, R_GAS = 0.004002602, 0.028964922481160, 8.3144621
 TOL_M = 1e-5                                       # features.py:52
 
 
+def simple_static_wind_column(x, y, pressures, elapsed_s):
+  """SimpleStaticWindField.get_forecast (reference env/wind_field.py:149-184) at an array of pressures: four sheets blowing E / N / W / S
+  by pressure band."""
+  p = np.asarray(pressures, np.float64)
+  band = (p >= 8000.0).astype(int) + (p >= 10000.0) + (p >= 12000.0)
+  return np.array([10.0, 0.0, -10.0, 0.0])[band], np.array([0.0, 10.0, 0.0, -10.0])[band]
+
+
 def gp_kernel(a, b):                               # 3.6^2 * Matern(nu=0.5): s^2 exp(-|d / ls|)
   d = (a[:, None, :] - b[None, :, :]) / LENGTH_SCALE
   return SIGMA2 * np.exp(-np.sqrt((d * d).sum(-1)))
@@ -36,8 +44,15 @@ class FeatureOracle:
   """One environment.  `observe(row, err_uv)`: row is a dict of float64 state values in the
   units of ble_state_f32 (plus start_unix, time_elapsed_s), err_uv = measured - forecast."""
 
-  def __init__(self, field, alpha):
+  def __init__(self, field, alpha, vehicle=None, forecast_column=None):
+    """forecast_column: None (the forecast is the grid `field`) or a function (x m, y m, pressures Pa, elapsed s) -> (u, v) arrays: a
+    forecast that is not a grid, asked for its column like the reference does (features.py:499-503 -> WindField.get_forecast_column).
+    vehicle: None or a dict of the BalloonState vehicle fields that differ from the reference's defaults (oracle.VEHICLE_DEFAULTS):
+    the features read battery_soc and excess_energy (balloon.py:223-238), get_pressure_range the envelope, masses and lift gas."""
     self.field, self.alpha = field, float(alpha)
+    self.forecast_column = forecast_column
+    self.vehicle = dict(vehicle or {})
+    self.veh = dict(oracle.VEHICLE_DEFAULTS); self.veh.update(self.vehicle)
     self.locs, self.errs = [], []
     self.row = None
 
@@ -60,7 +75,10 @@ class FeatureOracle:
     mean = k_star @ scipy.linalg.cho_solve((chol, True), y)
     v = scipy.linalg.solve_triangular(chol, k_star.T, lower=True)
     var = np.maximum(SIGMA2 - (v * v).sum(0), 0.0)
-    fu, fv = oracle.wind_forecast(self.field, q[:, 0], q[:, 1], LEVELS, np.full(N_LEVELS, int(r['time_elapsed_s']), np.int64))
+    if self.forecast_column is not None:
+      fu, fv = self.forecast_column(r['x'], r['y'], LEVELS, int(r['time_elapsed_s']))
+    else:
+      fu, fv = oracle.wind_forecast(self.field, q[:, 0], q[:, 1], LEVELS, np.full(N_LEVELS, int(r['time_elapsed_s']), np.int64))
     mean[:, 0] += fu; mean[:, 1] += fv
     return mean, var / SIGMA2
 
@@ -71,7 +89,8 @@ class FeatureOracle:
     levels = np.linspace(1000.0, p_floor, 20)
     t_col = oracle.at_pressure(self.alpha, levels)[1]
     p_over_t = levels / t_col
-    target = (92.5 + 68.5 + 6830.0 * HE_MOLAR_MASS) * R_GAS / (AIR_MOLAR_MASS * 1804.0)
+    v = self.veh                                     # pressure_range_builder.py:236-245
+    target = (v['payload_mass'] + v['envelope_mass'] + v['mols_lift_gas'] * HE_MOLAR_MASS) * R_GAS / (AIR_MOLAR_MASS * v['envelope_volume_base'])
     i = int(np.clip(np.searchsorted(p_over_t, target), 1, 19))           # interp1d linear, extrapolating
     ceiling = (levels[i] - levels[i - 1]) / (p_over_t[i] - p_over_t[i - 1]) * (target - p_over_t[i - 1]) + levels[i - 1]
     now = int(r['start_unix']) + int(r['time_elapsed_s'])
@@ -80,11 +99,11 @@ class FeatureOracle:
       ps = np.atleast_1d(np.asarray(ps, np.float64)); n = ps.size
       out, _ = oracle.stable_init(ps, np.full(n, r['center_lat_deg']), np.full(n, r['center_lng_deg']), np.full(n, r['x']),
                                   np.full(n, r['y']), np.full(n, now, np.int64), np.full(n, r['upwelling_infrared']),
-                                  np.full(n, self.alpha))
+                                  np.full(n, self.alpha), vehicle=self.vehicle)
       return out['superpressure']
 
     sp_levels = superpressure(levels)
-    lo, hi = BUFFER_PA, MAX_SUPERPRESSURE - BUFFER_PA
+    lo, hi = BUFFER_PA, v['envelope_max_superpressure'] - BUFFER_PA          # :224-228
 
     def crossing(p1, s1, p2, s2):                                        # :73-108 (+ :43-70)
       if (s1 < lo) != (s2 < lo):
@@ -119,7 +138,7 @@ class FeatureOracle:
     now = int(r['start_unix']) + int(r['time_elapsed_s'])
     lat, lng = oracle.latlng_from_offset(math.radians(r['center_lat_deg']), math.radians(r['center_lng_deg']), r['x'], r['y'])
     el = float(oracle.solar_calculator(lat, lng, now)[0][0])
-    soc = r['battery_charge'] / 3058.56
+    soc = r['battery_charge'] / self.veh['battery_capacity_wh']
     out[0] = np.clip((r['pressure'] - P_MIN) / (P_MAX - P_MIN), 0.0, 1.0)
     out[1] = soc
     out[2] = np.clip((el + 90.0) / 180.0, 0.0, 1.0)
@@ -136,7 +155,7 @@ class FeatureOracle:
     out[8], out[9], out[10] = (float(int(r['last_command']) == c) for c in (2, 1, 0))
     paused = bool(r['power_paused']) or int(r['env_fsm']) != 0 or int(r['alt_fsm']) != 0
     out[11], out[12] = float(paused), float(not paused)
-    out[13] = float(float(oracle.solar_power(el, r['pressure'])[0][0]) > 120.4 and soc > 0.99)
+    out[13] = float(float(oracle.solar_power(el, r['pressure'])[0][0]) > self.veh['daytime_power_load_w'] and soc > 0.99)
     ratio = (r['pressure'] + max(r['superpressure'], 0.0)) / r['pressure']
     out[14] = np.clip((float(oracle.power_table(ratio, soc)[0][0]) - 100.0) / 200.0, 0.0, 1.0)
     out[15] = ratio

@@ -772,10 +772,107 @@ def f16_vehicles(n_steps=40):
       snap = snapshot(b.state, su)
       for k in SNAP_KEYS:
         cols[k][j, i + 1] = snap[k]
+  # ---- the observation of such a vehicle: PerciatelliFeatureConstructor (features.py:301-581) reads battery_soc (capacity),
+  # excess_energy (daytime load, capacity) and get_pressure_range (volume base, dV/dp, masses, lift gas, maximum superpressure)
+  from balloon_learning_environment.env import features
+  field = make_field(0)
+  n_obs = 8
+  nv = len(F16_VEHICLES)
+  obs_feats = np.zeros((nv, n_obs + 1, 1099), np.float32)
+  obs_cols = {k: np.zeros((nv, n_obs + 1)) for k in STATE_FLOATS}
+  for k in ('time_elapsed_s', 'sunrise_h', 'sunset'):
+    obs_cols[k] = np.zeros((nv, n_obs + 1), np.int64)
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused'):
+    obs_cols[k] = np.zeros((nv, n_obs + 1), np.uint8)
+  obs_wind = np.zeros((nv, n_obs + 1, 2)); obs_actions = rng.integers(0, 3, (nv, n_obs)).astype(np.uint8)
+  obs_consts = {k: np.zeros(nv) for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha')}
+  obs_start = np.zeros(nv, np.int64)
+  for j in range(nv):
+    so = dict(lat=float(rng.uniform(-10, 10)), lng=float(rng.uniform(-175, 175)), start=(day, night, dusk)[j % 3],
+              pressure=float(rng.uniform(7500, 10000)), x=float(rng.uniform(-1.5e5, 1.5e5)), y=float(rng.uniform(-1.5e5, 1.5e5)),
+              ir=float(rng.uniform(230, 320)), alpha=float(rng.uniform(0, 1)))
+    atm = ref_shims.make_atmosphere(so['alpha'])
+    wf = ref_shims.make_grid_wind_field(field)
+    st = balloon.BalloonState(center_latlng=s2.LatLng.from_degrees(so['lat'], so['lng']), date_time=so['start'],
+                              x=units.Distance(m=so['x']), y=units.Distance(m=so['y']), pressure=so['pressure'],
+                              upwelling_infrared=so['ir'], **f16_vehicle_kwargs(F16_VEHICLES[j]))
+    stable_init.cold_start_to_stable_params(st, atm)
+    if j % 2 == 0:       # a nearly full battery by day: excess_energy depends on the vehicle's capacity and daytime load
+      st.battery_charge = units.Energy(watt_hours=0.995 * st.battery_capacity.watt_hours)
+    b = balloon.Balloon(st)
+    su = int(so['start'].timestamp()); obs_start[j] = su
+    obs_consts['center_lat_deg'][j] = so['lat']; obs_consts['center_lng_deg'][j] = so['lng']
+    obs_consts['upwelling_infrared'][j] = so['ir']; obs_consts['alpha'][j] = so['alpha']
+    fc = features.PerciatelliFeatureConstructor(wf, atm)
+    for i in range(n_obs + 1):
+      if i > 0:
+        w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+        b.simulate_step(w, atm, control.AltitudeControlCommand(int(obs_actions[j, i - 1])), dt.timedelta(minutes=3))
+      w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+      obs_wind[j, i] = (w.u.mps + 1.2 * np.sin(0.4 * i + j), w.v.mps - 0.8 * np.cos(0.23 * i) + 0.1 * j)
+      fc.observe(simulator_data.SimulatorObservation(
+          balloon_observation=b.state, wind_at_balloon=wind_field.WindVector(units.Velocity(mps=float(obs_wind[j, i, 0])),
+                                                                            units.Velocity(mps=float(obs_wind[j, i, 1])))))
+      obs_feats[j, i] = fc.get_features()
+      snap = snapshot(b.state, su)
+      for k in SNAP_KEYS:
+        obs_cols[k][j, i] = snap[k]
+  obs = dict(obs_features=obs_feats, obs_wind_measured=obs_wind, obs_actions=obs_actions, obs_start_unix=obs_start, field_seed=np.int64(0),
+             field_scale=np.float64(5.0), **{'obs_' + k: v for k, v in obs_consts.items()}, **{'obs_' + k: v for k, v in obs_cols.items()})
   print(f'f16: {ns} trajectories over {len(F16_VEHICLES)} vehicles, {int(valid.sum())} reference steps, final status counts '
         f'{np.bincount(cols["status"][:, -1], minlength=4).tolist()}, paused at some step: {int((cols["power_paused"].max(axis=1) > 0).sum())}')
   save('f16_vehicles', vehicles=vehicles, vehicle_fields=np.array(F16_VEHICLE_FIELDS), vehicle_index=vehicle_index, actions=actions,
-       wind_uv=wind, reward=reward, valid=valid, start_unix=start_unix, **{'cold_' + k: v for k, v in cold.items()}, **consts, **cols)
+       wind_uv=wind, reward=reward, valid=valid, start_unix=start_unix, **{'cold_' + k: v for k, v in cold.items()}, **consts, **cols, **obs)
+
+
+# ----------------------------------------------------------------------------- F17
+def f17_static_wind_features(n_env=2, n_steps=14):
+  """PerciatelliFeatureConstructor (env/features.py:270-581) over a forecast that is NOT a grid: the reference's unit-test field,
+  SimpleStaticWindField (env/wind_field.py:149-184: four sheets blowing E / N / W / S by pressure band -- a step function of
+  pressure).  The constructor asks the WindField for its column above the balloon (features.py:499-503); balloons fly in the
+  forecast, the 'measured' wind adds a smooth pseudo-noise so that the WindGP has errors to model."""
+  from balloon_learning_environment.env import features
+  rng = np.random.default_rng(17)
+  feats = np.zeros((n_env, n_steps + 1, 1099), np.float32)
+  cols = {k: np.zeros((n_env, n_steps + 1)) for k in STATE_FLOATS}
+  for k in ('time_elapsed_s', 'sunrise_h', 'sunset'):
+    cols[k] = np.zeros((n_env, n_steps + 1), np.int64)
+  for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused'):
+    cols[k] = np.zeros((n_env, n_steps + 1), np.uint8)
+  wind_meas = np.zeros((n_env, n_steps + 1, 2)); forecast_at = np.zeros((n_env, n_steps + 1, 2))
+  consts = {k: np.zeros(n_env) for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha')}
+  start_unix = np.zeros(n_env, np.int64)
+  actions = rng.integers(0, 3, (n_env, n_steps)).astype(np.uint8)
+  starts = [units.datetime(2013, 3, 25, 9, 25, 32), units.datetime(2011, 7, 1, 22, 0, 5)]
+  wf = wind_field.SimpleStaticWindField.__new__(wind_field.SimpleStaticWindField)      # (no SimplexWindNoise: get_forecast only)
+  for j in range(n_env):
+    s = dict(lat=float(rng.uniform(-10, 10)), lng=float(rng.uniform(-175, 175)), start=starts[j % 2],
+             pressure=(7900.0, 9950.0)[j % 2], x=float(rng.uniform(-1e5, 1e5)), y=float(rng.uniform(-1e5, 1e5)),
+             ir=float(rng.uniform(230, 320)), alpha=float(rng.uniform(0, 1)), tweak=None)     # (next to a sheet boundary)
+    atm = ref_shims.make_atmosphere(s['alpha'])
+    b = balloon.Balloon(build_state(s, atm))
+    su = int(s['start'].timestamp()); start_unix[j] = su
+    consts['center_lat_deg'][j] = s['lat']; consts['center_lng_deg'][j] = s['lng']
+    consts['upwelling_infrared'][j] = s['ir']; consts['alpha'][j] = s['alpha']
+    fc = features.PerciatelliFeatureConstructor(wf, atm)
+    for i in range(n_steps + 1):
+      if i > 0:
+        w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+        b.simulate_step(w, atm, control.AltitudeControlCommand(int(actions[j, i - 1])), dt.timedelta(minutes=3))
+      w = wf.get_forecast(b.state.x, b.state.y, b.state.pressure, b.state.time_elapsed)
+      forecast_at[j, i] = (w.u.mps, w.v.mps)
+      wind_meas[j, i] = (w.u.mps + 1.1 * np.sin(0.35 * i + j), w.v.mps - 0.9 * np.cos(0.21 * i) + 0.15 * j)
+      fc.observe(simulator_data.SimulatorObservation(
+          balloon_observation=b.state, wind_at_balloon=wind_field.WindVector(units.Velocity(mps=float(wind_meas[j, i, 0])),
+                                                                            units.Velocity(mps=float(wind_meas[j, i, 1])))))
+      feats[j, i] = fc.get_features()
+      snap = snapshot(b.state, su)
+      for k in SNAP_KEYS:
+        cols[k][j, i] = snap[k]
+  bands = sorted({(float(a), float(c)) for a, c in forecast_at.reshape(-1, 2)})
+  print(f'f17: forecast sheets visited {bands}')
+  save('f17_static_wind_features', features=feats, wind_measured=wind_meas, forecast_at_balloon=forecast_at, actions=actions,
+       start_unix=start_unix, **consts, **cols)
 
 
 if __name__ == '__main__':
@@ -791,3 +888,5 @@ if __name__ == '__main__':
     f15_decoder()
   if 'all' in which or 'f16' in which:
     f16_vehicles()
+  if 'all' in which or 'f17' in which:
+    f17_static_wind_features()

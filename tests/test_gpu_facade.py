@@ -172,8 +172,8 @@ def test_feature_driven_controller_beats_random(mods):
   _, balloon_env, features, wind_field = mods
 
   def run(policy, seed):
-    env = balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=seed, feature_constructor_factory=_host_fc())
-    obs, total = env.reset(), 0.0
+    env = balloon_env.BalloonEnv(wind_field_factory=wind_field.SimpleStaticWindField, seed=seed)      # (every default: the device constructor
+    obs, total = env.reset(), 0.0                                                                       #  over a forecast that is not a grid)
     for _ in range(120):
       obs, r, terminal, _ = env.step(policy(obs))
       total += r

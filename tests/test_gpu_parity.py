@@ -646,6 +646,58 @@ def test_shards_reset_and_fly_what_the_unsharded_batch_does(ble):
   np.testing.assert_array_equal(np.concatenate([p.episode.cpu().numpy() for p, _ in parts]), whole.episode.cpu().numpy())
 
 
+def test_shards_decode_the_unsharded_batchs_per_env_wind_fields(ble):
+  """with per_env_fields=True every shard used to decode IDENTICAL wind fields (the latents came from one generator stream that
+  did not know the shard's offset).  The latents are keyed by (seed, GLOBAL environment index, episode) now: two VecBalloonArenas with
+  env_offset 0 / 96 hold exactly the grids of the 256-environment arena's lanes, after reset() and after a masked refresh; and the fields
+  of different environments differ."""
+  from balloon_learning_environment_amd.env import balloon_arena
+  n, cut = 256, 96
+  whole = balloon_arena.VecBalloonArena(n, seed=17, per_env_fields=True)
+  parts = [(balloon_arena.VecBalloonArena(cut, seed=17, per_env_fields=True, env_offset=0), slice(0, cut)),
+           (balloon_arena.VecBalloonArena(n - cut, seed=17, per_env_fields=True, env_offset=cut), slice(cut, n))]
+  for arena, sl in parts:
+    assert torch.equal(arena._grids, whole._grids[sl]), f'shard at {arena.sim.env_offset} after reset()'
+  flat = whole._grids.reshape(n, -1)
+  assert not torch.equal(flat[0], flat[cut]) and float((flat[0] - flat[cut]).abs().max()) > 0.1         # (what ADVICE r5 found equal)
+  assert len({float(v) for v in flat[:, 1234].cpu()}) > n - 4
+  mask = torch.from_numpy((np.random.default_rng(8).random(n) < 0.25).astype(np.uint8)).cuda()
+  before = whole._grids.clone()
+  whole.reset_lanes(mask); assert whole.refresh_fields() == int(mask.sum())
+  for arena, sl in parts:
+    arena.reset_lanes(mask[sl].contiguous()); arena.refresh_fields()
+    assert torch.equal(arena._grids, whole._grids[sl]), f'shard at {arena.sim.env_offset} after a masked refresh'
+  changed = (whole._grids.reshape(n, -1) != before.reshape(n, -1)).any(dim=1).cpu().numpy()
+  np.testing.assert_array_equal(changed, mask.cpu().numpy() != 0)
+
+
+def test_checkpoint_from_another_shard_offset_rekeys_noise(ble):
+  """load_state_dict takes the checkpoint's env_offset; the harmonic-draw cache (keyed by seed and episode, not by offset) and
+  the generators prepared launches hold are re-keyed with it -- a simulator that loads shard B's checkpoint flies shard B's noise."""
+  n, k = 512, 4
+  field = (np.random.default_rng(3).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(4).integers(0, 3, (k, n)).astype(np.uint8)).cuda()
+  b = ble.VecSimulator(n, env_offset=4096); b.set_grid(field); b.reset_device(seed=9)
+  ckpt = b.state_dict()
+  rb = torch.zeros(k, n, device='cuda'); tb = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
+  b.step_n(acts, rb, tb, noise_seed=7)
+  a = ble.VecSimulator(n, env_offset=0); a.set_grid(field); a.reset_device(seed=9)
+  ra = torch.zeros(k, n, device='cuda'); ta = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
+  launch = a.prepare_step_n(acts, ra, ta, noise_seed=7)
+  launch(); torch.cuda.synchronize()                 # shard A's own flight: fills A's draw cache for (seed 7, episode 1)
+  assert not torch.equal(ra, rb)
+  a.load_state_dict(ckpt)
+  assert a.env_offset == 4096
+  launch(); torch.cuda.synchronize(); a.check_errors()          # the PREPARED launch, after the load
+  assert torch.equal(ra, rb) and torch.equal(ta, tb)
+  sa, sb = a.get_state(), b.get_state()
+  for name in sa:
+    np.testing.assert_array_equal(sa[name], sb[name], err_msg=name)
+  bad = dict(ckpt, noise_primitive_version=1)
+  with pytest.raises(ValueError, match='noise primitive'):
+    a.load_state_dict(bad)
+
+
 def test_wide_domain_states_every_env(ble):
   """16 385 environments drawn far outside the flight envelope (helpers.wide_domain_states): from 1 200 Pa (above the
   atmosphere window's 21 km) to 40 000 Pa, 85 deg of latitude, beyond the wind grid, 110 h into the episode, safety layers

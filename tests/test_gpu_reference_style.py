@@ -164,8 +164,17 @@ def test_safety_layers_like_the_reference(mods):
     layer = envelope_safety.EnvelopeSafetyLayer(max_superpressure=2380.0)
     assert layer.get_action(cmd(action), sp) == cmd(expected), (sp, action)
     assert layer.navigation_is_paused == (not 300.0 <= sp < 2080.0)
-  with pytest.raises(NotImplementedError):
-    envelope_safety.EnvelopeSafetyLayer(max_superpressure=2000.0)       # the device layer's envelope is a kernel constant
+  # another envelope (ABI 5: the layer's maximum superpressure is an input of the device function): the reference's bands move with it
+  # (envelope_safety.py:40-50,109-137: HIGH from max - 250 - 50 with hysteresis, HIGH_CRITICAL from max - 150)
+  for max_sp in (2000.0, 2600.0):
+    for sp, action, expected in ((max_sp - 100.0, 0, 2), (max_sp - 100.0, 1, 2), (max_sp - 200.0, 0, 1), (max_sp - 200.0, 2, 2),
+                                 (max_sp - 400.0, 0, 0), (200.0, 0, 1), (100.0, 1, 2)):
+      layer = envelope_safety.EnvelopeSafetyLayer(max_superpressure=max_sp)
+      assert layer.get_action(cmd(action), sp) == cmd(expected), (max_sp, sp, action)
+      assert layer.navigation_is_paused == (not 300.0 <= sp < max_sp - 300.0)
+  layer = envelope_safety.EnvelopeSafetyLayer(max_superpressure=2000.0)       # hysteresis: HIGH is left only below max - 300
+  assert layer.get_action(cmd.DOWN, 1800.0) == cmd.STAY and layer.get_action(cmd.DOWN, 1720.0) == cmd.STAY
+  assert layer.get_action(cmd.DOWN, 1690.0) == cmd.DOWN and not layer.navigation_is_paused
 
   alt = KA['altitude_safety']
   atmosphere = mods['atm'].Atmosphere(np.array([0, 0], np.uint32))      # altitude_safety_test.py:31 (jax key 0)

@@ -333,6 +333,53 @@ def test_f16_non_default_vehicles_teacher_forced():
   assert np.abs(st['pressure'] - d['pressure'][rows, 1]).max() > 1.0
 
 
+def test_f16_observation_of_non_default_vehicles():
+  """F16's observation part: the reference's PerciatelliFeatureConstructor on BalloonStates of other vehicles (battery_soc and
+  excess_energy read the capacity and the daytime load, get_pressure_range the envelope / masses / lift gas / maximum
+  superpressure) against the feature oracle with the same vehicle."""
+  import features_oracle
+  g = golden('f16_vehicles')
+  field = helpers.fixture_field(g)
+  worst = 0.0
+  for j in range(len(g['vehicles'])):
+    veh = helpers.fixture_vehicle(g, j)
+    fo = features_oracle.FeatureOracle(field, g['obs_alpha'][j], vehicle=veh)
+    plain = features_oracle.FeatureOracle(field, g['obs_alpha'][j])
+    for i in range(g['obs_features'].shape[1]):
+      row = {k: float(g['obs_' + k][j, i]) for k in STATE_FLOATS}
+      for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
+        row[k] = int(g['obs_' + k][j, i])
+      for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+        row[k] = float(g['obs_' + k][j])
+      row['start_unix'] = int(g['obs_start_unix'][j])
+      fu, fv = oracle.wind_forecast(field, row['x'], row['y'], row['pressure'], row['time_elapsed_s'])
+      err = (g['obs_wind_measured'][j, i, 0] - fu[0], g['obs_wind_measured'][j, i, 1] - fv[0])
+      fo.observe(row, err); plain.observe(row, err)
+      got = fo.features()
+      worst = max(worst, float(np.abs(got.astype(np.float64) - g['obs_features'][j, i]).max()))
+    if 'power_safety_layer_enabled' not in veh or len(veh) > 1:      # (a vehicle that differs only by the switch observes like the default one)
+      assert np.abs(plain.features().astype(np.float64) - g['obs_features'][j, -1]).max() > 1e-3
+  assert worst <= 2e-6, worst
+
+
+def test_f17_features_over_a_forecast_that_is_not_a_grid():
+  """F17: the reference's PerciatelliFeatureConstructor over its unit-test wind field, SimpleStaticWindField (a step function of
+  pressure, wind_field.py:149-184) -- the feature oracle with that forecast's own column."""
+  import features_oracle
+  g = golden('f17_static_wind_features')
+  worst = 0.0
+  for j in range(g['features'].shape[0]):
+    fo = features_oracle.FeatureOracle(None, g['alpha'][j], forecast_column=features_oracle.simple_static_wind_column)
+    for i in range(g['features'].shape[1]):
+      row = helpers.feature_row(g, j, i)
+      fu, fv = features_oracle.simple_static_wind_column(row['x'], row['y'], [row['pressure']], row['time_elapsed_s'])
+      assert (fu[0], fv[0]) == tuple(g['forecast_at_balloon'][j, i])
+      fo.observe(row, (g['wind_measured'][j, i, 0] - fu[0], g['wind_measured'][j, i, 1] - fv[0]))
+      worst = max(worst, float(np.abs(fo.features().astype(np.float64) - g['features'][j, i]).max()))
+  assert worst <= 2e-6, worst
+  assert len({tuple(v) for v in g['forecast_at_balloon'].reshape(-1, 2)}) >= 2      # the balloons cross a sheet boundary
+
+
 def test_f9_arena_step_with_grid_wind_field():
   d = golden('f9_arena')
   assert _check_traj(d, use_field=True) < 2e-9
