@@ -423,6 +423,17 @@ def policy_in_the_loop_leg(roll, launches=256):
                   'finish dispersion) is paid every step; the fused headline (ble_step_n_f32) pays it once per 32 steps'}
 
 
+_T0 = [time.perf_counter()]
+
+
+def tick(what):
+  """BLE_BENCH_TIMING=1: wall-clock seconds of every leg on stderr (where a run's time goes)."""
+  if os.environ.get('BLE_BENCH_TIMING'):
+    now = time.perf_counter()
+    print(f'[bench timing] rank {os.environ.get("RANK", "0")} {what}: {now - _T0[0]:.1f} s', file=sys.stderr, flush=True)
+    _T0[0] = now
+
+
 PMC_BUDGET_S = [240.0]      # wall-clock budget of ALL nested profiler passes of one bench.py run (--pmc-budget-s)
 
 
@@ -621,9 +632,11 @@ def main():
                    steps=steps or args.steps, warmup=args.warmup if warmup is None else warmup, substeps=args.substeps,
                    noise_seed=noise_seed)
 
+  tick('start-up (imports, process group, grid broadcast)')
   # ---- headline leg
   head = make(args.config, n=args.envs_per_gpu, noise_seed=args.noise_seed)
   hs = head.summary(args.reps)
+  tick('headline leg')
   n = head.n
   bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * (hs['live_env_steps_per_repetition'] / world / head.launches_per_region)
   achieved = bytes_per_launch / (hs['kernel_ms_mean'] * 1e-3) / 1e9      # the AVERAGE launch duration (HIP events on the launch stream)
@@ -647,6 +660,7 @@ def main():
   if world == 1 and args.traffic == 'auto' and not args.no_extras:
     issue, issue_note = measure_issue('ble_step_kernel', child, head.launches_per_region, groups=3,
                                       agent_steps_per_launch=args.steps / head.launches_per_region)
+  tick('nested PMC passes')
   if issue is None:            # labelled fallback: the committed profile of an earlier build, NOT this run
     for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
       try:
@@ -684,8 +698,10 @@ def main():
                               'evaluated inside ble_step_kernel<noise> (same launch shape, exchanges and counting as the headline)')
       configs[f'configs[{args.config}] in the ground-truth wind (noise in-kernel)'] = ground_truth
       del rn
+      tick('ground-truth-wind leg')
     if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
       observe = observe_leg(head, args.observe, world, measure=(args.traffic == 'auto'))
+      tick('observation leg')
     head_initial_host_state = head.initial_host_state() if (world == 1 and not args.no_cpu_baseline) else None
     del head
     torch.cuda.empty_cache()
@@ -702,7 +718,8 @@ def main():
       # side legs time 192-step regions after 32 warm-up steps whatever --steps / --warmup say (the default run's shape: six
       # 32-step launches on one rank): a 20-step region of a 10 us-per-step shard is 0.2 ms, of which the host's launch +
       # synchronise is 12 %, and five warm-up steps leave the first repetitions on a cold clock
-      r = make(cfg, n=size, steps=192, warmup=32)
+      side_steps = int(os.environ.get('BLE_BENCH_SIDE_STEPS', '192'))       # (tests: over gloo -- two ranks on one GPU -- every gather goes through the host)
+      r = make(cfg, n=size, steps=side_steps, warmup=32)
       s = r.summary(extra_reps)
       key = f'configs[{cfg}]' + (' per-GPU shard (8 192 of 65 536), 1 GPU' if (cfg == 3 and world == 1) else '')
       configs[key] = {k: s[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'envs_per_gpu', 'global_envs', 'ms_per_step', 'decode_ms',
@@ -725,20 +742,23 @@ def main():
                                 'hbm_gbs_algorithmic': ol['roofline']['hbm_gbs_algorithmic'], 'window_observations': ol['window_observations'],
                                 'live_env_fraction': ol['live_env_fraction']}
         configs[key]['closed_loop'] = observe_configs[key]
+      tick(f'side leg {key}')
       del r
       torch.cuda.empty_cache()
       if cfg != 4:       # the same leg in the reference's own wind (noise generated in-kernel; the ten harmonics on the four waves)
-        rg = make(cfg, n=size, steps=192, warmup=32, noise_seed=20240917)
+        rg = make(cfg, n=size, steps=side_steps, warmup=32, noise_seed=20240917)
         sg = rg.summary(max(3, extra_reps // 2))
         configs[key]['env_steps_per_s_ground_truth_wind'] = sg['env_steps_per_s']
         configs[key]['ms_per_step_ground_truth_wind'] = sg['ms_per_step']
         del rg
         torch.cuda.empty_cache()
+        tick(f'side leg {key} in the ground-truth wind')
     if rank == 0:
       try:
         configs['configs[0] counterpart: single-env facade'] = facade_leg()
       except Exception as e:            # the facade is not the measured product; never lose the line over it
         configs['configs[0] counterpart: single-env facade'] = {'error': repr(e)}
+      tick('facade leg')
 
   if rank == 0:
     out = {
@@ -797,6 +817,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and not args.no_extras:
       acts = np.random.default_rng(7).integers(0, 3, (64, n)).astype(np.uint8)
       out['cpu_baseline'] = cpu_baseline(head_initial_host_state, list(acts), field)     # the SAME initial states the GPU flew
+      tick('cpu baseline')
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()

@@ -58,7 +58,9 @@ def test_bench_gpus_2_default_legs_run_sharded():
   learner, rank-local), and the configs[3] / configs[4] legs -- two ranks on the box's one GPU over gloo, a small headline
   batch so that the test stays short."""
   out = _bench(['--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '3', '--observe', '2', '--envs-per-gpu', '2048'],
-               {'BLE_DIST_BACKEND': 'gloo', 'BLE_BENCH_SIDE_ENVS': '4096'}, timeout=900)      # (side legs at 4 096 per rank: the code path, not the rate)
+               {'BLE_DIST_BACKEND': 'gloo', 'BLE_BENCH_SIDE_ENVS': '4096', 'BLE_BENCH_SIDE_STEPS': '32'}, timeout=900)
+  # (side legs at 4 096 environments per rank and 32-step regions: the code path, not the rate -- over gloo every one of a 192-step
+  #  region's 24 gathers crosses the host, 0.1 s each: 57 s of this test's 60 were that)
   assert out['n_gpus'] == 2 and out['config']['envs_per_gpu'] == 2048 and out['config']['global_envs'] == 4096
   gt = out['config']['ground_truth_wind']
   assert gt is not None and gt['env_steps_per_s'] > 1e4 and gt['global_envs'] == 4096     # (gloo moves the gathers through the host)

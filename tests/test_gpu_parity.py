@@ -656,8 +656,14 @@ def test_shards_decode_the_unsharded_batchs_per_env_wind_fields(ble):
   whole = balloon_arena.VecBalloonArena(n, seed=17, per_env_fields=True)
   parts = [(balloon_arena.VecBalloonArena(cut, seed=17, per_env_fields=True, env_offset=0), slice(0, cut)),
            (balloon_arena.VecBalloonArena(n - cut, seed=17, per_env_fields=True, env_offset=cut), slice(cut, n))]
+  # (the latents are equal bit for bit; the decoder's four library GEMMs run at another batch size in a shard -- another tiling,
+  #  another summation order -- so the decoded winds agree to GEMM rounding, not to the bit)
+  sampler = whole.wind_field._wind_field_sampler
+  lat = sampler.sample_latents_keyed(torch.arange(n, device='cuda'), whole.sim.episode, whole._seed)
   for arena, sl in parts:
-    assert torch.equal(arena._grids, whole._grids[sl]), f'shard at {arena.sim.env_offset} after reset()'
+    idx = torch.arange(arena.num_envs, device='cuda')
+    assert torch.equal(sampler.sample_latents_keyed(idx + arena.sim.env_offset, arena.sim.episode, arena._seed), lat[sl])
+    assert float((arena._grids - whole._grids[sl]).abs().max()) <= 1e-3, f'shard at {arena.sim.env_offset} after reset()'
   flat = whole._grids.reshape(n, -1)
   assert not torch.equal(flat[0], flat[cut]) and float((flat[0] - flat[cut]).abs().max()) > 0.1         # (what ADVICE r5 found equal)
   assert len({float(v) for v in flat[:, 1234].cpu()}) > n - 4
@@ -666,7 +672,7 @@ def test_shards_decode_the_unsharded_batchs_per_env_wind_fields(ble):
   whole.reset_lanes(mask); assert whole.refresh_fields() == int(mask.sum())
   for arena, sl in parts:
     arena.reset_lanes(mask[sl].contiguous()); arena.refresh_fields()
-    assert torch.equal(arena._grids, whole._grids[sl]), f'shard at {arena.sim.env_offset} after a masked refresh'
+    assert float((arena._grids - whole._grids[sl]).abs().max()) <= 1e-3, f'shard at {arena.sim.env_offset} after a masked refresh'
   changed = (whole._grids.reshape(n, -1) != before.reshape(n, -1)).any(dim=1).cpu().numpy()
   np.testing.assert_array_equal(changed, mask.cpu().numpy() != 0)
 
