@@ -33,7 +33,7 @@ NOISE_CACHE_ROWS = 53
 
 # every symbol include/ble_abi.h declares
 EXPORTS = ('ble_abi_version', 'ble_noise_primitive_version', 'ble_vehicle_default', 'ble_last_hip_error', 'ble_device_count', 'ble_set_step_form', 'ble_step_f32', 'ble_step_n_f32', 'ble_reset_f32', 'ble_reset_at_f32', 'ble_wind_noise_at_f32', 'ble_observe_f32', 'ble_observe_forecast_f32', 'ble_decode_flow_fields_f32', 'ble_wind_noise_f32', 'ble_forecast_f32',
-           'ble_forecast_column_f32', 'ble_state_rows_f64', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
+           'ble_forecast_column_f32', 'ble_state_rows_f64', 'ble_power_table_f32', 'ble_probe_atmosphere_f32', 'ble_probe_atmosphere_at_height_f64', 'ble_probe_solar_f32', 'ble_probe_latlng_f64',
            'ble_probe_solar_power_f32', 'ble_probe_thermal_f32', 'ble_probe_sp_volume_f32', 'ble_probe_thermal_vehicle_f32', 'ble_probe_sp_volume_vehicle_f32', 'ble_probe_acs_f32', 'ble_probe_safety_f32',
            'ble_probe_f64_prims')
 
@@ -104,6 +104,7 @@ def lib():
   l.ble_power_table_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_state_rows_f64.argtypes = [st, _i64, _i64, _vp, _i64, _vp]
   l.ble_probe_atmosphere_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _vp]
+  l.ble_probe_atmosphere_at_height_f64.argtypes = [_vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_latlng_f64.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
   l.ble_probe_solar_power_f32.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp]

@@ -329,6 +329,13 @@ __global__ __launch_bounds__(256) void probe_atmosphere_kernel(const float* alph
   }
   report_flags(flags, err_flags);
 }
+__global__ __launch_bounds__(256) void probe_at_height_kernel(const float* alpha, const double* height, double* pressure, double* temperature,
+                                                              uint32_t* err_flags, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t flags = 0;
+  if (i < n) atm_at_height_f64((double)alpha[i], height[i], &pressure[i], &temperature[i], &flags);
+  report_flags(flags, err_flags);
+}
 __global__ __launch_bounds__(256) void probe_solar_kernel(const float* lat0, const float* lng0, const float* x,
                                                           const float* y, const int64_t* unix_s, float* el_deg,
                                                           float* flux, int64_t n) {
@@ -772,7 +779,8 @@ int ble_vehicle_default(ble_vehicle* v) {
 int ble_last_hip_error(void) { return g_last_hip_error; }
 
 int ble_set_step_form(int waves_per_env) {
-  if (waves_per_env != 0 && waves_per_env != 1 && waves_per_env != 4 && !(kHavePairForm && waves_per_env == 2)) return BLE_E_INVALID_ARG;
+  if (waves_per_env != 0 && waves_per_env != 1 && waves_per_env != 4 && !(kHavePairForm && waves_per_env == 2))
+    return BLE_E_INVALID_ARG;
   const int before = step_form();
   g_step_form.store(waves_per_env, std::memory_order_relaxed);
   return before;
@@ -945,6 +953,14 @@ int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* h
   if (n == 0) return BLE_OK;
   BLE_LAUNCH(probe_atmosphere_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, pressure,
                      height, temperature, err_flags, n);
+  return launch_status();
+}
+
+int ble_probe_atmosphere_at_height_f64(const float* alpha, const double* height_m, double* pressure, double* temperature, uint32_t* err_flags,
+                                       int64_t n, void* stream) {
+  if (!alpha || !height_m || !pressure || !temperature || n < 0) return BLE_E_INVALID_ARG;
+  if (n == 0) return BLE_OK;
+  BLE_LAUNCH(probe_at_height_kernel, dim3(blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, alpha, height_m, pressure, temperature, err_flags, n);
   return launch_status();
 }
 

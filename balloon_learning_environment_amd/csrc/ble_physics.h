@@ -474,6 +474,29 @@ BLE_FN AtmWindow atm_window_from(const AtmBase& b, double alpha, double p, uint3
 BLE_FN AtmWindow atm_window(double alpha, double p, uint32_t* flags) {
   return atm_window_from(atm_base(alpha), alpha, p, flags);
 }
+// Atmosphere.at_height (standard_atmosphere.py:89-120): pressure and temperature at a height, walking the layers from the ground like
+// the reference's transition tables (:169-202).  fp64; used once per episode on the host side (the 50 000 ft bound of the initial-condition
+// sampler) -- the transition itself only ever goes from pressure to height.
+BLE_FN void atm_at_height_f64(double alpha, double h, double* pressure, double* temperature, uint32_t* flags) {
+  const double g = 9.80665;
+  *flags |= !(h >= -610.0 && h < atm_height_f64c(7)) ? kFlagPressureRange : 0u;      // (the reference asserts the same range, :94-95)
+  double t_base = 300.0, p_base = 108870.8213, p = 0.0, t = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < 7; ++i) {
+    const double lapse = atm_lapse_f64(i, alpha);
+    const double top = atm_height_f64c(i + 1);
+    const bool here = h < top || i == 6;
+    const double dh = (here ? h : top) - atm_height_f64c(i);
+    t = t_base + lapse * dh;
+    if (lapse == 0.0)
+      p = p_base * d_exp_fast(-(g * dh) * d_rcp(kAirSpecificGasD * t));
+    else
+      p = p_base * d_pow_fast(t * d_rcp(t_base), -g * d_rcp(kAirSpecificGasD * lapse));
+    if (here) break;
+    t_base = t; p_base = p;
+  }
+  *pressure = p; *temperature = t;
+}
 // height and temperature at p inside layer i0 of the window (standard_atmosphere.py:135-150)
 BLE_FN void atm_at_pressure_f64(const AtmWindow& w, double alpha, double p, double* height, double* temperature) {
   (void)alpha;

@@ -42,6 +42,20 @@ def atmosphere(alpha, pressure):
   return float(h.item()), float(t.item())
 
 
+def atmosphere_at_height(alpha, height_m):
+  """Atmosphere.at_height -> (pressure Pa, temperature K), float64 on the device (`ble_probe_atmosphere_at_height_f64`); raises like the
+  reference outside the model's range."""
+  dev.require_gpu('cuda')
+  a, = _f32(alpha)
+  h = torch.tensor([float(height_m)], dtype=torch.float64, device='cuda')
+  out, flags = torch.empty(2, dtype=torch.float64, device='cuda'), _flags()
+  _lib.check(_lib.lib().ble_probe_atmosphere_at_height_f64(a.data_ptr(), h.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), flags.data_ptr(), 1,
+                                                           _stream()), 'ble_probe_atmosphere_at_height_f64')
+  _raise(flags)
+  p, t = out.cpu().tolist()
+  return p, t
+
+
 def latlng(center_lat_deg, center_lng_deg, x_m, y_m):
   """BalloonState.latlng: (lat deg, lng deg) of the point (x, y) metres east / north of the centre."""
   dev.require_gpu('cuda')

@@ -2,8 +2,9 @@
 
 `at_pressure` -- the lookup the transition makes every stride -- runs the kernel's own device function
 (`ble_probe_atmosphere_f32`); `at_height` (needed once per episode: the 50 000 ft pressure bound of the initial-condition
-sampler, utils/sampling.py:86-117, which the reset kernel has inline) INVERTS that same device function by bracketing --
-four launches of 4 096 pressures -- so that the package holds one implementation of the atmosphere, the device's."""
+sampler, utils/sampling.py:86-117, which the reset kernel has inline) is the float64 device function
+`ble_probe_atmosphere_at_height_f64` (ABI 5: the layer walk of the reference's transition tables; rounds 4-5 inverted the
+float32 lookup by bracketing, 1e-7)."""
 import dataclasses
 
 import numpy as np
@@ -34,24 +35,8 @@ class AtmosphereOps:
   def at_height(self, height: units.Distance) -> AtmosphericValues:
     from balloon_learning_environment_amd.env.balloon import _probes
     h = float(height.meters)
-    assert -610.0 <= h < 85000.0, 'Atmosphere.at_height: height out of range (standard_atmosphere.py:94-95)'
-    # height falls monotonically with pressure: bracket h on a geometric pressure grid and refine; the device evaluates in
-    # fp64 and returns float32 (resolution 1 mm at 15 km), a float32 pressure resolves 6e-8 relative
-    lo, hi = 0.3, 120000.0                                   # Pa: 85 km .. -610 m
-    for _ in range(4):
-      ps = np.geomspace(lo, hi, 4096)
-      hs, _ = _probes.atmosphere_column(self.alpha, ps)
-      ok = np.isfinite(hs)
-      k = int(np.searchsorted(-hs[ok], -h))                   # first grid pressure whose height is <= h
-      ps_ok = ps[ok]
-      k = min(max(k, 1), ps_ok.size - 1)
-      lo, hi = float(ps_ok[k - 1]), float(ps_ok[k])
-    (h0, h1), (t0, t1) = _probes.atmosphere_column(self.alpha, [lo, hi])
-    w = 0.0 if h0 == h1 else (h0 - h) / (h0 - h1)
-    pressure = lo * (hi / lo) ** w
-    temperature = t0 + w * (t1 - t0)
-    return AtmosphericValues(units.Distance(meters=h), float(temperature), float(pressure),
-                             float(pressure) / (DRY_AIR_SPECIFIC_GAS_CONSTANT * float(temperature)))
+    pressure, temperature = _probes.atmosphere_at_height(self.alpha, h)      # raises AssertionError out of range, like :94-95
+    return AtmosphericValues(units.Distance(meters=h), temperature, pressure, pressure / (DRY_AIR_SPECIFIC_GAS_CONSTANT * temperature))
 
 
 class Atmosphere(AtmosphereOps):

@@ -662,7 +662,7 @@ def main():
                                       agent_steps_per_launch=args.steps / head.launches_per_region)
   tick('nested PMC passes')
   if issue is None:            # labelled fallback: the committed profile of an earlier build, NOT this run
-    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for tag in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
       try:
         d = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json')))['derived']
         per = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_summary.json'))).get('agent_steps_per_profiled_launch', 32.0)

@@ -397,6 +397,11 @@ int ble_power_table_f32(const float* pressure_ratio, const float* state_of_charg
 /* Atmosphere.at_pressure (standard_atmosphere.py:122-154): height [m], temperature [K] */
 int ble_probe_atmosphere_f32(const float* alpha, const float* pressure, float* height,
                              float* temperature, uint32_t* err_flags, int64_t n, void* stream);
+/* Atmosphere.at_height (standard_atmosphere.py:89-120): pressure [Pa] and temperature [K] at heights [m], float64 (ABI 5; until then the
+ * host mirror inverted ble_probe_atmosphere_f32 by bracketing its float32 outputs: 1e-7).  Heights outside [-610 m, 84 852 m) set
+ * BLE_FLAG_PRESSURE_RANGE (the reference asserts, :94-95). */
+int ble_probe_atmosphere_at_height_f64(const float* alpha, const double* height_m, double* pressure, double* temperature,
+                                       uint32_t* err_flags, int64_t n, void* stream);
 /* solar_calculator at BalloonState.latlng (solar.py:43-174, spherical_geometry.py:44-76):
  * sin/cos of the refraction-corrected elevation, elevation [deg] and flux [W/m^2] */
 int ble_probe_solar_f32(const float* center_lat_deg, const float* center_lng_deg, const float* x_m,

@@ -47,8 +47,19 @@ def rows(d, s):
       f"**{sci(c3['env_steps_per_s'])}** ({c3['ms_per_step'] * 1e3:.2f} µs per step; {sci(c3['env_steps_per_s_ground_truth_wind'])} in the ground-truth wind)",
       f"**{sci(c4['env_steps_per_s'])}** ({c4['ms_per_step'] * 1e3:.1f} µs per step)",
       f"{sci(o['env_steps_per_s_with_observation'])} env-steps/s (observation launch {o['ms_per_observation_launch_median']:.2f} ms)",
+      closed_loops(d),
       f"{sci(cpu['value'])}; {sci(cpu['value_single_thread'])}",
   ]
+
+
+def closed_loops(d):
+  """step + noise + observation at the other configs' batch sizes (bench.py `observe_configs`, round 6)."""
+  oc = d.get('observe_configs') or {}
+  parts = []
+  for k, v in oc.items():
+    parts.append(f"{v['envs']:,}".replace(',', ' ') + (' (per-env grids)' if v['per_env_grids'] else '') +
+                 f": {sci(v['env_steps_per_s_with_observation'])} ({v['ms_per_observation_launch']:.2f} ms per observation launch, fp64 frac {v['fp64_frac_algorithmic']:.2f})")
+  return '; '.join(parts) if parts else 'n/a'
 
 
 LABELS = [
@@ -60,6 +71,7 @@ LABELS = [
     'configs[3]: one GPU\'s share, 8 192 envs (four-wave kernel)',
     'configs[4]: one GPU\'s share, 32 768 envs with per-env grids (four-wave kernel, two waves per SIMD)',
     'closed loop: step + noise + observation, 65 536 envs',
+    'closed loop at the other configs\' sizes: 4 096 (configs[1]) / 8 192 (configs[3] share) / 32 768 with per-env grids (configs[4] share)',
     'CPU baseline (fp64 C oracle, 16 threads; 1 thread)',
 ]
 

@@ -13,8 +13,16 @@ out = ['# Kernel resource usage of libble_hip.so (hipcc --offload-arch=gfx950 -O
        '| kernel | ' + ' | '.join(k for k, _ in keys) + ' |', '|' + '---|' * (len(keys) + 1)]
 for b in blocks:
   mangled = b.split()[0]
-  m = re.search(r'(\d+)(ble_\w+kernel|probe_\w+kernel)(ILb([01])E)?', mangled)
-  name = (m.group(2) + ('<%s>' % ('true' if m.group(4) == '1' else 'false') if m.group(3) else '')) if m else mangled
+  m = re.search(r'(\d+)(ble_\w+kernel|probe_\w+kernel)', mangled)
+  name = mangled
+  if m:      # template arguments: a bool (noise generated in-kernel) and / or the vehicle carrier (ABI 5: compile-time defaults | run-time struct)
+    targs = mangled[m.end():].split('StateDev')[0].split('SplitArgs')[0]          # (what stands between the name and the first parameter)
+    args = []
+    if targs.startswith('ILb1E'): args.append('noise')
+    elif targs.startswith('ILb0E'): args.append('no noise')
+    if 'VehicleRt' in targs: args.append('VehicleRt')
+    elif 'VehicleDefault' in targs: args.append('VehicleDefault')
+    name = m.group(2) + ('<' + ', '.join(args) + '>' if args else '')
   out.append('| `' + name + '` | ' + ' | '.join(re.search(pat + r': (\d+)', b).group(1) for _, pat in keys) + ' |')
 text = '\n'.join(out) + '\n'
 open(sys.argv[1], 'w').write(text) if len(sys.argv) > 1 else None

@@ -46,6 +46,16 @@ def test_standard_atmosphere_like_the_reference(mods):
   for h in KA['atmosphere_out_of_range']['heights_raise']:
     with pytest.raises(AssertionError):
       atmospheres[1].at_height(units.Distance(meters=h))
+  # the reference's own at_height values (fixture F1, float64): the device's float64 layer walk (ble_probe_atmosphere_at_height_f64)
+  import helpers
+  d = helpers.golden('f1_atmosphere')
+  for i, alpha in enumerate(d['alphas']):
+    atmospheres[5].alpha = float(alpha)       # (float32 on its way to the device: alphas of the fixture that are float32 numbers compare at 1e-12)
+    exact = float(np.float32(alpha)) == float(alpha)
+    for j in range(0, d['heights'].size, 5):
+      v = atmospheres[5].at_height(units.Distance(meters=float(d['heights'][j])))
+      tol = 1e-12 if exact else 1e-6
+      assert abs(v.pressure - d['p_of_h'][i, j]) <= tol * d['p_of_h'][i, j] and abs(v.temperature - d['t_of_h'][i, j]) <= tol * d['t_of_h'][i, j], (alpha, j)
   # at_pressure(at_height(h).pressure) gives h back (device lookup against host tables)
   for h in (12000.0, 17500.0, 19000.0):
     a = atmospheres[2]
