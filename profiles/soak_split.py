@@ -52,4 +52,4 @@ for t in range(steps):
     compared += 1
 _lib.set_step_form(None)
 print(f'soak: {n} environments x {steps} agent steps ({n * steps:.3g} env-steps per kernel form), {compared} full comparisons of every state array: '
-      f'one lane == four waves == two waves bit for bit; {ended} episodes ended and were restarted; no error flag')
+      f'one lane == ' + ' == '.join({'4': 'four waves', '2': 'two waves'}[m] for m in ('4',) + (('2',) if os.environ.get('BLE_WITH_PAIR_FORM') else ())) + ' bit for bit;' + f' {ended} episodes ended and were restarted; no error flag')

@@ -107,7 +107,8 @@ def test_observe_long_horizon_matches_reference(vec_state, carry):
 @pytest.mark.parametrize('carry', [True, False])
 def test_observe_rollout_matches_oracle(vec_state, carry):
   """48 environments flown by the step kernel for 130 agent steps with random actions and a
-  random measured-minus-forecast term; every 10th step (and the last 12) is compared."""
+  random measured-minus-forecast term; every 10th step (and the last 12) a rotating sixth of them is compared (200 oracle vectors of
+  66 ms each)."""
   import features_oracle
   n, steps = 48, 130
   rng = np.random.default_rng(5)
@@ -135,7 +136,7 @@ def test_observe_rollout_matches_oracle(vec_state, carry):
       for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
         row[k] = int(state[k][j])
       oracles[j].observe(row, noise[j].astype(np.float64))
-      if compare and alive[j] and j % 4 == i % 4:
+      if compare and alive[j] and j % 6 == i % 6:
         want = oracles[j].features()
         err = check(obs[j], want, f'env {j} step {i}')
         worst = max(worst, err.max())
