@@ -147,7 +147,7 @@ class Rollout:
   """One preset's workload on this rank: state + grid resident in HBM, `time_reps` runs the timed region."""
 
   def __init__(self, n, device, rank, world, *, per_env_grids=False, shared_field=None, seed_base=1000,
-               steps=192, warmup=32, substeps=18, noise_seed=None, env_offset=None):
+               steps=192, warmup=32, substeps=18, noise_seed=None, env_offset=None, vehicle=None):
     import numpy as np
     import torch
     from balloon_learning_environment_amd import distributed as bdist
@@ -165,6 +165,8 @@ class Rollout:
     # distributions from a Philox stream keyed by (seed, global env index, episode)), resident in HBM.  The legs that
     # restart the episodes copy this snapshot back.  (Rounds 1-4 drew them with a NumPy sampler that is test tooling now.)
     self.sim = vec_state.VecSimulator(n, device, env_offset=self.env_offset)
+    if vehicle:           # a flight vehicle other than the reference's default (ABI 5): the kernels' VehicleRt instantiations
+      self.sim.set_vehicle(**vehicle)
     self.sim.reset_device(seed=seed_base)
     self.sim.check_errors()
     self.initial_state = {k: t.clone() for k, t in self.sim.state.items()}
@@ -626,11 +628,11 @@ def main():
   def preset_size(cfg):
     return bdist.preset_layout(cfg, rank, world)['n_local']
 
-  def make(cfg, n=None, steps=None, warmup=None, noise_seed=None):
+  def make(cfg, n=None, steps=None, warmup=None, noise_seed=None, vehicle=None):
     n = n if n is not None else preset_size(cfg)
     return Rollout(n, device, rank, world, per_env_grids=(cfg == 4 or args.per_env_grids), shared_field=grid,
                    steps=steps or args.steps, warmup=args.warmup if warmup is None else warmup, substeps=args.substeps,
-                   noise_seed=noise_seed)
+                   noise_seed=noise_seed, vehicle=vehicle)
 
   tick('start-up (imports, process group, grid broadcast)')
   # ---- headline leg
@@ -699,6 +701,18 @@ def main():
       configs[f'configs[{args.config}] in the ground-truth wind (noise in-kernel)'] = ground_truth
       del rn
       tick('ground-truth-wind leg')
+    if world == 1 and args.noise_seed is None and not (args.config == 4 or args.per_env_grids):
+      # the same rollout with a flight vehicle handed in at run time (ABI 5: ble_state_f32.vehicle -> ble_step_kernel<VehicleRt>, its constants
+      # in scalar registers instead of the instruction stream): another skin, drag coefficient, power system and valve
+      veh = dict(envelope_max_superpressure=2500.0, envelope_cod=0.27, nighttime_power_load_w=150.0, daytime_power_load_w=110.0,
+                 acs_valve_hole_diameter_m=0.05, battery_capacity_wh=3400.0)      # (the default envelope and masses: the sampler's pressures suit it)
+      rv = make(args.config, n=args.envs_per_gpu, vehicle=veh)
+      sv = rv.summary(extra_reps)
+      configs[f'configs[{args.config}] with a run-time vehicle (ABI 5)'] = dict(
+          {k: sv[k] for k in ('env_steps_per_s', 'env_steps_per_s_min', 'env_steps_per_s_max', 'ms_per_step', 'kernel_ms_mean', 'envs_per_gpu', 'live_env_fraction_end')},
+          kernel='ble_step_kernel<VehicleRt> (one lane per environment whatever the batch size)', vehicle=veh)
+      del rv
+      tick('run-time vehicle leg')
     if args.observe > 0 and not (args.config == 4 or args.per_env_grids):
       observe = observe_leg(head, args.observe, world, measure=(args.traffic == 'auto'))
       tick('observation leg')

@@ -42,6 +42,7 @@ def rows(d, s):
       f"**{sci(head['env_steps_per_s'])} env-steps/s ({head['ms_per_step'] * 1e3:.2f} µs per step of wall clock; kernel {r['kernel_ms']:.3f} ms per "
       f"{spl}-step launch by HIP events; rocprofv3 {prof['avg_us']:.0f} µs average under the profiler)**",
       f"{sci(gt['env_steps_per_s'])} ({gt['ms_per_step'] * 1e3:.1f} µs per step)",
+      vehicle_leg(c),
       f"{sci(one['env_steps_per_s'])} ({one['us_per_step_back_to_back']:.1f} µs per step back to back; an isolated launch "
       f"{one['us_per_launch_event_median']:.1f} µs between an event pair; rocprofv3 {s['kernel_trace_1_step_launches']['avg_us']:.1f} µs per kernel)",
       f"**{sci(c3['env_steps_per_s'])}** ({c3['ms_per_step'] * 1e3:.2f} µs per step; {sci(c3['env_steps_per_s_ground_truth_wind'])} in the ground-truth wind)",
@@ -50,6 +51,11 @@ def rows(d, s):
       closed_loops(d),
       f"{sci(cpu['value'])}; {sci(cpu['value_single_thread'])}",
   ]
+
+
+def vehicle_leg(c):
+  v = next((x for k, x in c.items() if 'run-time vehicle' in k), None)
+  return 'n/a' if v is None else f"{sci(v['env_steps_per_s'])} ({v['ms_per_step'] * 1e3:.1f} µs per step; {v['live_env_fraction_end']:.3f} of the balloons flying at the end)"
 
 
 def closed_loops(d):
@@ -67,6 +73,7 @@ LABELS = [
     'configs[1]: 4 096 envs (four-wave kernel)',
     '**configs[2]: 65 536 envs (headline)**',
     'configs[2] in the ground-truth wind (noise generated in-kernel)',
+    'configs[2] with a run-time flight vehicle (ABI 5: `ble_step_kernel<VehicleRt>`)',
     'configs[2], one launch per agent step (`ble_step_f32`, policy in the loop)',
     'configs[3]: one GPU\'s share, 8 192 envs (four-wave kernel)',
     'configs[4]: one GPU\'s share, 32 768 envs with per-env grids (four-wave kernel, two waves per SIMD)',
