@@ -17,6 +17,12 @@ import datetime as dt
 import os
 import sys
 
+# One BLAS / OpenMP thread, whatever the caller's environment says: a threaded matrix product sums in an order that depends on the
+# thread count, and the fixtures are held to their generator BYTE for byte (tests/test_golden_reproducible.py) -- F15's float64 MLP and
+# the reference's own GP solves came out one ulp apart between 4 and 8 OpenBLAS threads.  Before NumPy is imported.
+for _var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+  os.environ[_var] = '1'
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -41,6 +41,21 @@ def _arrays(row):
   return {k: np.array([v]) for k, v in row.items()}
 
 
+def _oracle_vector(job):
+  """One 1099-vector of the feature oracle from a snapshot of its history (a 120 x 120 GP fit in NumPy: 66 ms) -- the snapshots of an
+  episode are independent of each other, so a process pool forms them side by side."""
+  import ctypes
+  import features_oracle
+  try:      # the C oracle's OpenMP regions would start one thread per hardware thread in every worker
+    ctypes.CDLL('libgomp.so.1').omp_set_num_threads(1)
+  except OSError:
+    pass
+  field, alpha, locs, errs, row = job
+  fo = features_oracle.FeatureOracle(field, alpha)
+  fo.locs, fo.errs, fo.row = locs, errs, row
+  return fo.features().astype(np.float64)
+
+
 def test_station_seeker_episode_teacher_forced(vec_state):
   g = helpers.golden('f13_station_seeker')
   field = helpers.fixture_field(g)
@@ -50,6 +65,7 @@ def test_station_seeker_episode_teacher_forced(vec_state):
   import features_oracle
   fo = features_oracle.FeatureOracle(field, float(np.float32(g['alpha'][0])))
   worst_obs = 0.0; worst_ref = 0.0; worst_sens = 0.0; worst_state = 0.0; compared = 0
+  jobs, kept = [], []
   for i in range(n):
     row = helpers.feature_row(g, 0, i)
     sim.set_state(_arrays(row))
@@ -63,20 +79,13 @@ def test_station_seeker_episode_teacher_forced(vec_state):
     np.testing.assert_array_equal(unreachable(obs), unreachable(want), err_msg=f'step {i}')
     np.testing.assert_array_equal(obs[8:14], want[8:14], err_msg=f'step {i}')
     # the oracle on the device's own inputs (float32 state and noise): every entry within 1e-5.  The oracle sees every
-    # observation; its 1099-vector (a 120 x 120 GP fit in NumPy: 66 ms) is formed on the first 126 steps -- the window
-    # fills and starts to slide --, then on every 12th step, and on the last 16.
-    fo.observe({k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in row.items()},
-               g['noise_uv'][0, i].astype(np.float32).astype(np.float64))
+    # observation; its 1099-vector is formed on the first 126 steps -- the window fills and starts to slide --, then on every 12th
+    # step, and on the last 16: snapshots of its history now, the vectors from a process pool after the flight.
+    row32 = {k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in row.items()}
+    fo.observe(row32, g['noise_uv'][0, i].astype(np.float32).astype(np.float64))
     if i < 126 or i % 12 == 0 or i >= n - 16:
-      same = fo.features().astype(np.float64)
-      err = np.abs(obs.astype(np.float64) - same)
-      assert err.max() <= 1e-5, (i, err.max(), int(err.argmax()))
-      # the reference's vector directly: 1e-5 + what the float32 rounding of the inputs does to the reference itself
-      sens = np.abs(same - want.astype(np.float64))
-      err_ref = np.abs(obs.astype(np.float64) - want.astype(np.float64))
-      assert (err_ref - sens).max() <= 1e-5, (i, err_ref.max(), int((err_ref - sens).argmax()))
-      worst_obs = max(worst_obs, float(err.max())); worst_ref = max(worst_ref, float(err_ref.max())); worst_sens = max(worst_sens, float(sens.max()))
-      compared += 1
+      jobs.append((field, fo.alpha, [list(v) for v in fo.locs[-130:]], [list(v) for v in fo.errs[-130:]], row32))      # (the 6 h window holds <= 120)
+      kept.append((i, obs.copy(), want.copy()))
     # the transition with the agent's action and the ground-truth wind
     act = torch.tensor([g['actions'][0, i]], dtype=torch.uint8).cuda()
     reward, terminal = sim.step(act, noise)
@@ -89,6 +98,18 @@ def test_station_seeker_episode_teacher_forced(vec_state):
     for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s'):
       assert int(got[k]) == int(g[k][0, i + 1]), (i, k)
     assert abs(float(reward[0]) - g['reward'][0, i]) <= 1e-5 and int(terminal[0]) == 0
+  import multiprocessing as mp
+  with mp.get_context('fork').Pool(min(16, len(jobs))) as pool:
+    vectors = pool.map(_oracle_vector, jobs, chunksize=4)
+  for (i, obs, want), same in zip(kept, vectors):
+    err = np.abs(obs.astype(np.float64) - same)
+    assert err.max() <= 1e-5, (i, err.max(), int(err.argmax()))
+    # the reference's vector directly: 1e-5 + what the float32 rounding of the inputs does to the reference itself
+    sens = np.abs(same - want.astype(np.float64))
+    err_ref = np.abs(obs.astype(np.float64) - want.astype(np.float64))
+    assert (err_ref - sens).max() <= 1e-5, (i, err_ref.max(), int((err_ref - sens).argmax()))
+    worst_obs = max(worst_obs, float(err.max())); worst_ref = max(worst_ref, float(err_ref.max())); worst_sens = max(worst_sens, float(sens.max()))
+    compared += 1
   assert compared >= 200
   print(f'F13 teacher-forced: 960/960 actions equal; on {compared} steps worst |obs diff| {worst_obs:.2e} vs the oracle on the same inputs, '
         f'{worst_ref:.2e} vs the reference (own input-rounding sensitivity {worst_sens:.2e}); worst state rel err {worst_state:.2e}')

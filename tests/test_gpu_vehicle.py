@@ -275,3 +275,32 @@ def test_reference_style_objects_carry_the_vehicle(ble):
   obs, _, _, _ = env.step(1)
   assert env.arena.get_balloon_state().battery_capacity.watt_hours == 2000.0
   assert obs[1] == pytest.approx(env.arena.get_balloon_state().battery_charge.watt_hours / 2000.0, abs=1e-6)      # battery_soc with ITS capacity
+
+
+def test_checkpoint_carries_the_vehicle(ble):
+  """state_dict() / load_state_dict() of a simulator that flies a non-default vehicle: the restored one flies on bit for bit (the vehicle is
+  part of the checkpoint; a fresh simulator would otherwise continue as the default balloon)."""
+  d = golden('f16_vehicles')
+  veh = helpers.fixture_vehicle(d, 1)
+  n, k = 2048, 5
+  field = (np.random.default_rng(21).standard_normal((21, 21, 10, 9, 2)) * 5.0).astype(np.float32)
+  acts = torch.from_numpy(np.random.default_rng(22).integers(0, 3, (2 * k, n)).astype(np.uint8)).cuda()
+  a = ble.VecSimulator(n); a.set_vehicle(**veh); a.set_grid(field); a.reset_device(seed=4)
+  r = torch.zeros(k, n, device='cuda'); t = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
+  a.step_n(acts[:k], r, t, noise_seed=3)
+  ckpt = a.state_dict()
+  assert ckpt['vehicle'] == a.vehicle and set(a.vehicle) == set(veh)
+  b = ble.VecSimulator(n); b.set_grid(field)
+  b.load_state_dict(ckpt)
+  assert b.vehicle == a.vehicle
+  rb = torch.zeros(k, n, device='cuda'); tb = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
+  a.step_n(acts[k:], r, t, noise_seed=3); b.step_n(acts[k:], rb, tb, noise_seed=3)
+  torch.cuda.synchronize(); a.check_errors(); b.check_errors()
+  assert torch.equal(r, rb) and torch.equal(t, tb)
+  sa, sb = a.get_state(), b.get_state()
+  for name in sa:
+    np.testing.assert_array_equal(sa[name], sb[name], err_msg=name)
+  c = ble.VecSimulator(n); c.set_grid(field); c.load_state_dict(dict(ckpt, vehicle={}))      # the same state flown as the default balloon goes elsewhere
+  rc = torch.zeros(k, n, device='cuda'); tc = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
+  c.step_n(acts[k:], rc, tc, noise_seed=3); torch.cuda.synchronize()
+  assert not np.array_equal(c.get_state()['pressure'], sa['pressure'])
