@@ -133,9 +133,10 @@ class VecSimulator:
     envelope_max_superpressure, envelope_cod, payload_mass, nighttime_power_load_w, daytime_power_load_w,
     acs_valve_hole_diameter_m, battery_capacity_wh), mols_lift_gas (:183) and power_safety_layer_enabled (:200), by keyword;
     what is not named keeps the reference's default.  No argument (or all defaults): the kernels with compile-time constants
-    (ble_state_f32.vehicle == NULL).  Takes effect with the next launch, prepared launches and captured graphs included
-    (they read the struct this updates) -- except that a captured graph holds the KERNEL it captured: re-capture after
-    switching between the default vehicle and another one."""
+    (ble_state_f32.vehicle == NULL).  Takes effect with the next call of an entry point, launches prepared by prepare_step_n
+    included (they call the entry point, which reads the struct this updates).  A captured HIP graph does NOT see it: the
+    entry point derived the vehicle's constants and chose the kernel when the graph was recorded -- capture again after
+    set_vehicle (BalloonArena does so itself; VecBalloonEnv.capture_graph is the caller's)."""
     veh = _abi.vehicle_struct(**fields)
     _abi.set_vehicle(self._struct, veh)
     self.vehicle = {} if veh is None else {k: getattr(veh, k) for k in _abi.VEHICLE_DEFAULTS if getattr(veh, k) != _abi.VEHICLE_DEFAULTS[k]}
@@ -320,6 +321,7 @@ class VecSimulator:
     gen = _abi.BleNoiseGen(int(noise_seed) & (2 ** 64 - 1), self.episode.data_ptr(), self._noise_cache.data_ptr(), self.env_offset)
     if prepared:          # a prepared launch keeps its generator: load_state_dict re-keys it when the shard offset changes
       self._noise_gens.append(gen)
+      del self._noise_gens[:-4096]          # (bounded: a long-lived simulator may prepare launches again and again)
     return gen
 
   @_on_own_device
