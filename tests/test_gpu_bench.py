@@ -80,6 +80,25 @@ def test_bench_gpus_2_default_legs_run_sharded():
   assert 'cpu_baseline' not in out                                            # rank 0 at N = 1 only
 
 
+def test_bench_gpus_8_every_leg_with_eight_ranks():
+  """The driver's 8-GPU command shape with EIGHT ranks -- the node size the scaling run uses -- on the box's one GPU over gloo, small
+  batches: the rank / offset arithmetic (contiguous shards of the global index range), the eight-way gathers and all_to_all, the per-rank
+  decomposition and every default leg run with world = 8, not only with 2."""
+  out = _bench(['--gpus', '8', '--steps', '20', '--warmup', '5', '--reps', '3', '--observe', '2', '--envs-per-gpu', '1024'],
+               {'BLE_DIST_BACKEND': 'gloo', 'BLE_BENCH_SIDE_ENVS': '1024', 'BLE_BENCH_SIDE_STEPS': '32', 'OMP_NUM_THREADS': '2'}, timeout=900)
+  assert out['n_gpus'] == 8 and out['config']['envs_per_gpu'] == 1024 and out['config']['global_envs'] == 8192 and out['scaling'] == 'weak'
+  ex = out['config']['exchanges']
+  assert ex['gathers_per_timed_region'] == 3 and ex['agent_step_rows_gathered_per_timed_region'] == 20
+  assert len(out['per_rank']['kernel_us_per_timed_region']) == 8 and min(out['per_rank']['kernel_us_per_timed_region']) > 0
+  modes = out['observe']['exchange_modes']
+  assert set(modes) == {'gather', 'all_to_all', 'local'} and modes['all_to_all']['bytes_per_link'] == 1024 * 1099 * 4 // 8
+  keys = ' '.join(out['configs'])
+  assert 'configs[3]' in keys and 'configs[4]' in keys and out['config']['ground_truth_wind']['global_envs'] == 8192
+  for k, v in out['configs'].items():
+    if k.startswith('configs[3]') or k.startswith('configs[4]'):
+      assert v['global_envs'] == 8 * 1024 and v['env_steps_per_s'] > 1e5, k
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
   env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras'],
