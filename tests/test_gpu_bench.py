@@ -99,6 +99,28 @@ def test_bench_gpus_8_every_leg_with_eight_ranks():
       assert v['global_envs'] == 8 * 1024 and v['env_steps_per_s'] > 1e5, k
 
 
+def test_bench_under_the_drivers_launcher_command():
+  """The driver's own N > 1 command line, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  --master-port P bench.py --gpus N --steps K --warmup W` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's environment), N = 2
+  on the box's one GPU over gloo."""
+  import socket
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device; none visible')
+  sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+  env = dict(os.environ, BLE_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                      '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '3',
+                      '--no-extras', '--envs-per-gpu', '4096'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+  out = json.loads(lines[0])
+  assert out['n_gpus'] == 2 and out['steps'] == 20 and out['warmup'] == 5 and out['config']['global_envs'] == 8192
+  assert out['value'] > 1e6 and out['config']['exchanges']['agent_step_rows_gathered_per_timed_region'] == 20
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
   env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras'],
