@@ -21,7 +21,7 @@
 // the sun of stride 0 with it); the safety layers publish their action MAPS (a layer is a function of the action alone once
 // its state machine has moved).  With a wind-noise generator (ABI 3) a step starts with the ten harmonic values, one 4-D
 // simplex evaluation each, spread over the waves, and one more barrier.  The same template runs as TWO wavefronts per
-// environment ({vertical, thermal} | {sun + envelope, ACS + power}: ble_step_pair_kernel, an experiment knob).
+// environment ({vertical, thermal} | {sun + envelope, ACS + power}: ble_step_pair_kernel, experiment builds only -- -DBLE_WITH_PAIR_FORM).
 // Between agent steps every value goes through float32, exactly where ble_step_kernel keeps its state as float32.
 //
 // The stride loops are straight-line: a lane whose episode ended (or was over on entry) keeps computing on a shadow of its
