@@ -304,3 +304,85 @@ def test_checkpoint_carries_the_vehicle(ble):
   rc = torch.zeros(k, n, device='cuda'); tc = torch.zeros(k, n, dtype=torch.uint8, device='cuda')
   c.step_n(acts[k:], rc, tc, noise_seed=3); torch.cuda.synchronize()
   assert not np.array_equal(c.get_state()['pressure'], sa['pressure'])
+
+
+def test_random_vehicles_every_env_matches_oracle(ble):
+  """Eight vehicles drawn at random inside +-20 % of the reference's constants (every field varied at once, the power layer on or off), 2 048
+  environments each: the vehicle's own cold start on the device (every environment against the oracle's), then two agent steps with random
+  actions in a grid wind, every environment against the oracle from the device's own pre-step state -- 1e-5, discrete exact."""
+  from balloon_learning_environment_amd import _abi
+  rng = np.random.default_rng(2026)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 6.0).astype(np.float32)
+  n = 2048
+  checked = 0
+  for trial in range(8):
+    veh = {k: float(v * rng.uniform(0.8, 1.2)) for k, v in _abi.VEHICLE_DEFAULTS.items() if k != 'power_safety_layer_enabled'}
+    veh['power_safety_layer_enabled'] = int(trial % 2)
+    sim = ble.VecSimulator(n)
+    sim.set_vehicle(**veh)
+    sim.set_grid(field)
+    sim.reset_device(seed=100 + trial)
+    torch.cuda.synchronize(); sim.check_errors()
+    st = sim.get_state()
+    out, err = oracle.stable_init(st['pressure'], st['center_lat_deg'], st['center_lng_deg'], st['x'], st['y'], st['start_unix'],
+                                  st['upwelling_infrared'], st['alpha'], vehicle=veh)
+    for key, v in out.items():
+      assert rel_err(st[key], v, FLOORS[key]).max() <= RTOL, (trial, key)
+    # the sampler's pressures suit the reference's vehicle: some of these start burst / deflated -- the transition must say so exactly like the oracle
+    for step in range(2):
+      before = sim.get_state()
+      live = before['status'] == 0
+      acts = rng.integers(0, 3, n).astype(np.uint8)
+      reward, terminal = sim.step(torch.from_numpy(acts).cuda())
+      torch.cuda.synchronize(); sim.check_errors()
+      got = sim.get_state()
+      o = oracle_state_from_abi({k: v[live] for k, v in before.items()})
+      ro, to, eo, err = oracle.step(o, acts[live], field=field, vehicle=veh)
+      assert err == 0
+      compare_states({k: v[live] for k, v in got.items()}, o, ctx=f'vehicle trial {trial} step {step}')
+      np.testing.assert_array_equal(sim.effective_action.cpu().numpy()[live], eo)
+      np.testing.assert_array_equal(terminal.cpu().numpy()[live], to)
+      np.testing.assert_allclose(reward.cpu().numpy()[live], ro, rtol=RTOL, atol=RTOL)
+      checked += int(live.sum())
+  assert checked > 20000
+
+
+def test_random_vehicles_observation_matches_oracle(ble):
+  """The observation of three random vehicles (as above), six environments each flown and observed for four steps: every 1099-vector
+  against the feature oracle with the same vehicle on the device's own float32 state."""
+  import features_oracle
+  from balloon_learning_environment_amd import _abi
+  from test_gpu_observe import check
+  rng = np.random.default_rng(77)
+  field = (rng.standard_normal((21, 21, 10, 9, 2)) * 6.0).astype(np.float32)
+  n = 6
+  compared = 0
+  for trial in range(3):
+    veh = {k: float(v * rng.uniform(0.85, 1.15)) for k, v in _abi.VEHICLE_DEFAULTS.items() if k != 'power_safety_layer_enabled'}
+    veh['power_safety_layer_enabled'] = int(trial % 2)
+    sim = ble.VecSimulator(n)
+    sim.set_vehicle(**veh); sim.set_grid(field); sim.reset_device(seed=500 + trial)
+    alpha = sim.state['alpha'].cpu().numpy().astype(np.float64)
+    oracles = [features_oracle.FeatureOracle(field, alpha[j], vehicle=veh) for j in range(n)]
+    for i in range(4):
+      if i > 0:
+        sim.step(torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda())
+      noise = (rng.standard_normal((n, 2)) * 1.5).astype(np.float32)
+      obs = sim.observe(torch.from_numpy(noise).cuda()).cpu().numpy()
+      sim.check_errors()
+      state = sim.get_state()
+      for j in range(n):
+        row = {k: float(state[k][j]) for k in STATE_FLOATS}
+        for k in ('center_lat_deg', 'center_lng_deg', 'upwelling_infrared', 'alpha'):
+          row[k] = float(state[k][j])
+        for k in ('status', 'last_command', 'alt_fsm', 'env_fsm', 'power_paused', 'time_elapsed_s', 'start_unix'):
+          row[k] = int(state[k][j])
+        oracles[j].observe(row, noise[j].astype(np.float64))
+        if state['status'][j] == 0:
+          try:
+            want = oracles[j].features()
+          except ValueError:        # the reference raises ("no safe pressure") for a vehicle that cannot float anywhere in the band: the device flags it
+            continue
+          check(obs[j], want, f'vehicle trial {trial} env {j} step {i}')
+          compared += 1
+  assert compared >= 40, compared
